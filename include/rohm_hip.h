@@ -1,0 +1,140 @@
+/*
+ * rohm_hip.h -- C ABI of librohm_hip.so, the MI355X (gfx950) native library behind
+ * RoHM's iterative-denoising hot path.
+ *
+ * The reference (sanweiliti/RoHM) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md §8b); each entry point below names the reference function (file:line
+ * under the RoHM tree) whose arithmetic it replaces.  The Python host side
+ * (rohm_amd/) binds these through ctypes and mirrors the reference's classes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; rohm_last_error() returns a
+ *     thread-local message.  Nothing throws or aborts across the boundary.
+ *   - all tensor arguments are DEVICE pointers to contiguous fp32 (int64 for
+ *     timesteps) owned by the caller; the library never allocates inside a
+ *     forward/step call: scratch comes from the caller's workspace
+ *     (*_workspace_bytes).  Weights are copied and re-laid-out at *_create time, so
+ *     the caller may free its copies afterwards.
+ *   - every launch goes on the caller-supplied hipStream_t (passed as void*);
+ *     no hidden device synchronisation.
+ *   - handles are immutable after create; calls are re-entrant across streams given
+ *     distinct workspaces.  One handle per device.
+ */
+#ifndef ROHM_HIP_H
+#define ROHM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROHM_OK 0
+#define ROHM_ERR_ARG (-1)
+#define ROHM_ERR_HIP (-2)
+#define ROHM_ERR_WORKSPACE (-3)
+#define ROHM_ERR_UNSUPPORTED (-4)
+
+typedef void* rohm_stream_t; /* hipStream_t */
+
+const char* rohm_last_error(void);
+int rohm_version(void);
+
+/* ------------------------------------------------------------------ building blocks
+ * Exposed so that each kernel can be parity-tested and profiled on its own.        */
+
+/* C[M,N] = epi(A[M,K] . W[N,K]^T): the fp32-MFMA GEMM every Linear of the path runs
+ * on (nn.Linear in model/heads.py:154,169, nn.TransformerEncoderLayer in
+ * model/posenet.py:63-69).  A, W row-major with K contiguous (lda/ldw in floats,
+ * multiples of 4, 16-byte aligned); K a multiple of 32; M, N arbitrary.
+ * epi: 0 = +bias, 1 = +bias, exact-erf GELU, 2 = +bias +R[M,N](ldr).
+ * bias may be NULL. */
+int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N,
+                  int K, const float* bias, const float* R, int ldr, int epi, rohm_stream_t stream);
+
+/* In-place LayerNorm over the last dimension of x[M,D] (D == 512 or 256), eps 1e-5, biased
+ * variance, affine -- nn.LayerNorm inside nn.TransformerEncoderLayer (model/posenet.py:63-69). */
+int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, int D,
+                       rohm_stream_t stream);
+
+/* Multi-head self-attention over S = 144 tokens, head dim 128, for n_seq sequences:
+ * qkv[n_seq*144, 3*n_head*128] (q | k | v blocks, q already scaled by 128^-1/2)
+ * -> ctx[n_seq*144, n_head*128].  Replaces the scaled-dot-product inside
+ * nn.MultiheadAttention (model/posenet.py:63-69). */
+int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, rohm_stream_t stream);
+
+/* One DDPM ancestral update, elementwise over n floats:
+ *   x_prev = c1*x0 + c2*x_t + guid_scale*guid_grad + sigma*noise
+ * = q_posterior_mean_variance + p_sample[_with_grad]
+ * (diffusion/gaussian_diffusion_posenet.py:212-234,426-434,466-479).  guid_grad may be NULL;
+ * noise may be NULL when sigma == 0 (t == 0).  x_prev may alias x_t. */
+int rohm_ddpm_step(const float* x_t, const float* x0, const float* noise, const float* guid_grad,
+                   float c1, float c2, float sigma, float guid_scale, float* x_prev, size_t n,
+                   rohm_stream_t stream);
+
+/* Same update with per-sample timesteps and device-resident schedule tables (no host sync):
+ *   tables [n_steps, 4] fp32 rows = {posterior_mean_coef1, posterior_mean_coef2,
+ *                                     posterior_variance, posterior_log_variance_clipped}
+ *   t      int64[B]   timestep of each sample (row of `tables`)
+ *   x_prev[b] = c1*x0 + c2*x_t + var*(w_a*grad_a + w_b*grad_b) + [t_b != 0]*exp(0.5*logvar)*noise
+ * over `row_len` floats per sample.  grad_a / grad_b may be NULL.  This is exactly
+ * p_sample_with_grad (diffusion/gaussian_diffusion_posenet.py:436-480) after the network call. */
+int rohm_ddpm_step_table(const float* x_t, const float* x0, const float* noise, const float* grad_a,
+                         float w_a, const float* grad_b, float w_b, const float* tables,
+                         const int64_t* t, int n_steps, float* x_prev, int B, size_t row_len,
+                         rohm_stream_t stream);
+
+/* ------------------------------------------------------------------------- PoseNet
+ * model/posenet.py:12-96 + model/heads.py:112-176.                                   */
+typedef struct rohm_posenet rohm_posenet_t;
+
+typedef struct {
+    const float *in_proj_w, *in_proj_b;   /* [3D, D], [3D]   self_attn.in_proj_*      */
+    const float *out_proj_w, *out_proj_b; /* [D, D], [D]     self_attn.out_proj.*     */
+    const float *lin1_w, *lin1_b;         /* [F, D], [F]     linear1.*                */
+    const float *lin2_w, *lin2_b;         /* [D, F], [D]     linear2.*                */
+    const float *norm1_w, *norm1_b;       /* [D]             norm1.*                  */
+    const float *norm2_w, *norm2_b;       /* [D]             norm2.*                  */
+} rohm_posenet_layer_weights;
+
+typedef struct {
+    const float *in_x_w, *in_x_b; /* [D, C_in], [D]  input_process.poseEmbedding.*         */
+    const float *in_c_w, *in_c_b; /* [D, C_in], [D]  input_process_cond.poseEmbedding.*    */
+    const float* pe;              /* [pe_len, D]     sequence_pos_encoder.pe (squeezed)    */
+    int pe_len;
+    const float *t_w0, *t_b0;     /* [D, D], [D]     embed_timestep.time_embed.0.*         */
+    const float *t_w2, *t_b2;     /* [D, D], [D]     embed_timestep.time_embed.2.*         */
+    const float *out_w, *out_b;   /* [C_out, D], [C_out]  output_process.poseFinal.*       */
+    const rohm_posenet_layer_weights* layers; /* [n_layer] */
+} rohm_posenet_weights;
+
+/* Weight pointers may be host or device memory (copied with hipMemcpyDefault). */
+int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int d_model, int n_head,
+                        int d_ff, int n_layer, int c_in, int c_out, int traj_dim, int device);
+void rohm_posenet_destroy(rohm_posenet_t* h);
+size_t rohm_posenet_workspace_bytes(const rohm_posenet_t* h, int B, int T);
+
+/* PoseNet.forward (model/posenet.py:75-96): x_t, cond [B, C_in, 1, T] contiguous, t int64[B]
+ * -> x0_out [B, C_in, 1, T] (channels < traj_dim copied from cond, the C_out others predicted). */
+int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float* cond, const int64_t* t,
+                         float* x0_out, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
+
+/* Device-resident DDPM loop without guidance: p_sample_loop over `n_steps` descending timesteps
+ * (diffusion/gaussian_diffusion_posenet.py:578-662, 388-434).
+ *   x        [B, C_in, 1, T]  in: x_T, out: final sample (x_{-1})
+ *   cond     [B, C_in, 1, T]
+ *   t_model  int64[n_steps]   timestep fed to the network at loop step i (after timestep_map)
+ *   coef     float[n_steps*3] per loop step: posterior_mean_coef1, posterior_mean_coef2,
+ *                             sigma = exp(0.5*posterior_log_variance_clipped) (0 when t == 0)
+ *   noise    [n_steps, B, C_in, 1, T] injected Gaussian noise (row i used at loop step i)
+ *   x0_last  optional [B, C_in, 1, T]: pred_xstart of the last executed step (early_stop result)
+ * All per-step scalars are host arrays (the loop is driven from the host, kernels stay async). */
+int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* cond, const int64_t* t_model,
+                             const float* coef, const float* noise, float* x0_last, int n_steps, int B,
+                             int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROHM_HIP_H */

@@ -1,0 +1,101 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+    python -m oracle.make_golden
+
+The reference (/root/reference) is imported with the cv2/smplx stubs of oracle/refload.py; weights and
+inputs come from rohm_amd.utils.synth (seeded, reproducible), so a fixture stores only seeds and the
+reference's outputs.  The committed fixtures pin (a) the oracle restatement (CPU tests) and (b) the HIP
+path (GPU tests) to what the reference computes.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refload  # noqa: E402
+from rohm_amd.utils import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+class _DS:
+    pose_feat_dim = 272
+    traj_feat_dim = 22
+
+
+def seeded(seed, *shape):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.standard_normal(size=shape).astype(np.float32))
+
+
+class _Args:
+    noise_schedule = 'cosine'
+    sigma_small = True
+
+
+def main():
+    warnings.filterwarnings('ignore')
+    os.makedirs(OUT, exist_ok=True)
+    ref = refload.load()
+    torch.set_num_threads(8)
+
+    # ---- PoseNet forward, full config, B=2 -------------------------------------------------------
+    sd = synth.posenet_state_dict(seed=11)
+    net = ref.posenet.PoseNet(_DS(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4,
+                              traj_feat_dim=22, device='cpu').eval()
+    net.load_state_dict(sd, strict=True)
+    x, c = seeded(101, 2, 294, 1, 143), seeded(102, 2, 294, 1, 143)
+    t = torch.tensor([999, 7])
+    with torch.no_grad():
+        y = net({'x_t': x, 'cond': c}, t)
+    np.savez_compressed(os.path.join(OUT, 'posenet_forward.npz'), weight_seed=11, x_seed=101, cond_seed=102,
+                        t=t.numpy(), y=y.numpy())
+
+    # ---- PoseNet 8-step DDPM loop (reference SpacedDiffusionPoseNet, CPU generator noise) ----------
+    diff = ref.model_util.create_gaussian_diffusion(_Args, ref.gd_posenet, ref.respace.SpacedDiffusionPoseNet,
+                                                    8, '', device='cpu')
+    batch = {'cond': seeded(103, 2, 294, 1, 143)}
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        _, y = diff.eval_losses(model=net, batch=batch, shape=[2, 294, 1, 143], progress=False,
+                                clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
+                                compute_loss=False)
+    np.savez_compressed(os.path.join(OUT, 'posenet_loop8.npz'), weight_seed=11, cond_seed=103, torch_seed=1234,
+                        steps=8, y=y.numpy())
+
+    # ---- TrajNet forward, vanilla and TrajControl ---------------------------------------------------
+    for ctrl in (False, True):
+        sdt = synth.trajnet_state_dict(seed=21 + ctrl, trajcontrol=ctrl)
+        tn = ref.trajnet.TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=ctrl).eval()
+        tn.load_state_dict(sdt, strict=True)
+        x, c, cc = seeded(201, 2, 144, 13), seeded(202, 2, 144, 13), seeded(203, 2, 144, 272)
+        t = torch.tensor([99, 3])
+        with torch.no_grad():
+            y = tn({'x_t': x, 'cond': c, 'control_cond': cc}, t)
+        name = 'trajnet_control_forward.npz' if ctrl else 'trajnet_forward.npz'
+        np.savez_compressed(os.path.join(OUT, name), weight_seed=21 + ctrl, x_seed=201, cond_seed=202,
+                            control_seed=203, t=t.numpy(), y=y.numpy())
+        # 100-step loop, B=1 (BASELINE config 1 shape)
+        if not ctrl:
+            d = ref.model_util.create_gaussian_diffusion(_Args, ref.gd_trajnet, ref.respace.SpacedDiffusionTrajNet,
+                                                         100, '', device='cpu')
+            batch = {'cond': seeded(204, 1, 144, 13)}
+            torch.manual_seed(4321)
+            with torch.no_grad():
+                _, y = d.eval_losses(model=tn, batch=batch, shape=[1, 144, 13], progress=False,
+                                     clip_denoised=False, timestep_respacing='', cond_fn_with_grad=True,
+                                     compute_loss=False)
+            np.savez_compressed(os.path.join(OUT, 'trajnet_loop100.npz'), weight_seed=21, cond_seed=204,
+                                torch_seed=4321, steps=100, y=y.numpy())
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,108 @@
+"""ctypes binding of librohm_hip.so (the C ABI in include/rohm_hip.h).
+
+There is no CPU fallback: if the library is missing, or a tensor is not on a HIP device,
+the call raises.  Build the library with `python -m rohm_amd.build`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librohm_hip.so')
+
+c_float_p = C.POINTER(C.c_float)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class RohmHipError(RuntimeError):
+    pass
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b',
+        'norm1_w', 'norm1_b', 'norm2_w', 'norm2_b')]
+
+
+class PoseNetWeights(C.Structure):
+    _fields_ = [('in_x_w', C.c_void_p), ('in_x_b', C.c_void_p), ('in_c_w', C.c_void_p), ('in_c_b', C.c_void_p),
+                ('pe', C.c_void_p), ('pe_len', C.c_int),
+                ('t_w0', C.c_void_p), ('t_b0', C.c_void_p), ('t_w2', C.c_void_p), ('t_b2', C.c_void_p),
+                ('out_w', C.c_void_p), ('out_b', C.c_void_p),
+                ('layers', C.POINTER(LayerWeights))]
+
+
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol declared in include/rohm_hip.h
+SIGNATURES = {
+    'rohm_last_error': (C.c_char_p, []),
+    'rohm_version': (C.c_int, []),
+    'rohm_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'rohm_layernorm_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'rohm_attention_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'rohm_ddpm_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'rohm_ddpm_step_table': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_size_t, C.c_void_p]),
+    'rohm_posenet_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(PoseNetWeights), C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'rohm_posenet_destroy': (None, [C.c_void_p]),
+    'rohm_posenet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'rohm_posenet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'rohm_posenet_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                           C.c_void_p]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RohmHipError(
+                f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
+                f'Build it with `python -m rohm_amd.build` (needs hipcc, --offload-arch=gfx950).')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().rohm_last_error()
+        raise RohmHipError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RohmHipError('rohm_amd kernels need tensors on a HIP device (got CPU tensor); '
+                           'there is no CPU fallback')
+    if not t.is_contiguous():
+        raise RohmHipError('rohm_amd kernels need contiguous tensors')
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RohmHipError('this operator only runs on an AMD GPU through librohm_hip.so; '
+                               'got a CPU tensor and there is deliberately no CPU fallback')

@@ -1,0 +1,61 @@
+"""Build librohm_hip.so (gfx950) in-tree with hipcc.
+
+`python -m rohm_amd.build` or `rohm_amd.build.build()`; `__graft_entry__.build()` calls this.
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU
+box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'librohm_hip.so')
+ARCH = 'gfx950'
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def _deps():
+    return sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
+        glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in _deps())
+
+
+def find_hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def build(force=False, verbose=True):
+    if not force and not is_stale():
+        return LIB
+    hipcc = find_hipcc()
+    if hipcc is None:
+        raise RuntimeError('hipcc not found: cannot build librohm_hip.so')
+    cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-Wno-unused-result', '-o', LIB + '.tmp'] + sources()
+    if verbose:
+        print('[rohm_amd.build]', ' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(LIB + '.tmp', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,61 @@
+// C-ABI glue: error channel + the building-block entry points declared in include/rohm_hip.h.
+#include <string>
+#include "common.h"
+
+namespace rohm {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+}  // namespace rohm
+
+using namespace rohm;
+
+extern "C" {
+
+const char* rohm_last_error(void) { return g_err.c_str(); }
+int rohm_version(void) { return 100; }
+
+int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                  const float* bias, const float* R, int ldr, int epi, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(A && W && C, "gemm: null pointer");
+    ROHM_ARG_CHECK(epi >= EPI_BIAS && epi <= EPI_BIAS_RES, "gemm: public epilogues are 0..2 (got %d)", epi);
+    ROHM_ARG_CHECK(epi != EPI_BIAS_RES || R, "gemm: epilogue 2 needs a residual");
+    GemmParams g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.R = R; g.ldr = ldr;
+    return launch_gemm(g, epi, (hipStream_t)stream);
+}
+
+int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, int D, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(x && gamma && beta, "layernorm: null pointer");
+    return launch_layernorm(x, gamma, beta, M, D, (hipStream_t)stream);
+}
+
+int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(qkv && ctx, "attention: null pointer");
+    return launch_attention(qkv, ctx, n_seq, n_head, (hipStream_t)stream);
+}
+
+int rohm_ddpm_step(const float* x_t, const float* x0, const float* noise, const float* guid_grad, float c1,
+                   float c2, float sigma, float guid_scale, float* x_prev, size_t n, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(x_t && x0 && x_prev, "ddpm_step: null pointer");
+    ROHM_ARG_CHECK(sigma == 0.f || noise, "ddpm_step: noise required when sigma != 0");
+    return launch_ddpm_step(x_t, x0, noise, guid_grad, c1, c2, sigma, guid_scale, x_prev, n, (hipStream_t)stream);
+}
+
+int rohm_ddpm_step_table(const float* x_t, const float* x0, const float* noise, const float* grad_a, float w_a,
+                         const float* grad_b, float w_b, const float* tables, const int64_t* t, int n_steps,
+                         float* x_prev, int B, size_t row_len, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(x_t && x0 && x_prev && tables && t, "ddpm_step_table: null pointer");
+    ROHM_ARG_CHECK(n_steps > 0, "ddpm_step_table: empty schedule");
+    return launch_ddpm_step_table(x_t, x0, noise, grad_a, w_a, grad_b, w_b, tables, t, n_steps, x_prev, B, row_len,
+                                  (hipStream_t)stream);
+}
+
+}  // extern "C"

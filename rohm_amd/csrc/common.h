@@ -1,0 +1,93 @@
+// Shared helpers for librohm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/rohm_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace rohm {
+
+void set_error(const char* fmt, ...);
+
+#define ROHM_HIP_CHECK(expr)                                                             \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            rohm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                   \
+            return ROHM_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+#define ROHM_LAUNCH_CHECK()                                                              \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess) {                                                          \
+            rohm::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),   \
+                            __FILE__, __LINE__);                                         \
+            return ROHM_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+#define ROHM_ARG_CHECK(cond, ...)                                                        \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            rohm::set_error(__VA_ARGS__);                                                \
+            return ROHM_ERR_ARG;                                                         \
+        }                                                                                \
+    } while (0)
+
+constexpr int kNumXCD = 8;
+
+// Bijective XCD-aware remap of a linear workgroup id (guide §5 "XCD swizzle must be
+// bijective"): hardware places block b on XCD b % 8; we hand each XCD a contiguous run of
+// logical tiles so neighbouring tiles (which share an A panel) share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid % kNumXCD;
+    const int q = nwg / kNumXCD, r = nwg % kNumXCD;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + bid / kNumXCD;
+}
+
+// ---- GEMM (gemm_f32.hip) ---------------------------------------------------------------
+enum GemmEpi {
+    EPI_BIAS = 0,        // C = acc + bias[n]
+    EPI_BIAS_GELU = 1,   // C = gelu_erf(acc + bias[n])
+    EPI_BIAS_RES = 2,    // C = acc + bias[n] + R[m][n]
+    EPI_QKV = 3,         // C = (acc + bias[n]) * (n < qcols ? qscale : 1)
+    EPI_EMBED = 4,       // token-major embed: tok = m % S; tok==0 ? tab0[m/S][n] : acc + tab[tok][n]
+    EPI_OUT_T = 5,       // transposed store of the output head (see posenet.hip)
+};
+
+struct GemmParams {
+    const float* A; int lda;
+    const float* W; int ldw;
+    float* C; int ldc;
+    int M, N, K;
+    const float* bias;
+    const float* R; int ldr;
+    // EPI_QKV
+    int qcols; float qscale;
+    // EPI_EMBED
+    int S; const float* tab; const float* tab0; int ldtab; int ldtab0;
+    // EPI_OUT_T: rows = output channels (M = c_out), cols = tokens n -> (b = n / S, tok = n % S);
+    // writes out[b][ch_off + m][tok-1] for tok >= 1 (T = S - 1 frames).
+    int ch_off; int C_total; int T;
+};
+
+int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
+
+// ---- other kernels -----------------------------------------------------------------------
+int launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
+int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, hipStream_t s);
+int launch_ddpm_step(const float* x_t, const float* x0, const float* noise, const float* grad, float c1,
+                     float c2, float sigma, float gscale, float* out, size_t n, hipStream_t s);
+
+int launch_ddpm_step_table(const float* x_t, const float* x0, const float* noise, const float* ga, float wa,
+                           const float* gb, float wb, const float* tables, const int64_t* t, int n_steps,
+                           float* out, int B, size_t row_len, hipStream_t s);
+
+}  // namespace rohm

@@ -1,0 +1,128 @@
+// Bandwidth-bound helpers of the PoseNet step: LayerNorm, layout pack, timestep token, DDPM update.
+// All are vectorised to 16 B per lane and sized so that >> 256 workgroups are in flight.
+#include "common.h"
+
+namespace rohm {
+
+// ------------------------------------------------------------------------------ LayerNorm
+// One wave per row, whole row in registers (two-pass mean / variance like torch's CPU kernel):
+// nn.LayerNorm(eps=1e-5) inside nn.TransformerEncoderLayer, post-norm (model/posenet.py:63-69).
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, int M) {
+    constexpr int V = D / 256;   // float4 per lane
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float* xr = x + (size_t)row * D;
+    f32x4 v[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[i][j] - mean;
+            q += d * d;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + (i * 64 + lane) * 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + (i * 64 + lane) * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+        *reinterpret_cast<f32x4*>(xr + (i * 64 + lane) * 4) = o;
+    }
+}
+
+int launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s) {
+    ROHM_ARG_CHECK(M > 0, "layernorm: empty");
+    const dim3 grid((M + 3) / 4), block(256);
+    if (D == 512) hipLaunchKernelGGL(layernorm_kernel<512>, grid, block, 0, s, x, g, b, M);
+    else if (D == 256) hipLaunchKernelGGL(layernorm_kernel<256>, grid, block, 0, s, x, g, b, M);
+    else if (D == 1024) hipLaunchKernelGGL(layernorm_kernel<1024>, grid, block, 0, s, x, g, b, M);
+    else { set_error("layernorm: unsupported D=%d", D); return ROHM_ERR_UNSUPPORTED; }
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+// ------------------------------------------------------------------------------ DDPM update
+// x_prev = c1*x0 + c2*x_t + gscale*grad + sigma*noise
+// (q_posterior_mean_variance + p_sample, diffusion/gaussian_diffusion_posenet.py:212-234,426-434).
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* x_t, const float* __restrict__ x0,
+                                                        const float* __restrict__ noise,
+                                                        const float* __restrict__ grad, float c1, float c2,
+                                                        float sigma, float gscale, float* out,
+                                                        size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = c1 * x0[i] + c2 * x_t[i];
+        if (grad) v += gscale * grad[i];
+        if (noise) v += sigma * noise[i];
+        out[i] = v;
+    }
+}
+
+int launch_ddpm_step(const float* x_t, const float* x0, const float* noise, const float* grad, float c1,
+                     float c2, float sigma, float gscale, float* out, size_t n, hipStream_t s) {
+    if (n == 0) return ROHM_OK;
+    if (sigma == 0.f) noise = nullptr;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x_t, x0, noise, grad, c1, c2,
+                       sigma, gscale, out, n);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+
+// Per-sample timesteps, schedule tables on the device (p_sample_with_grad without a host sync).
+__global__ __launch_bounds__(256) void ddpm_step_table_kernel(const float* x_t, const float* __restrict__ x0,
+                                                              const float* __restrict__ noise,
+                                                              const float* __restrict__ ga, float wa,
+                                                              const float* __restrict__ gb, float wb,
+                                                              const float* __restrict__ tables,
+                                                              const int64_t* __restrict__ t, int n_steps,
+                                                              float* out, size_t row_len) {
+    const int b = blockIdx.y;
+    int64_t tb = t[b];
+    tb = tb < 0 ? 0 : (tb >= n_steps ? n_steps - 1 : tb);
+    const float c1 = tables[tb * 4 + 0], c2 = tables[tb * 4 + 1], var = tables[tb * 4 + 2];
+    const float sigma = (tb != 0) ? expf(0.5f * tables[tb * 4 + 3]) : 0.f;
+    const size_t base = (size_t)b * row_len;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_len; i += stride) {
+        const size_t k = base + i;
+        float v = c1 * x0[k] + c2 * x_t[k];
+        if (ga) v += wa * var * ga[k];
+        if (gb) v += wb * var * gb[k];
+        if (noise) v += sigma * noise[k];
+        out[k] = v;
+    }
+}
+
+int launch_ddpm_step_table(const float* x_t, const float* x0, const float* noise, const float* ga, float wa,
+                           const float* gb, float wb, const float* tables, const int64_t* t, int n_steps,
+                           float* out, int B, size_t row_len, hipStream_t s) {
+    if (B <= 0 || row_len == 0) return ROHM_OK;
+    size_t bx = (row_len + 255) / 256;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(ddpm_step_table_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, s, x_t, x0, noise, ga,
+                       wa, gb, wb, tables, t, n_steps, out, row_len);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+}  // namespace rohm

@@ -1,0 +1,424 @@
+// PoseNet on MI355X: handle, forward (model/posenet.py:75-96) and the device-resident DDPM loop
+// (diffusion/gaussian_diffusion_posenet.py:578-662).
+//
+// Data layout in HBM.  The reference keeps activations sequence-first [S, B, D] and pays a permute
+// copy around every block (41 % of its CPU time).  Here everything between the input
+// embed and the output head is TOKEN-MAJOR: row m = b*S + tok of a [B*S, D] matrix, S = T + 1 tokens,
+// token 0 = timestep token (posenet.py:90).  A clip is 144 consecutive rows = exactly one GEMM
+// M-tile and one attention workgroup per head.
+//
+// Per step:  pack(x_t | cond) -> [B*S, 608]   (transpose of the [B, C, 1, T] motion tensor)
+//            timestep token    -> tab0[B, D]  (heads.py:145-146, + pe[0])
+//            embed GEMM  K=608 (= 294 + 294 + pad; both InputProcess Linears fused), + pe
+//            8 x { QKV GEMM (q pre-scaled) -> attention -> out-proj GEMM + residual -> LayerNorm
+//                  -> FF1 GEMM + GELU -> FF2 GEMM + residual -> LayerNorm }
+//            output head as a transposed GEMM (rows = 272 channels, cols = tokens) that stores
+//            straight into the [B, C, 1, T] layout, then `finish` copies the trajectory channels
+//            from cond (posenet.py:94-95) and applies the DDPM update.
+#include <vector>
+#include "common.h"
+
+namespace rohm {
+
+constexpr int kMaxTok = 256;
+
+struct LayerW {
+    float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+};
+
+}  // namespace rohm
+
+struct rohm_posenet {
+    int D, H, F, L, Cin, Cout, traj, device;
+    int KP;            // padded K of the fused embed GEMM
+    float* arena;      // one allocation holding every weight
+    float* w_embed;    // [D, KP]   = [Wx | Wc | 0]
+    float* tab;        // [kMaxTok, D]  pe[tok] + bx + bc
+    float* pe;         // [pe_len, D]
+    int pe_len;
+    float *t_w0T, *t_b0, *t_w2T, *t_b2;   // time MLP, weights stored [in][out]
+    float *out_w, *out_b;                 // [Cout, D], [Cout]
+    std::vector<rohm::LayerW> layers;
+};
+
+namespace rohm {
+
+// ----------------------------------------------------------------------------- small kernels
+// [B, C, T] (T contiguous) -> columns [col0, col0+C) of the token-major pack [B*S, KP], rows tok>=1.
+// Also zeroes the tok = 0 row and (when zero_to > C) the pad columns [col0+C, col0+zero_to).
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                   int C, int T, int S, int KP, int col0, int zero_to) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const float* s = src + (size_t)b * C * T;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, t = t0 + tx;
+        tile[ty + i * 8][tx] = (c < C && t < T) ? s[(size_t)c * T + t] : 0.f;
+    }
+    __syncthreads();
+    float* d = dst + (size_t)b * S * KP + col0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + i * 8, c = c0 + tx;
+        if (t < T && c < zero_to) d[(size_t)(t + 1) * KP + c] = tile[tx][ty + i * 8];
+    }
+    if (blockIdx.y == 0 && ty == 0) {
+        const int c = c0 + tx;
+        if (c < zero_to) d[c] = 0.f;
+    }
+}
+
+// Timestep token: tab0[b] = W2 . silu(W0 . pe[t_b] + b0) + b2 + pe[0]   (heads.py:145-146, posenet.py:90-91)
+// One block per row, D threads; weights are stored transposed ([in][out]) so reads coalesce.
+__global__ __launch_bounds__(1024) void timestep_token_kernel(const float* __restrict__ pe, int pe_len,
+                                                              const int64_t* __restrict__ t_dev, int64_t t_host,
+                                                              const float* __restrict__ w0T,
+                                                              const float* __restrict__ b0,
+                                                              const float* __restrict__ w2T,
+                                                              const float* __restrict__ b2,
+                                                              float* __restrict__ tab0, int D) {
+    extern __shared__ float sh[];   // [2*D]
+    float* e = sh;
+    float* h = sh + D;
+    const int n = threadIdx.x;
+    int64_t t = t_dev ? t_dev[blockIdx.x] : t_host;
+    if (t < 0) t = 0;
+    if (t >= pe_len) t = pe_len - 1;
+    e[n] = pe[(size_t)t * D + n];
+    __syncthreads();
+    float a = b0[n];
+    for (int k = 0; k < D; ++k) a = fmaf(e[k], w0T[(size_t)k * D + n], a);
+    h[n] = a / (1.0f + expf(-a));
+    __syncthreads();
+    float o = b2[n];
+    for (int k = 0; k < D; ++k) o = fmaf(h[k], w2T[(size_t)k * D + n], o);
+    tab0[(size_t)blockIdx.x * D + n] = o + pe[n];
+}
+
+// x0[:, :traj] = cond[:, :traj] (posenet.py:94-95); optionally the DDPM update
+// x_prev = c1*x0 + c2*x_t + sigma*noise (gaussian_diffusion_posenet.py:212-234,426-434).
+__global__ __launch_bounds__(256) void finish_kernel(float* __restrict__ x0, const float* __restrict__ cond,
+                                                     const float* x_t,
+                                                     const float* __restrict__ noise, float* x_prev,
+                                                     float c1, float c2, float sigma, int traj, int C, int T,
+                                                     size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = (int)((i / T) % C);
+        float v;
+        if (c < traj) {
+            v = cond[i];
+            x0[i] = v;
+        } else {
+            v = x0[i];
+        }
+        if (x_prev) {
+            float o = c1 * v + c2 * x_t[i];
+            if (noise) o += sigma * noise[i];
+            x_prev[i] = o;
+        }
+    }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+    // dst[c][r] = src[r][c]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R * Cc) {
+        const int r = i / Cc, c = i % Cc;
+        dst[(size_t)c * R + r] = src[i];
+    }
+}
+
+__global__ void build_embed_kernel(const float* __restrict__ wx, const float* __restrict__ wc,
+                                   float* __restrict__ w_embed, int D, int C, int KP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D * KP) {
+        const int n = i / KP, k = i % KP;
+        float v = 0.f;
+        if (k < C) v = wx[(size_t)n * C + k];
+        else if (k < 2 * C) v = wc[(size_t)n * C + (k - C)];
+        w_embed[i] = v;
+    }
+}
+
+__global__ void build_tab_kernel(const float* __restrict__ pe, const float* __restrict__ bx,
+                                 const float* __restrict__ bc, float* __restrict__ tab, int rows, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * D) {
+        const int n = i % D;
+        tab[i] = pe[i] + (bx[n] + bc[n]);
+    }
+}
+
+// ----------------------------------------------------------------------------- workspace
+struct Workspace {
+    float *apack, *h, *y, *qkv, *ctx, *ff, *tab0, *x0;
+    size_t floats;
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
+    const size_t M = (size_t)B * (T + 1);
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        float* ptr = base ? base + off : nullptr;
+        off += align_up(n, 64);
+        return ptr;
+    };
+    w.apack = take(M * p->KP);
+    w.h = take(M * p->D);
+    w.y = take(M * p->D);
+    w.qkv = take(M * 3 * p->D);
+    w.ctx = take(M * p->D);
+    w.ff = take(M * p->F);
+    w.tab0 = take((size_t)B * p->D);
+    w.x0 = take((size_t)B * p->Cin * T);
+    w.floats = off;
+    return w;
+}
+
+static int check_shape(const rohm_posenet* p, int B, int T) {
+    ROHM_ARG_CHECK(p != nullptr, "posenet: null handle");
+    ROHM_ARG_CHECK(B > 0, "posenet: batch must be positive (got %d)", B);
+    ROHM_ARG_CHECK(T + 1 == 144, "posenet: this build supports T = 143 frames (144 tokens); got T=%d", T);
+    ROHM_ARG_CHECK(T + 1 <= kMaxTok && T + 1 <= p->pe_len, "posenet: sequence too long");
+    return ROHM_OK;
+}
+
+// Network body: from packed input (w.apack complete) to x0 channels [traj, Cin) in `x0_out`.
+static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t* t_dev, int64_t t_host,
+                       float* x0_out, int B, int T, hipStream_t s) {
+    const int S = T + 1, D = p->D, M = B * S;
+    // timestep token(s)
+    {
+        const int rows = t_dev ? B : 1;
+        hipLaunchKernelGGL(timestep_token_kernel, dim3(rows), dim3(D), 2 * D * sizeof(float), s, p->pe, p->pe_len,
+                           t_dev, t_host, p->t_w0T, p->t_b0, p->t_w2T, p->t_b2, w.tab0, D);
+        ROHM_LAUNCH_CHECK();
+    }
+    int rc;
+    {   // fused input embed (+cond embed, + biases, + positional table)
+        GemmParams g{};
+        g.A = w.apack; g.lda = p->KP; g.W = p->w_embed; g.ldw = p->KP; g.C = w.h; g.ldc = D;
+        g.M = M; g.N = D; g.K = p->KP; g.S = S; g.tab = p->tab; g.tab0 = w.tab0; g.ldtab = D;
+        g.ldtab0 = t_dev ? D : 0;
+        if ((rc = launch_gemm(g, EPI_EMBED, s))) return rc;
+    }
+    float* h = w.h;
+    float* y = w.y;
+    for (int l = 0; l < p->L; ++l) {
+        const LayerW& lw = p->layers[l];
+        GemmParams g{};
+        g.A = h; g.lda = D; g.W = lw.in_w; g.ldw = D; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        g.bias = lw.in_b; g.qcols = D; g.qscale = 1.0f / sqrtf((float)(D / p->H));
+        if ((rc = launch_gemm(g, EPI_QKV, s))) return rc;
+        if ((rc = launch_attention(w.qkv, w.ctx, B, p->H, s))) return rc;
+        g = GemmParams{};
+        g.A = w.ctx; g.lda = D; g.W = lw.out_w; g.ldw = D; g.C = y; g.ldc = D; g.M = M; g.N = D; g.K = D;
+        g.bias = lw.out_b; g.R = h; g.ldr = D;
+        if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
+        if ((rc = launch_layernorm(y, lw.n1_w, lw.n1_b, M, D, s))) return rc;
+        g = GemmParams{};
+        g.A = y; g.lda = D; g.W = lw.l1_w; g.ldw = D; g.C = w.ff; g.ldc = p->F; g.M = M; g.N = p->F; g.K = D;
+        g.bias = lw.l1_b;
+        if ((rc = launch_gemm(g, EPI_BIAS_GELU, s))) return rc;
+        g = GemmParams{};
+        g.A = w.ff; g.lda = p->F; g.W = lw.l2_w; g.ldw = p->F; g.C = h; g.ldc = D; g.M = M; g.N = D; g.K = p->F;
+        g.bias = lw.l2_b; g.R = y; g.ldr = D;
+        if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
+        if ((rc = launch_layernorm(h, lw.n2_w, lw.n2_b, M, D, s))) return rc;
+    }
+    {   // output head, transposed: rows = channels, cols = tokens
+        GemmParams g{};
+        g.A = p->out_w; g.lda = D; g.W = h; g.ldw = D; g.C = x0_out; g.M = p->Cout; g.N = M; g.K = D;
+        g.bias = p->out_b; g.S = S; g.ch_off = p->Cin - p->Cout; g.C_total = p->Cin; g.T = T;
+        if ((rc = launch_gemm(g, EPI_OUT_T, s))) return rc;
+    }
+    return ROHM_OK;
+}
+
+static int launch_pack(const rohm_posenet* p, const float* src, float* apack, int B, int T, int which,
+                       hipStream_t s) {
+    const int C = p->Cin, S = T + 1;
+    const int zero_to = which == 0 ? C : (p->KP - C);   // second half also clears the K padding
+    dim3 grid((zero_to + 31) / 32, (T + 31) / 32, B);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, s, src, apack, C, T, S, p->KP, which * C, zero_to);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+static int launch_finish(float* x0, const float* cond, const float* x_t, const float* noise, float* x_prev,
+                         float c1, float c2, float sigma, int traj, int C, int T, size_t n, hipStream_t s) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (sigma == 0.f) noise = nullptr;
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x0, cond, x_t, noise, x_prev, c1, c2,
+                       sigma, traj, C, T, n);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+}  // namespace rohm
+
+using namespace rohm;
+
+extern "C" {
+
+int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int d_model, int n_head, int d_ff,
+                        int n_layer, int c_in, int c_out, int traj_dim, int device) {
+    ROHM_ARG_CHECK(out && w && w->layers, "posenet_create: null argument");
+    ROHM_ARG_CHECK(d_model % 256 == 0 && d_model <= 1024, "posenet_create: d_model must be 256/512/1024");
+    ROHM_ARG_CHECK(n_head > 0 && d_model / n_head == 128 && d_model % n_head == 0,
+                   "posenet_create: head dim must be 128 (d_model=%d, n_head=%d)", d_model, n_head);
+    ROHM_ARG_CHECK(d_ff % 64 == 0 && n_layer > 0, "posenet_create: bad d_ff/n_layer");
+    ROHM_ARG_CHECK(c_out + traj_dim == c_in, "posenet_create: c_out + traj_dim must equal c_in");
+    ROHM_ARG_CHECK(w->pe_len >= kMaxTok, "posenet_create: positional table too short");
+    ROHM_HIP_CHECK(hipSetDevice(device));
+    rohm_posenet* p = new rohm_posenet();
+    p->D = d_model; p->H = n_head; p->F = d_ff; p->L = n_layer; p->Cin = c_in; p->Cout = c_out;
+    p->traj = traj_dim; p->device = device; p->pe_len = w->pe_len;
+    p->KP = (int)align_up((size_t)2 * c_in, 32);
+    const size_t D = d_model, F = d_ff;
+    size_t total = 0;
+    auto cnt = [&](size_t n) { size_t o = total; total += align_up(n, 64); return o; };
+    const size_t o_embed = cnt(D * p->KP), o_tab = cnt((size_t)kMaxTok * D), o_pe = cnt((size_t)w->pe_len * D);
+    const size_t o_w0 = cnt(D * D), o_b0 = cnt(D), o_w2 = cnt(D * D), o_b2 = cnt(D);
+    const size_t o_ow = cnt((size_t)c_out * D), o_ob = cnt(c_out);
+    const size_t o_tmp = cnt(D * D);                      // staging for transposes / embed build
+    const size_t o_tmp2 = cnt(2 * D * (size_t)c_in + 2 * D);
+    const size_t per_layer = align_up(3 * D * D, 64) + align_up(3 * D, 64) + align_up(D * D, 64) + align_up(D, 64) +
+                             align_up(F * D, 64) + align_up(F, 64) + align_up(D * F, 64) + align_up(D, 64) +
+                             4 * align_up(D, 64);
+    const size_t o_layers = cnt(per_layer * n_layer);
+    hipError_t e = hipMalloc(&p->arena, total * sizeof(float));
+    if (e != hipSuccess) {
+        delete p;
+        set_error("posenet_create: hipMalloc(%zu) failed: %s", total * sizeof(float), hipGetErrorString(e));
+        return ROHM_ERR_HIP;
+    }
+    float* a = p->arena;
+    auto put = [&](float* dst, const float* src, size_t n) {
+        return hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDefault);
+    };
+#define PUT(dst, src, n)                                                                \
+    do {                                                                                \
+        hipError_t _e = put(dst, src, n);                                               \
+        if (_e != hipSuccess) {                                                         \
+            set_error("posenet_create: copy of %s failed: %s", #src, hipGetErrorString(_e)); \
+            (void)hipFree(p->arena);                                                          \
+            delete p;                                                                   \
+            return ROHM_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+    p->w_embed = a + o_embed; p->tab = a + o_tab; p->pe = a + o_pe;
+    p->t_w0T = a + o_w0; p->t_b0 = a + o_b0; p->t_w2T = a + o_w2; p->t_b2 = a + o_b2;
+    p->out_w = a + o_ow; p->out_b = a + o_ob;
+    float* tmp = a + o_tmp;
+    float* tmp2 = a + o_tmp2;
+    PUT(p->pe, w->pe, (size_t)w->pe_len * D);
+    PUT(p->t_b0, w->t_b0, D);
+    PUT(p->t_b2, w->t_b2, D);
+    PUT(p->out_w, w->out_w, (size_t)c_out * D);
+    PUT(p->out_b, w->out_b, c_out);
+    const int th = 256;
+    PUT(tmp, w->t_w0, D * D);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((D * D + th - 1) / th)), dim3(th), 0, 0, tmp, p->t_w0T, (int)D, (int)D);
+    ROHM_HIP_CHECK(hipDeviceSynchronize());
+    PUT(tmp, w->t_w2, D * D);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((D * D + th - 1) / th)), dim3(th), 0, 0, tmp, p->t_w2T, (int)D, (int)D);
+    ROHM_HIP_CHECK(hipDeviceSynchronize());
+    float* wx = tmp2; float* wc = tmp2 + D * c_in; float* bx = wc + D * c_in; float* bc = bx + D;
+    PUT(wx, w->in_x_w, D * c_in);
+    PUT(wc, w->in_c_w, D * c_in);
+    PUT(bx, w->in_x_b, D);
+    PUT(bc, w->in_c_b, D);
+    hipLaunchKernelGGL(build_embed_kernel, dim3((unsigned)((D * p->KP + th - 1) / th)), dim3(th), 0, 0, wx, wc, p->w_embed, (int)D, c_in, p->KP);
+    hipLaunchKernelGGL(build_tab_kernel, dim3((unsigned)((kMaxTok * D + th - 1) / th)), dim3(th), 0, 0, p->pe, bx, bc, p->tab, kMaxTok, (int)D);
+    ROHM_HIP_CHECK(hipDeviceSynchronize());
+    float* lp = a + o_layers;
+    p->layers.resize(n_layer);
+    for (int l = 0; l < n_layer; ++l) {
+        const rohm_posenet_layer_weights& s = w->layers[l];
+        LayerW& d = p->layers[l];
+        auto take = [&](size_t n) { float* r = lp; lp += align_up(n, 64); return r; };
+        d.in_w = take(3 * D * D); d.in_b = take(3 * D); d.out_w = take(D * D); d.out_b = take(D);
+        d.l1_w = take(F * D); d.l1_b = take(F); d.l2_w = take(D * F); d.l2_b = take(D);
+        d.n1_w = take(D); d.n1_b = take(D); d.n2_w = take(D); d.n2_b = take(D);
+        PUT(d.in_w, s.in_proj_w, 3 * D * D); PUT(d.in_b, s.in_proj_b, 3 * D);
+        PUT(d.out_w, s.out_proj_w, D * D); PUT(d.out_b, s.out_proj_b, D);
+        PUT(d.l1_w, s.lin1_w, F * D); PUT(d.l1_b, s.lin1_b, F);
+        PUT(d.l2_w, s.lin2_w, D * F); PUT(d.l2_b, s.lin2_b, D);
+        PUT(d.n1_w, s.norm1_w, D); PUT(d.n1_b, s.norm1_b, D);
+        PUT(d.n2_w, s.norm2_w, D); PUT(d.n2_b, s.norm2_b, D);
+    }
+#undef PUT
+    ROHM_HIP_CHECK(hipDeviceSynchronize());
+    *out = p;
+    return ROHM_OK;
+}
+
+void rohm_posenet_destroy(rohm_posenet_t* h) {
+    if (!h) return;
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+}
+
+size_t rohm_posenet_workspace_bytes(const rohm_posenet_t* h, int B, int T) {
+    if (!h || B <= 0 || T <= 0) return 0;
+    return carve(h, B, T, nullptr).floats * sizeof(float);
+}
+
+int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float* cond, const int64_t* t,
+                         float* x0_out, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream) {
+    int rc = check_shape(h, B, T);
+    if (rc) return rc;
+    ROHM_ARG_CHECK(x_t && cond && t && x0_out && ws, "posenet_forward: null argument");
+    ROHM_ARG_CHECK(((uintptr_t)ws % 256) == 0, "posenet_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w = carve(h, B, T, (float*)ws);
+    if (w.floats * sizeof(float) > ws_bytes) {
+        set_error("posenet_forward: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
+        return ROHM_ERR_WORKSPACE;
+    }
+    if ((rc = launch_pack(h, x_t, w.apack, B, T, 0, s))) return rc;
+    if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;
+    if ((rc = run_network(h, w, t, 0, x0_out, B, T, s))) return rc;
+    const size_t n = (size_t)B * h->Cin * T;
+    return launch_finish(x0_out, cond, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, h->traj, h->Cin, T, n, s);
+}
+
+int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* cond, const int64_t* t_model,
+                             const float* coef, const float* noise, float* x0_last, int n_steps, int B, int T,
+                             void* ws, size_t ws_bytes, rohm_stream_t stream) {
+    int rc = check_shape(h, B, T);
+    if (rc) return rc;
+    ROHM_ARG_CHECK(x && cond && t_model && coef && ws, "posenet_sample_loop: null argument");
+    ROHM_ARG_CHECK(n_steps >= 0, "posenet_sample_loop: negative step count");
+    ROHM_ARG_CHECK(((uintptr_t)ws % 256) == 0, "posenet_sample_loop: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w = carve(h, B, T, (float*)ws);
+    if (w.floats * sizeof(float) > ws_bytes) {
+        set_error("posenet_sample_loop: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
+        return ROHM_ERR_WORKSPACE;
+    }
+    const size_t n = (size_t)B * h->Cin * T;
+    if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;   // cond is constant over the loop
+    for (int i = 0; i < n_steps; ++i) {
+        const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
+        ROHM_ARG_CHECK(sigma == 0.f || noise, "posenet_sample_loop: noise is required when sigma != 0");
+        if ((rc = launch_pack(h, x, w.apack, B, T, 0, s))) return rc;
+        float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
+        if ((rc = run_network(h, w, nullptr, t_model[i], x0, B, T, s))) return rc;
+        if ((rc = launch_finish(x0, cond, x, noise ? noise + (size_t)i * n : nullptr, x, c1, c2, sigma, h->traj,
+                                h->Cin, T, n, s)))
+            return rc;
+    }
+    return ROHM_OK;
+}
+
+}  // extern "C"

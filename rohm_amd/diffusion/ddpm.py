@@ -1,0 +1,309 @@
+"""DDPM ancestral sampling engine shared by the PoseNet and TrajNet diffusions.
+
+Behavioural contract = RoHM's `diffusion/gaussian_diffusion_{posenet,trajnet}.py` restricted to what
+is reachable at inference: x0-prediction, fixed-small variance, the
+`p_sample[_with_grad]` update, the 999..0 (or 999..20 with `early_stop`) loop and `eval_losses`.
+The implementation is not the reference's: schedule tables are built once in float64 on the host
+(same formulas, gaussian_diffusion_posenet.py:114-173) and uploaded once as one fp32 [steps, 4]
+device table; every per-step update is ONE HIP kernel that indexes the table on the device (no
+per-step H2D uploads, no host syncs); and when the model is the native PoseNet and no guidance is
+due, whole runs of steps execute inside `rohm_posenet_sample_loop` without returning to Python.
+"""
+from __future__ import annotations
+
+import enum
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """beta_i = min(1 - abar((i+1)/n) / abar(i/n), max_beta) (gaussian_diffusion_posenet.py:41-58)."""
+    n = num_diffusion_timesteps
+    return np.array([min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), max_beta) for i in range(n)])
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=1.):
+    """'linear' / 'cosine' schedules in float64 (gaussian_diffusion_posenet.py:14-38)."""
+    if schedule_name == 'linear':
+        scale = scale_betas * 1000 / num_diffusion_timesteps
+        return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+    if schedule_name == 'cosine':
+        return betas_for_alpha_bar(num_diffusion_timesteps,
+                                   lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f'unknown beta schedule: {schedule_name}')
+
+
+# Guidance schedule hard-coded in the reference (gaussian_diffusion_posenet.py:461-477):
+#   grad_type -> (t threshold, [(hook name, weight), ...]) applied in this order.
+GUIDANCE = {
+    'prox': (100, (('guide_2d_projection_with_smpl', 3e5), ('guide_skating_with_smpl', 1e5))),
+    'amass': (50, (('guide_skating_with_smpl', 3e6),)),
+}
+
+
+class DDPMSampler:
+    """Base of `GaussianDiffusionPoseNet` / `GaussianDiffusionTrajNet`."""
+
+    supports_guidance = False
+
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False,
+                 dataset=None, device=''):
+        if model_mean_type.name != 'START_X':
+            raise NotImplementedError('only x0-prediction (ModelMeanType.START_X) is used by RoHM')
+        self.model_mean_type, self.model_var_type, self.loss_type = model_mean_type, model_var_type, loss_type
+        self.rescale_timesteps = rescale_timesteps
+        self.dataset, self.device = dataset, device
+        betas = np.array(betas, dtype=np.float64)
+        if betas.ndim != 1 or not ((betas > 0).all() and (betas <= 1).all()):
+            raise ValueError('betas must be a 1-D array in (0, 1]')
+        self.betas = betas
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        self.alphas_cumprod, self.alphas_cumprod_prev = ac, ac_prev
+        self.alphas_cumprod_next = np.append(ac[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(ac)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - ac)
+        self.posterior_variance = betas * (1.0 - ac_prev) / (1.0 - ac)
+        # index 0 borrows index 1: the posterior variance is 0 at t = 0 (gaussian_diffusion_posenet.py:155-160)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1],
+                                                               self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(ac_prev) / (1.0 - ac)
+        self.posterior_mean_coef2 = (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac)
+        self._tables_cache = {}
+        self._map_cache = {}
+        self.timestep_map = list(range(self.num_timesteps))
+        self.original_num_steps = self.num_timesteps
+        self.noise_source = None     # optional callable (loop_step, like_tensor) -> noise; tests inject here
+        self.fused_chunk = 50        # loop steps per rohm_posenet_sample_loop call / noise chunk
+
+    # ------------------------------------------------------------------ schedule tables
+    def host_tables(self):
+        """float32 [steps, 4] = coef1, coef2, variance, log_variance (cast once, like `.float()` at use)."""
+        return np.stack([self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_variance,
+                         self.posterior_log_variance_clipped], axis=1).astype(np.float32)
+
+    def device_tables(self, device):
+        key = str(device)
+        if key not in self._tables_cache:
+            self._tables_cache[key] = torch.from_numpy(self.host_tables()).to(device).contiguous()
+        return self._tables_cache[key]
+
+    def _mapped(self, t):
+        """Network-side timestep (`_WrappedModel`, respace.py:183-195)."""
+        if self.timestep_map == list(range(self.num_timesteps)) and not self.rescale_timesteps:
+            return t
+        key = str(t.device)
+        if key not in self._map_cache:
+            self._map_cache[key] = torch.tensor(self.timestep_map, device=t.device, dtype=torch.int64)
+        new_t = self._map_cache[key][t]
+        if self.rescale_timesteps:
+            new_t = new_t.float() * (1000.0 / self.original_num_steps)
+        return new_t
+
+    def _noise(self, step, like):
+        if self.noise_source is not None:
+            return self.noise_source(step, like).to(device=like.device, dtype=like.dtype).contiguous()
+        return torch.randn_like(like)
+
+    # ------------------------------------------------------------------ single steps (API parity)
+    def p_mean_variance(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """Network call + posterior mean (gaussian_diffusion_posenet.py:236-280)."""
+        raw = getattr(model, 'model', model)
+        B = x.shape[0]
+        assert t.shape == (B,)
+        batch['x_t'] = x
+        pred_xstart = raw(batch, self._mapped(t), **(model_kwargs or {}))
+        tab = self.device_tables(x.device)
+        mean = ops.ddpm_step_table(x.contiguous(), pred_xstart, None, tab, t.contiguous())
+        shape = (B,) + (1,) * (x.dim() - 1)
+        return {'mean': mean, 'variance': tab[t, 2].view(shape), 'log_variance': tab[t, 3].view(shape),
+                'pred_xstart': pred_xstart}
+
+    def _step(self, model, batch, x, t, step, grad_type=None, t_int=None):
+        """One ancestral step: network -> (guidance) -> fused update kernel."""
+        raw = getattr(model, 'model', model)
+        batch['x_t'] = x
+        x0 = raw(batch, self._mapped(t))
+        noise = self._noise(step, x)                       # drawn BEFORE guidance (…posenet.py:458)
+        grads = []
+        if grad_type is not None:
+            if not self.supports_guidance or grad_type not in GUIDANCE:
+                raise ValueError(f'unknown grad_type {grad_type!r}')
+            thr, hooks = GUIDANCE[grad_type]
+            if t_int is None:
+                t_int = int(t[0])
+            if t_int <= thr:
+                out = {'pred_xstart': x0}
+                for name, w in hooks:
+                    g = getattr(raw, name)(batch, out, t, compute_grad='x_0')
+                    if g.dim() != 0:                        # 0-d zero = "no active constraint"
+                        grads.append((g.float().contiguous(), w))
+        ga, wa = grads[0] if len(grads) > 0 else (None, 0.0)
+        gb, wb = grads[1] if len(grads) > 1 else (None, 0.0)
+        sample = ops.ddpm_step_table(x.contiguous(), x0, noise, self.device_tables(x.device), t.contiguous(),
+                                     ga, wa, gb, wb)
+        return {'sample': sample, 'pred_xstart': x0, 'x_t': x}
+
+    def p_sample(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                 model_kwargs=None, const_noise=False):
+        if cond_fn is not None or const_noise:
+            raise NotImplementedError('cond_fn / const_noise are never used by the RoHM drivers')
+        with torch.no_grad():
+            return self._step(model, batch, x, t, step=None)
+
+    def p_sample_with_grad(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                           grad_type=None, model_kwargs=None, const_noise=False):
+        with torch.no_grad():
+            return self._step(model, batch, x, t, step=None, grad_type=grad_type)
+
+    # ------------------------------------------------------------------ loops
+    def _indices(self, skip_timesteps=0, early_stop=False):
+        idx = list(range(self.num_timesteps - skip_timesteps))[::-1]
+        return idx[0:980] if early_stop else idx          # hard-coded in the reference (…posenet.py:625-626)
+
+    def p_sample_loop_progressive(self, model, batch, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                  cond_fn=None, model_kwargs=None, device=None, progress=False, skip_timesteps=0,
+                                  init_image=None, randomize_class=False, cond_fn_with_grad=False, grad_type=None,
+                                  early_stop=False, const_noise=False):
+        """Generator over per-step dicts, one kernel-chain per step (…posenet.py:578-662)."""
+        if skip_timesteps or init_image is not None or const_noise or cond_fn is not None:
+            raise NotImplementedError('skip_timesteps / init_image / const_noise / cond_fn are unused by RoHM')
+        raw = getattr(model, 'model', model)
+        if device is None:
+            device = next(raw.parameters()).device
+        img = noise if noise is not None else self._x_T(shape, device)
+        indices = self._indices(0, early_stop)
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        B = shape[0]
+        for step, i in enumerate(indices):
+            t = torch.full((B,), i, device=device, dtype=torch.int64)
+            with torch.no_grad():
+                out = self._step(model, batch, img, t, step,
+                                 grad_type=grad_type if cond_fn_with_grad else None, t_int=i)
+            yield out
+            img = out['sample']
+
+    def _x_T(self, shape, device):
+        if self.noise_source is not None:
+            like = torch.empty(*shape, device=device)
+            return self.noise_source(-1, like).to(device=device, dtype=torch.float32).contiguous()
+        return torch.randn(*shape, device=device)
+
+    def _fused_ok(self, raw):
+        return hasattr(raw, 'sample_loop_native') and not self.rescale_timesteps
+
+    def p_sample_loop(self, model, batch, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                      randomize_class=False, cond_fn_with_grad=False, grad_type=None, early_stop=False,
+                      dump_steps=None, const_noise=False, save_intermediate_result=False):
+        """Full sampling run; returns the last `sample` (or last `pred_xstart` with `early_stop`)."""
+        raw = getattr(model, 'model', model)
+        if dump_steps is not None or save_intermediate_result or not self._fused_ok(raw):
+            final = None
+            dump = []
+            for k, out in enumerate(self.p_sample_loop_progressive(
+                    model, batch, shape, noise=noise, device=device, progress=progress,
+                    cond_fn_with_grad=cond_fn_with_grad, grad_type=grad_type, early_stop=early_stop)):
+                if dump_steps is not None and k in dump_steps:
+                    dump.append(out['sample'].clone())
+                final = out
+            if dump_steps is not None:
+                return dump
+            return final['pred_xstart'] if early_stop else final['sample']
+        return self._fused_loop(raw, batch, shape, noise, device, cond_fn_with_grad, grad_type, early_stop)
+
+    def _fused_loop(self, raw, batch, shape, noise, device, cond_fn_with_grad, grad_type, early_stop):
+        """Device-resident runs of un-guided steps + per-step execution of the guided tail."""
+        if device is None:
+            device = next(raw.parameters()).device
+        x = (noise if noise is not None else self._x_T(shape, device)).to(torch.float32).contiguous().clone()
+        cond = batch['cond'].detach().to(torch.float32).contiguous()
+        indices = self._indices(0, early_stop)
+        thr = -1
+        if cond_fn_with_grad and grad_type is not None:
+            if not self.supports_guidance or grad_type not in GUIDANCE:
+                raise ValueError(f'unknown grad_type {grad_type!r}')
+            thr = GUIDANCE[grad_type][0]
+        n_free = sum(1 for i in indices if i > thr)        # leading un-guided steps
+        tabs = self.host_tables()
+        x0_last = None
+        with torch.no_grad():
+            pos = 0
+            while pos < n_free:
+                n = min(self.fused_chunk, n_free - pos)
+                ts = indices[pos:pos + n]
+                coef = np.empty((n, 3), np.float32)
+                for k, i in enumerate(ts):
+                    coef[k, 0], coef[k, 1] = tabs[i, 0], tabs[i, 1]
+                    coef[k, 2] = np.exp(np.float32(0.5) * tabs[i, 3]) if i != 0 else 0.0
+                if self.noise_source is not None:
+                    nz = torch.stack([self._noise(pos + k, x) for k in range(n)])
+                else:
+                    nz = torch.randn((n,) + tuple(x.shape), device=x.device, dtype=torch.float32)
+                last = (pos + n == len(indices))
+                x0 = raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz,
+                                            want_x0_last=last)
+                if last:
+                    x0_last = x0
+                pos += n
+            B = shape[0]
+            for step in range(n_free, len(indices)):
+                i = indices[step]
+                t = torch.full((B,), i, device=x.device, dtype=torch.int64)
+                out = self._step(raw, batch, x, t, step, grad_type=grad_type, t_int=i)
+                x, x0_last = out['sample'], out['pred_xstart']
+        batch['x_t'] = x
+        return x0_last if early_stop else x
+
+    # ------------------------------------------------------------------ entry point
+    def _eval(self, model, batch, shape, progress, clip_denoised, cond_fn_with_grad, grad_type, early_stop,
+              timestep_respacing, compute_loss):
+        if compute_loss:
+            raise NotImplementedError('compute_loss=True needs the training losses, which are outside the '
+                                      'inference hot path; the RoHM test drivers pass compute_loss=False')
+        if timestep_respacing != '':
+            raise NotImplementedError("only timestep_respacing='' reaches a sampler in RoHM "
+                                      '(gaussian_diffusion_posenet.py:943-955)')
+        out = self.p_sample_loop(model=getattr(model, 'model', model), batch=batch, shape=shape, progress=progress,
+                                 clip_denoised=clip_denoised, cond_fn_with_grad=cond_fn_with_grad,
+                                 grad_type=grad_type, early_stop=early_stop)
+        return None, out
+
+    def training_losses(self, *a, **k):
+        raise NotImplementedError('training is outside the inference hot path (SURVEY.md §8)')
+
+
+def _extract_into_tensor(arr, timesteps, broadcast_shape):
+    """Schedule lookup helper kept for API parity (gaussian_diffusion_posenet.py:967-980)."""
+    res = torch.from_numpy(np.asarray(arr)).to(device=timesteps.device)[timesteps].float()
+    while res.dim() < len(broadcast_shape):
+        res = res[..., None]
+    return res.expand(broadcast_shape)

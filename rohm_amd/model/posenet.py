@@ -1,0 +1,233 @@
+"""PoseNet with the reference's constructor / state_dict / call contract, computed by librohm_hip.so.
+
+Mirror of `model/posenet.py` in RoHM: same class name, constructor arguments, sub-module names
+(so released checkpoints load with `strict=True`), same `forward(batch, timesteps)` semantics and
+the same guidance hooks.  The arithmetic does NOT run in PyTorch: `forward` hands raw device
+pointers to `rohm_posenet_forward` (hand-written gfx950 kernels) on the current HIP stream.
+There is no CPU path: calling the module with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import LayerWeights, PoseNetWeights, check, lib, ptr, stream_ptr
+from .heads import InputProcess, OutputProcess, PositionalEncoding, TimestepEmbedder
+
+
+def _make_body_model(body_model_path, device):
+    """`smplx.create(...)` as in model/posenet.py:57-58, or an injected nn.Module body model."""
+    if isinstance(body_model_path, nn.Module):
+        return body_model_path.to(device) if device is not None else body_model_path
+    try:
+        import smplx  # noqa: WPS433  (third-party; optional in this environment)
+    except ImportError:
+        from ..body_model import SMPLXLayer
+        if isinstance(body_model_path, str) and body_model_path.endswith('.npz'):
+            m = SMPLXLayer.from_npz(body_model_path)
+            return m.to(device) if device is not None else m
+        warnings.warn('smplx is not installed and no body model was injected: PoseNet.smplx_model is None; '
+                      'test-time guidance will raise until a body model is attached')
+        return None
+    m = smplx.create(model_path=body_model_path, model_type='smplx', gender='neutral', flat_hand_mean=True,
+                     use_pca=False)
+    return m.to(device) if device is not None else m
+
+
+class _NativePoseNet:
+    """Owns a `rohm_posenet_t*` built from a snapshot of the module's parameters."""
+
+    def __init__(self, module, device):
+        sd = {k: v.detach() for k, v in module.state_dict().items() if not k.startswith('smplx_model.')}
+        f = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()
+        keep = []
+
+        def p(k):
+            t = f(k)
+            keep.append(t)
+            return C.c_void_p(t.data_ptr())
+
+        L = module.num_layers
+        layers = (LayerWeights * L)()
+        for i in range(L):
+            pre = f'seqTransEncoder.layers.{i}.'
+            lw = layers[i]
+            lw.in_proj_w, lw.in_proj_b = p(pre + 'self_attn.in_proj_weight'), p(pre + 'self_attn.in_proj_bias')
+            lw.out_proj_w, lw.out_proj_b = p(pre + 'self_attn.out_proj.weight'), p(pre + 'self_attn.out_proj.bias')
+            lw.lin1_w, lw.lin1_b = p(pre + 'linear1.weight'), p(pre + 'linear1.bias')
+            lw.lin2_w, lw.lin2_b = p(pre + 'linear2.weight'), p(pre + 'linear2.bias')
+            lw.norm1_w, lw.norm1_b = p(pre + 'norm1.weight'), p(pre + 'norm1.bias')
+            lw.norm2_w, lw.norm2_b = p(pre + 'norm2.weight'), p(pre + 'norm2.bias')
+        w = PoseNetWeights()
+        w.in_x_w, w.in_x_b = p('input_process.poseEmbedding.weight'), p('input_process.poseEmbedding.bias')
+        w.in_c_w, w.in_c_b = p('input_process_cond.poseEmbedding.weight'), p('input_process_cond.poseEmbedding.bias')
+        pe = sd['sequence_pos_encoder.pe'][:, 0].to(device=device, dtype=torch.float32).contiguous()
+        keep.append(pe)
+        w.pe, w.pe_len = C.c_void_p(pe.data_ptr()), pe.shape[0]
+        w.t_w0, w.t_b0 = p('embed_timestep.time_embed.0.weight'), p('embed_timestep.time_embed.0.bias')
+        w.t_w2, w.t_b2 = p('embed_timestep.time_embed.2.weight'), p('embed_timestep.time_embed.2.bias')
+        w.out_w, w.out_b = p('output_process.poseFinal.weight'), p('output_process.poseFinal.bias')
+        w.layers = layers
+        self.handle = C.c_void_p()
+        self.device = device
+        torch.cuda.synchronize(device)
+        with torch.cuda.device(device):
+            check(lib().rohm_posenet_create(C.byref(self.handle), C.byref(w), module.latent_dim, module.num_heads,
+                                            module.ff_size, L, module.input_feats, module.dataset_pose_feat_dim,
+                                            module.input_feats - module.dataset_pose_feat_dim, device.index or 0),
+                  'rohm_posenet_create')
+        del keep
+        self._ws = {}
+
+    def workspace(self, B, T):
+        key = (B, T)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = lib().rohm_posenet_workspace_bytes(self.handle, B, T)
+            if nbytes == 0:
+                raise _lib.RohmHipError('rohm_posenet_workspace_bytes returned 0 (bad shape)')
+            self._ws.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().rohm_posenet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class PoseNet(nn.Module):
+    """Drop-in for `model.posenet.PoseNet` (model/posenet.py:11-72)."""
+
+    def __init__(self, dataset, body_feat_dim, nfeats=1,
+                 latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1, activation="gelu",
+                 body_model_path='', device=None, traj_feat_dim=4,
+                 weight_loss_rec_repr_full_body=0.0, weight_loss_repr_foot_contact_mse=0.0,
+                 weight_loss_joint_pos_global=0.0, weight_loss_joint_vel_global=0.0,
+                 weight_loss_joint_smooth=0.0, weight_loss_foot_skating=0.0, start_skating_loss_epoch=0):
+        super().__init__()
+        if activation != 'gelu':
+            raise ValueError('the HIP PoseNet implements the exact-erf GELU feed-forward only')
+        self.dataset = dataset
+        self.body_feat_dim, self.nfeats, self.traj_feat_dim = body_feat_dim, nfeats, traj_feat_dim
+        self.foot_joint_index_list = [7, 10, 8, 11]   # l-ankle, l-toe, r-ankle, r-toe (posenet.py:30-31)
+        self.foot_skating_vel_thres = 0.1
+        self.fps = 30
+        self.latent_dim, self.ff_size = latent_dim, ff_size
+        self.num_layers, self.num_heads = num_layers, num_heads
+        self.dropout, self.activation = dropout, activation
+        self.input_feats = body_feat_dim * nfeats
+        self.dataset_pose_feat_dim = dataset.pose_feat_dim
+        self.device = device
+        self.weight_loss_rec_repr_full_body = weight_loss_rec_repr_full_body
+        self.weight_loss_repr_foot_contact_mse = weight_loss_repr_foot_contact_mse
+        self.weight_loss_joint_pos_global = weight_loss_joint_pos_global
+        self.weight_loss_joint_vel_global = weight_loss_joint_vel_global
+        self.weight_loss_joint_smooth = weight_loss_joint_smooth
+        self.weight_loss_foot_skating = weight_loss_foot_skating
+        self.start_skating_loss_epoch = start_skating_loss_epoch
+
+        body = _make_body_model(body_model_path, device)
+        if body is not None:
+            self.smplx_model = body
+        else:
+            self.smplx_model = None
+        self.input_process = InputProcess(self.input_feats, latent_dim)
+        self.input_process_cond = InputProcess(self.input_feats, latent_dim)
+        self.sequence_pos_encoder = PositionalEncoding(latent_dim, dropout)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            layer = nn.TransformerEncoderLayer(d_model=latent_dim, nhead=num_heads, dim_feedforward=ff_size,
+                                               dropout=dropout, activation=activation)
+            self.seqTransEncoder = nn.TransformerEncoder(layer, num_layers=num_layers)
+        self.embed_timestep = TimestepEmbedder(latent_dim, self.sequence_pos_encoder)
+        self.output_process = OutputProcess(dataset.pose_feat_dim, latent_dim, nfeats)
+        self._native = None
+        self._native_key = None
+
+    # ------------------------------------------------------------------ native handle cache
+    def _fingerprint(self, device):
+        vs = tuple((p.data_ptr(), p._version) for p in self.parameters(recurse=True))
+        return (str(device), hash(vs))
+
+    def native(self, device=None):
+        """The `rohm_posenet_t` for the current weights on `device` (rebuilt if they changed)."""
+        if device is None:
+            device = next(self.parameters()).device
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise _lib.RohmHipError('PoseNet runs only on an AMD GPU via librohm_hip.so (no CPU fallback); '
+                                    'move the module and its inputs to a HIP device')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        key = self._fingerprint(device)
+        if self._native is None or self._native_key != key:
+            self._native = _NativePoseNet(self, device)
+            self._native_key = key
+        return self._native
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch, timesteps):
+        """batch['x_t'], batch['cond']: [B, body_feat_dim, 1, T]; timesteps int64 [B] -> [B, body_feat_dim, 1, T]
+        (model/posenet.py:75-96)."""
+        x_t, cond = batch['x_t'], batch['cond']
+        _lib.require_hip(x_t, cond, timesteps)
+        nat = self.native(x_t.device)
+        B, Cc, nf, T = x_t.shape
+        if Cc != self.input_feats or nf != 1:
+            raise ValueError(f'x_t must be [B, {self.input_feats}, 1, T]; got {tuple(x_t.shape)}')
+        x_c = x_t.detach().to(torch.float32).contiguous()
+        c_c = cond.detach().to(torch.float32).contiguous()
+        t_c = timesteps.to(torch.int64).contiguous()
+        out = torch.empty_like(x_c)
+        ws = nat.workspace(B, T)
+        check(lib().rohm_posenet_forward(nat.handle, ptr(x_c), ptr(c_c), ptr(t_c), ptr(out), B, T, ptr(ws),
+                                         ws.numel(), stream_ptr(x_c.device)), 'rohm_posenet_forward')
+        return out
+
+    # ------------------------------------------------------------------ fused sampling loop
+    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False):
+        """Run `n = len(t_model)` DDPM steps on the device (rohm_posenet_sample_loop).
+
+        x [B,C,1,T] is updated in place; noise [n,B,C,1,T]; coef float32 host array [n,3] of
+        (coef1, coef2, sigma); t_model int64 host array [n].  Returns pred_xstart of the last step
+        when `want_x0_last`."""
+        import numpy as np
+        _lib.require_hip(x, cond, noise)
+        nat = self.native(x.device)
+        B, Cc, _, T = x.shape
+        assert x.is_contiguous() and cond.is_contiguous()
+        n = len(t_model)
+        t_arr = np.ascontiguousarray(t_model, dtype=np.int64)
+        c_arr = np.ascontiguousarray(coef, dtype=np.float32).reshape(-1)
+        assert c_arr.size == 3 * n
+        if noise is not None:
+            assert noise.is_contiguous() and noise.shape[0] >= n and noise[0].numel() == x.numel()
+        x0_last = torch.empty_like(x) if want_x0_last else None
+        ws = nat.workspace(B, T)
+        check(lib().rohm_posenet_sample_loop(nat.handle, ptr(x), ptr(cond),
+                                             t_arr.ctypes.data_as(_lib.c_int64_p),
+                                             c_arr.ctypes.data_as(_lib.c_float_p), ptr(noise), ptr(x0_last), n, B, T,
+                                             ptr(ws), ws.numel(), stream_ptr(x.device)),
+              'rohm_posenet_sample_loop')
+        return x0_last
+
+    # ------------------------------------------------------------------ guidance hooks (posenet.py:196-317)
+    def guide_skating_with_smpl(self, batch, out, denoise_t, compute_grad='x_t'):
+        from ..guidance import guide_skating
+        return guide_skating(self, batch, out, denoise_t, compute_grad)
+
+    def guide_2d_projection_with_smpl(self, batch, out, denoise_t, compute_grad='x_t'):
+        from ..guidance import guide_2d_projection
+        return guide_2d_projection(self, batch, out, denoise_t, compute_grad)
+
+    def compute_losses_with_smpl(self, *a, **k):
+        raise NotImplementedError('training losses are outside the inference hot path (SURVEY.md §8)')
