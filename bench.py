@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoised 145-frame clips/s at 1000 DDPM steps (BASELINE.json `metric`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--ddpm-steps 1000]
+
+One "step" = one complete pass of the hot path over one batch: a full PoseNet `eval_losses` run
+(x_T -> x_0 through 1000 ancestral DDPM steps, on-device noise generation included) for `--batch`
+synthetic clips per GPU (BASELINE.json configs[1]: B = 64 on one MI355X).  Clips are independent, so
+with N > 1 every rank denoises its own B clips (weak scaling, no data-path collective) and the ranks
+exchange only the finished results with one RCCL all-gather inside the timed region.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the fp32-MFMA GEMM
+family: algorithmic flops / HIP-event-measured launch time, sampled every 16th denoising step of the
+timed region on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle port of the same
+p_sample step timed on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, 2.4 GHz
+POSENET_GFLOP_PER_CLIP_STEP = 5.298   # SURVEY.md §8(d) / BASELINE.md §2
+
+
+class _Dataset:
+    pose_feat_dim, traj_feat_dim, body_feat_dim = 272, 22, 294
+    Mean = np.zeros(294, np.float32)
+    Std = np.ones(294, np.float32)
+
+
+class _Args:
+    noise_schedule = 'cosine'
+    sigma_small = True
+
+
+def synthetic_cond(B, device, seed):
+    """cfg 2 of SURVEY.md §8(d): cond ~ N(0,1), contact channels zeroed, lower-body joints
+    [1,2,4,5,7,8,10,11] occluded as in test_amass_full.py:340-348."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    cond = torch.randn(B, 143, 294, generator=g)
+    jid = np.asarray([1, 2, 4, 5, 7, 8, 10, 11])
+    for k in range(3):
+        cond[:, :, 22 + jid * 3 + k] = 0.
+        cond[:, :, 22 + 66 + jid * 3 + k] = 0.
+    for k in range(6):
+        cond[:, :, 22 + 132 + (jid - 1) * 6 + k] = 0.
+    cond[:, :, -4:] = 0.
+    return cond.permute(0, 2, 1).unsqueeze(2).contiguous().to(device)
+
+
+def cpu_baseline(batch=8, budget_s=12.0):
+    """Oracle port of one PoseNet p_sample step on the host cores, extrapolated to 1000 steps."""
+    from oracle import diffusion as odiff
+    from oracle import nets
+    from rohm_amd.utils import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.posenet_state_dict(0)
+    tab = odiff.tables(odiff.cosine_betas(1000))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, 294, 1, 143, generator=g)
+    cond = torch.randn(batch, 294, 1, 143, generator=g)
+    fn = lambda xx, i: nets.posenet_forward(sd, xx, cond, torch.full((batch,), i, dtype=torch.int64))
+
+    def one(i):
+        nz = [torch.randn(batch, 294, 1, 143, generator=g)]
+        return odiff.p_sample_loop(fn, x, nz, tab, [i])
+    with torch.no_grad():
+        one(999)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one(998 - n)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 200:
+                break
+    sec_per_step = el / n
+    return {'value': batch / (sec_per_step * 1000.0), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle (torch-CPU fp32 restatement) PoseNet p_sample, B={batch}, {n} timed steps '
+                      f'({el:.1f} s, {sec_per_step * 1e3:.1f} ms/step) extrapolated to 1000 steps',
+            'torch_threads': torch.get_num_threads()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--ddpm-steps', type=int, default=1000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-stride', type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an AMD GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+
+    from rohm_amd import _lib
+    from rohm_amd.diffusion import gaussian_diffusion_posenet as gdp
+    from rohm_amd.diffusion.respace import SpacedDiffusionPoseNet
+    from rohm_amd.model.posenet import PoseNet
+    from rohm_amd.utils import synth
+    from rohm_amd.utils.model_util import create_gaussian_diffusion
+
+    B, S = args.batch, args.ddpm_steps
+    net = PoseNet(_Dataset(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                  body_model_path=torch.nn.Identity(), device=dev)
+    net.load_state_dict(synth.posenet_state_dict(0), strict=True)
+    net = net.to(dev).eval()
+    diffusion = create_gaussian_diffusion(_Args, gdp, SpacedDiffusionPoseNet, S, '', device=dev)
+    cond = synthetic_cond(B, dev, seed=1000 + rank)
+    torch.manual_seed(rank)
+    gathered = [torch.empty(B, 294, 1, 143, device=dev) for _ in range(world)] if world > 1 else None
+
+    def one_pass():
+        batch = {'cond': cond}
+        _, x0 = diffusion.eval_losses(model=net, batch=batch, shape=[B, 294, 1, 143], progress=False,
+                                      clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
+                                      compute_loss=False)
+        if world > 1:
+            dist.all_gather(gathered, x0.contiguous())
+        return x0
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_pass()
+    sync()
+    _lib.profile_start(args.profile_stride)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all(), 'non-finite samples'
+
+    if rank == 0:
+        clips = world * B * args.steps
+        gemm = {k: v for k, v in prof.items() if k.startswith('gemm_')}
+        g_ms = sum(v['total_ms'] for v in gemm.values())
+        g_fl = sum(v['flops'] for v in gemm.values())
+        g_n = sum(v['launches'] for v in gemm.values())
+        all_ms = sum(v['total_ms'] for v in prof.values())
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else None
+        kernels = {k: {'launches': v['launches'], 'avg_us': round(v['total_ms'] / v['launches'] * 1e3, 2),
+                       'tflops': round(v['flops'] / (v['total_ms'] * 1e-3) / 1e12, 2) if v['flops'] else None,
+                       'gbps': round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1),
+                       'time_share': round(v['total_ms'] / all_ms, 4)}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
+        rec = {
+            'metric': 'denoised 145-frame clips/sec @1000 DDPM steps' if S == 1000 else
+                      f'denoised 145-frame clips/sec @{S} DDPM steps',
+            'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'PoseNet {S}-step DDPM (x0-pred, fixed-small var), batch={B} synthetic '
+                                   f'145-frame clips per GPU (T=143 -> 144 tokens, d=512, 8 layers), no guidance '
+                                   f'[BASELINE.json configs[1]]',
+                       'clips_per_gpu': B, 'ddpm_steps': S, 'sharding': f'{world} x {B} independent clips, '
+                       'all-gather of results only' if world > 1 else 'single GPU', 'weights': 'random (seed 0)'},
+            'model_tflops': clips * S * POSENET_GFLOP_PER_CLIP_STEP * 1e-3 / elapsed,
+            'roofline': {
+                'kernel': 'gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region, '
+                          f'sampled every {args.profile_stride}th denoising step)',
+                'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': None,
+                'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
+                'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,
+                'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
+                'kernels': kernels,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -41,6 +41,23 @@ typedef void* rohm_stream_t; /* hipStream_t */
 const char* rohm_last_error(void);
 int rohm_version(void);
 
+/* ------------------------------------------------------------------ launch profiler
+ * Measurement aid for bench.py: while active, every instrumented kernel launch is bracketed by a
+ * pair of HIP events recorded ON THE LAUNCH STREAM (so it sees the library's launches whatever
+ * torch's current stream is).  Inside *_sample_loop only every `step_stride`-th denoising step is
+ * bracketed, which keeps the timed region's perturbation negligible.  Not thread-safe.
+ * rohm_profile_stop synchronises the recorded events and aggregates per kernel label:
+ * launches, summed duration, summed algorithmic flops / bytes (as priced in DESIGN.md). */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} rohm_profile_row;
+int rohm_profile_start(int step_stride);
+int rohm_profile_stop(rohm_profile_row* rows, int max_rows, int* n_rows);
+
 /* ------------------------------------------------------------------ building blocks
  * Exposed so that each kernel can be parity-tested and profiled on its own.        */
 

@@ -35,12 +35,19 @@ class PoseNetWeights(C.Structure):
                 ('layers', C.POINTER(LayerWeights))]
 
 
+class ProfileRow(C.Structure):
+    _fields_ = [('name', C.c_char * 48), ('launches', C.c_uint64), ('total_ms', C.c_double),
+                ('flops', C.c_double), ('bytes', C.c_double)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); must list every symbol declared in include/rohm_hip.h
 SIGNATURES = {
     'rohm_last_error': (C.c_char_p, []),
     'rohm_version': (C.c_int, []),
+    'rohm_profile_start': (C.c_int, [C.c_int]),
+    'rohm_profile_stop': (C.c_int, [C.POINTER(ProfileRow), C.c_int, C.POINTER(C.c_int)]),
     'rohm_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'rohm_layernorm_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -106,3 +113,16 @@ def require_hip(*tensors):
         if t is not None and not t.is_cuda:
             raise RohmHipError('this operator only runs on an AMD GPU through librohm_hip.so; '
                                'got a CPU tensor and there is deliberately no CPU fallback')
+
+
+def profile_start(step_stride=1):
+    check(lib().rohm_profile_start(step_stride), 'rohm_profile_start')
+
+
+def profile_stop():
+    """-> {label: dict(launches, total_ms, flops, bytes)} measured with HIP events on the launch stream."""
+    rows = (ProfileRow * 64)()
+    n = C.c_int(0)
+    check(lib().rohm_profile_stop(rows, 64, C.byref(n)), 'rohm_profile_stop')
+    return {rows[i].name.decode(): dict(launches=int(rows[i].launches), total_ms=rows[i].total_ms,
+                                        flops=rows[i].flops, bytes=rows[i].bytes) for i in range(n.value)}

@@ -1,5 +1,7 @@
 // C-ABI glue: error channel + the building-block entry points declared in include/rohm_hip.h.
 #include <string>
+#include <string.h>
+#include <vector>
 #include "common.h"
 
 namespace rohm {
@@ -14,9 +16,75 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace rohm
 
+namespace rohm {
+namespace prof {
+bool g_active = false;
+static bool g_enabled = false;
+static int g_stride = 1;
+struct Rec { const char* label; double flops, bytes; hipEvent_t a, b; };
+static std::vector<Rec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+Scope::Scope(const char* label, double flops, double bytes, hipStream_t s) : idx(-1), stream(s) {
+    if (!g_active) return;
+    Rec r{label, flops, bytes, get_event(), get_event()};
+    (void)hipEventRecord(r.a, s);
+    idx = (int)g_recs.size();
+    g_recs.push_back(r);
+}
+Scope::~Scope() {
+    if (idx >= 0) (void)hipEventRecord(g_recs[idx].b, stream);
+}
+void set_step(int step) { g_active = g_enabled && (step % g_stride == 0); }
+}  // namespace prof
+}  // namespace rohm
+
 using namespace rohm;
 
 extern "C" {
+
+int rohm_profile_start(int step_stride) {
+    prof::g_enabled = true;
+    prof::g_stride = step_stride > 0 ? step_stride : 1;
+    prof::g_active = true;
+    return ROHM_OK;
+}
+
+int rohm_profile_stop(rohm_profile_row* rows, int max_rows, int* n_rows) {
+    prof::g_enabled = false;
+    prof::g_active = false;
+    int n = 0;
+    for (auto& r : prof::g_recs) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+        prof::g_pool.push_back(r.a);
+        prof::g_pool.push_back(r.b);
+        if (e != hipSuccess) continue;
+        int k = 0;
+        for (; k < n; ++k)
+            if (strncmp(rows[k].name, r.label, sizeof(rows[k].name) - 1) == 0) break;
+        if (k == n) {
+            if (n >= max_rows) continue;
+            memset(&rows[n], 0, sizeof(rows[n]));
+            strncpy(rows[n].name, r.label, sizeof(rows[n].name) - 1);
+            ++n;
+        }
+        rows[k].launches += 1;
+        rows[k].total_ms += ms;
+        rows[k].flops += r.flops;
+        rows[k].bytes += r.bytes;
+    }
+    prof::g_recs.clear();
+    if (n_rows) *n_rows = n;
+    return ROHM_OK;
+}
 
 const char* rohm_last_error(void) { return g_err.c_str(); }
 int rohm_version(void) { return 100; }

@@ -151,6 +151,8 @@ int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, hipStr
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
+    prof::Scope ps("attention", 4.0 * AT_S * AT_S * AT_DH * (double)n_seq * n_head,
+                   4.0 * 4.0 * AT_S * AT_DH * (double)n_seq * n_head, s);
     hipLaunchKernelGGL(attention_f32_kernel, dim3(n_seq * n_head), dim3(AT_THREADS), lds, s, qkv, ctx, n_head);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;

@@ -40,6 +40,18 @@ void set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
+// ---- in-library launch profiler (HIP events on the launch stream; see rohm_profile_* in rohm_hip.h) --
+namespace prof {
+extern bool g_active;          // true while this launch should be bracketed
+struct Scope {
+    Scope(const char* label, double flops, double bytes, hipStream_t s);
+    ~Scope();
+    int idx;
+    hipStream_t stream;
+};
+void set_step(int step);       // sample loops call this; activates every `stride`-th step
+}  // namespace prof
+
 constexpr int kNumXCD = 8;
 
 // Bijective XCD-aware remap of a linear workgroup id (guide §5 "XCD swizzle must be

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 int launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s) {
     ROHM_ARG_CHECK(M > 0, "layernorm: empty");
     const dim3 grid((M + 3) / 4), block(256);
+    prof::Scope ps("layernorm", 0.0, 8.0 * M * D, s);
     if (D == 512) hipLaunchKernelGGL(layernorm_kernel<512>, grid, block, 0, s, x, g, b, M);
     else if (D == 256) hipLaunchKernelGGL(layernorm_kernel<256>, grid, block, 0, s, x, g, b, M);
     else if (D == 1024) hipLaunchKernelGGL(layernorm_kernel<1024>, grid, block, 0, s, x, g, b, M);

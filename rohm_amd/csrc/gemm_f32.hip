@@ -194,6 +194,12 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
+    static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv", "gemm_embed",
+                                         "gemm_out_t"};
+    static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64",
+                                           "gemm_embed/64", "gemm_out_t/64"};
+    prof::Scope ps(BN == 128 ? kNames[EPI] : kNames64[EPI], 2.0 * p.M * p.N * p.K,
+                   4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
     hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI>), dim3(tiles), dim3(256), lds, s, p);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;

@@ -197,6 +197,7 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     // timestep token(s)
     {
         const int rows = t_dev ? B : 1;
+        prof::Scope ps("timestep_token", 4.0 * D * D * rows, 8.0 * D * D, s);
         hipLaunchKernelGGL(timestep_token_kernel, dim3(rows), dim3(D), 2 * D * sizeof(float), s, p->pe, p->pe_len,
                            t_dev, t_host, p->t_w0T, p->t_b0, p->t_w2T, p->t_b2, w.tab0, D);
         ROHM_LAUNCH_CHECK();
@@ -247,6 +248,7 @@ static int launch_pack(const rohm_posenet* p, const float* src, float* apack, in
     const int C = p->Cin, S = T + 1;
     const int zero_to = which == 0 ? C : (p->KP - C);   // second half also clears the K padding
     dim3 grid((zero_to + 31) / 32, (T + 31) / 32, B);
+    prof::Scope ps("pack", 0.0, 8.0 * B * C * T, s);
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, s, src, apack, C, T, S, p->KP, which * C, zero_to);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
@@ -257,6 +259,7 @@ static int launch_finish(float* x0, const float* cond, const float* x_t, const f
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (sigma == 0.f) noise = nullptr;
+    prof::Scope ps("finish_ddpm", 0.0, 4.0 * n * (x_prev ? 4 : 1), s);
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x0, cond, x_t, noise, x_prev, c1, c2,
                        sigma, traj, C, T, n);
     ROHM_LAUNCH_CHECK();
@@ -409,6 +412,7 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
     const size_t n = (size_t)B * h->Cin * T;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;   // cond is constant over the loop
     for (int i = 0; i < n_steps; ++i) {
+        prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
         ROHM_ARG_CHECK(sigma == 0.f || noise, "posenet_sample_loop: noise is required when sigma != 0");
         if ((rc = launch_pack(h, x, w.apack, B, T, 0, s))) return rc;

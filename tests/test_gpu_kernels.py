@@ -1,0 +1,91 @@
+"""GPU: each hand-written kernel against a float64 CPU evaluation of the same op (through the C ABI)."""
+import math
+
+import pytest
+import torch
+
+from helpers import max_abs, seeded
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda', 0)
+
+
+@pytest.mark.parametrize('M,N,K', [(144, 512, 512), (288, 1536, 512), (144 * 3, 512, 1024), (100, 70, 64),
+                                   (272, 288, 512), (1, 16, 32), (144 * 64, 512, 512)])
+@pytest.mark.parametrize('epi', [0, 1, 2])
+def test_gemm(M, N, K, epi):
+    from rohm_amd import ops
+    a, w = seeded(M + N, M, K), seeded(K + 7, N, K) / math.sqrt(K)
+    bias, res = seeded(3, N), seeded(4, M, N)
+    ref = a.double() @ w.double().T + bias.double()
+    if epi == 1:
+        ref = nets.gelu_erf(ref)
+    if epi == 2:
+        ref = ref + res.double()
+    d = _dev()
+    out = ops.gemm(a.to(d), w.to(d), bias.to(d), res.to(d) if epi == 2 else None, epi)
+    # A = I check with asymmetric W (catches transposed C writes, guide G9)
+    assert max_abs(out.cpu(), ref) < 2e-5 * math.sqrt(K / 32)
+
+
+def test_gemm_identity_asymmetric():
+    from rohm_amd import ops
+    d = _dev()
+    a = torch.eye(144, 160)[:, :160].contiguous()
+    w = torch.arange(96 * 160, dtype=torch.float32).reshape(96, 160) / 100.0
+    out = ops.gemm(a.to(d), w.to(d))
+    assert torch.equal(out.cpu(), w[:, :144].T.contiguous())
+
+
+@pytest.mark.parametrize('M', [4, 144, 1000])
+def test_layernorm(M):
+    from rohm_amd import ops
+    x, g, b = seeded(M, M, 512) * 3 + 0.5, seeded(1, 512), seeded(2, 512)
+    ref = nets.layer_norm(x.double(), g.double(), b.double())
+    d = _dev()
+    out = ops.layernorm_(x.to(d), g.to(d), b.to(d))
+    assert max_abs(out.cpu(), ref) < 5e-6
+
+
+@pytest.mark.parametrize('n_seq,n_head', [(1, 4), (3, 4), (2, 2)])
+def test_attention(n_seq, n_head):
+    from rohm_amd import ops
+    D = n_head * 128
+    qkv = seeded(n_seq * 10 + n_head, n_seq * 144, 3 * D)
+    q, k, v = qkv.double().view(n_seq, 144, 3, n_head, 128).permute(2, 0, 3, 1, 4)
+    # the kernel expects q pre-scaled; scores up to ~|N(0,128)| exercise the max-subtraction
+    ref = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(n_seq * 144, D)
+    out = ops.attention(qkv.to(_dev()), n_seq, n_head)
+    # |score| reaches ~40 here, so fp32 rounding of the score itself (~2e-6) is amplified by exp
+    assert max_abs(out.cpu(), ref) < 1e-4
+    qkv2 = qkv.clone()
+    qkv2[:, :D] *= 128 ** -0.5
+    q2 = qkv2.double().view(n_seq, 144, 3, n_head, 128).permute(2, 0, 3, 1, 4)[0]
+    ref2 = (torch.softmax(q2 @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * 144, D)
+    out2 = ops.attention(qkv2.to(_dev()), n_seq, n_head)
+    assert max_abs(out2.cpu(), ref2) < 5e-6
+
+
+def test_ddpm_step_kernels():
+    from rohm_amd import ops
+    from oracle import diffusion as odiff
+    d = _dev()
+    B, n = 3, 294 * 143
+    x_t, x0, nz, g1, g2 = (seeded(s, B, n) for s in range(5))
+    out = ops.ddpm_step(x_t.to(d), x0.to(d), nz.to(d), 0.25, 0.75, 0.5, g1.to(d), 2.0)
+    assert max_abs(out.cpu(), 0.25 * x0 + 0.75 * x_t + 2.0 * g1 + 0.5 * nz) < 1e-6
+    tab = odiff.tables(odiff.cosine_betas(1000))
+    import numpy as np
+    tabs = np.stack([tab['coef1'], tab['coef2'], tab['variance'], tab['log_variance']], 1).astype(np.float32)
+    t = torch.tensor([999, 0, 37])
+    out = ops.ddpm_step_table(x_t.to(d), x0.to(d), nz.to(d), torch.from_numpy(tabs).to(d), t.to(d),
+                              g1.to(d), 3e5, g2.to(d), 1e5)
+    tt = torch.from_numpy(tabs)[t]
+    ref = tt[:, 0:1] * x0 + tt[:, 1:2] * x_t + 3e5 * tt[:, 2:3] * g1 + 1e5 * tt[:, 2:3] * g2 \
+        + (t != 0).float()[:, None] * torch.exp(0.5 * tt[:, 3:4]) * nz
+    assert max_abs(out.cpu(), ref) < 1e-4 * float(ref.abs().max())
