@@ -59,12 +59,24 @@ def synthetic_cond(B, device, seed):
     return cond.permute(0, 2, 1).unsqueeze(2).contiguous().to(device)
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(batch=8, budget_s=12.0):
     """Oracle port of one PoseNet p_sample step on the host cores, extrapolated to 1000 steps."""
     from oracle import diffusion as odiff
     from oracle import nets
     from rohm_amd.utils import synth
-    cores = os.cpu_count() or 1
+    cores = min(usable_cores(), 64)      # torch intra-op scaling flattens (and then degrades) past ~64 threads
     torch.set_num_threads(cores)
     sd = synth.posenet_state_dict(0)
     tab = odiff.tables(odiff.cosine_betas(1000))
@@ -86,7 +98,8 @@ def cpu_baseline(batch=8, budget_s=12.0):
             if el > budget_s or n >= 200:
                 break
     sec_per_step = el / n
-    return {'value': batch / (sec_per_step * 1000.0), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+    return {'value': batch / (sec_per_step * 1000.0), 'unit': 'clips/s', 'cores': cores,
+            'host_cpus': os.cpu_count(), 'kind': 'port',
             'sample': f'oracle (torch-CPU fp32 restatement) PoseNet p_sample, B={batch}, {n} timed steps '
                       f'({el:.1f} s, {sec_per_step * 1e3:.1f} ms/step) extrapolated to 1000 steps',
             'torch_threads': torch.get_num_threads()}

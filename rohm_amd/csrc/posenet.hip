@@ -21,6 +21,7 @@
 namespace rohm {
 
 constexpr int kMaxTok = 256;
+constexpr int kLoopChunk = 1024;   // max denoising steps per rohm_posenet_sample_loop call
 
 struct LayerW {
     float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
@@ -155,7 +156,8 @@ __global__ void build_tab_kernel(const float* __restrict__ pe, const float* __re
 
 // ----------------------------------------------------------------------------- workspace
 struct Workspace {
-    float *apack, *h, *y, *qkv, *ctx, *ff, *tab0, *x0;
+    float *apack, *h, *y, *qkv, *ctx, *ff, *tab0, *x0, *tok_all;
+    int64_t* t_all;
     size_t floats;
 };
 
@@ -178,6 +180,8 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
     w.ff = take(M * p->F);
     w.tab0 = take((size_t)B * p->D);
     w.x0 = take((size_t)B * p->Cin * T);
+    w.tok_all = take((size_t)kLoopChunk * p->D);     // timestep tokens of one sample-loop call
+    w.t_all = reinterpret_cast<int64_t*>(take(2 * (size_t)kLoopChunk));
     w.floats = off;
     return w;
 }
@@ -192,10 +196,10 @@ static int check_shape(const rohm_posenet* p, int B, int T) {
 
 // Network body: from packed input (w.apack complete) to x0 channels [traj, Cin) in `x0_out`.
 static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t* t_dev, int64_t t_host,
-                       float* x0_out, int B, int T, hipStream_t s) {
+                       const float* tok_pre, float* x0_out, int B, int T, hipStream_t s) {
     const int S = T + 1, D = p->D, M = B * S;
-    // timestep token(s)
-    {
+    // timestep token(s): per sample from device timesteps, or one precomputed row shared by the batch
+    if (!tok_pre) {
         const int rows = t_dev ? B : 1;
         prof::Scope ps("timestep_token", 4.0 * D * D * rows, 8.0 * D * D, s);
         hipLaunchKernelGGL(timestep_token_kernel, dim3(rows), dim3(D), 2 * D * sizeof(float), s, p->pe, p->pe_len,
@@ -206,8 +210,8 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     {   // fused input embed (+cond embed, + biases, + positional table)
         GemmParams g{};
         g.A = w.apack; g.lda = p->KP; g.W = p->w_embed; g.ldw = p->KP; g.C = w.h; g.ldc = D;
-        g.M = M; g.N = D; g.K = p->KP; g.S = S; g.tab = p->tab; g.tab0 = w.tab0; g.ldtab = D;
-        g.ldtab0 = t_dev ? D : 0;
+        g.M = M; g.N = D; g.K = p->KP; g.S = S; g.tab = p->tab; g.tab0 = tok_pre ? tok_pre : w.tab0; g.ldtab = D;
+        g.ldtab0 = (t_dev && !tok_pre) ? D : 0;
         if ((rc = launch_gemm(g, EPI_EMBED, s))) return rc;
     }
     float* h = w.h;
@@ -390,7 +394,7 @@ int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float*
     }
     if ((rc = launch_pack(h, x_t, w.apack, B, T, 0, s))) return rc;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;
-    if ((rc = run_network(h, w, t, 0, x0_out, B, T, s))) return rc;
+    if ((rc = run_network(h, w, t, 0, nullptr, x0_out, B, T, s))) return rc;
     const size_t n = (size_t)B * h->Cin * T;
     return launch_finish(x0_out, cond, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, h->traj, h->Cin, T, n, s);
 }
@@ -410,14 +414,24 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
         return ROHM_ERR_WORKSPACE;
     }
     const size_t n = (size_t)B * h->Cin * T;
+    ROHM_ARG_CHECK(n_steps <= kLoopChunk, "posenet_sample_loop: at most %d steps per call", kLoopChunk);
+    if (n_steps == 0) return ROHM_OK;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;   // cond is constant over the loop
+    // all timestep tokens of this call in one launch (the embedder depends on t only, heads.py:145-146)
+    ROHM_HIP_CHECK(hipMemcpyAsync(w.t_all, t_model, (size_t)n_steps * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    {
+        prof::Scope ps("timestep_token", 4.0 * h->D * h->D * n_steps, 8.0 * h->D * h->D, s);
+        hipLaunchKernelGGL(timestep_token_kernel, dim3(n_steps), dim3(h->D), 2 * h->D * sizeof(float), s, h->pe,
+                           h->pe_len, w.t_all, (int64_t)0, h->t_w0T, h->t_b0, h->t_w2T, h->t_b2, w.tok_all, h->D);
+        ROHM_LAUNCH_CHECK();
+    }
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
         ROHM_ARG_CHECK(sigma == 0.f || noise, "posenet_sample_loop: noise is required when sigma != 0");
         if ((rc = launch_pack(h, x, w.apack, B, T, 0, s))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
-        if ((rc = run_network(h, w, nullptr, t_model[i], x0, B, T, s))) return rc;
+        if ((rc = run_network(h, w, nullptr, t_model[i], w.tok_all + (size_t)i * h->D, x0, B, T, s))) return rc;
         if ((rc = launch_finish(x0, cond, x, noise ? noise + (size_t)i * n : nullptr, x, c1, c2, sigma, h->traj,
                                 h->Cin, T, n, s)))
             return rc;
