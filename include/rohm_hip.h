@@ -151,6 +151,44 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
                              const float* coef, const float* noise, float* x0_last, int n_steps, int B,
                              int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
 
+/* ------------------------------------------------------------------------- SMPL-X + guidance
+ * Joints-only SMPL-X (third-party smplx==0.1.28 `SMPLX.forward` / `lbs`, called from
+ * data_loaders/motion_representation.py:389) and the two test-time guidance gradients of
+ * model/posenet.py:196-317.  The hot path reads only joints[:, 0:22]; those depend on
+ * J_regressor.(v_template + shapedirs.beta) and the kinematic chain, never on vertices, so the
+ * regressor is folded once at create time (fp64 accumulation) and a step is O(22) 3x3 products
+ * per frame instead of full linear blend skinning. */
+typedef struct rohm_smplx rohm_smplx_t;
+
+/* v_template [V,3], shapedirs [V,3,n_shape_total] (first 10 = betas), J_regressor [J,V], parents int32[J];
+ * pointers may be host or device memory. */
+int rohm_smplx_create(rohm_smplx_t** out, const float* v_template, const float* shapedirs, int n_shape_total,
+                      const float* J_regressor, const int32_t* parents, int V, int J, int device);
+void rohm_smplx_destroy(rohm_smplx_t* h);
+
+/* joints[N, n_out, 3] (n_out <= 22) from axis-angle pose [N, n_pose, 3] (global orient first; joints beyond
+ * n_pose are unrotated), betas [N,10], transl [N,3]: Rodrigues (angle = |r + 1e-8|) + forward kinematics. */
+int rohm_smplx_joints(const rohm_smplx_t* h, const float* pose, int n_pose, const float* betas,
+                      const float* transl, int N, float* joints, int n_out, rohm_stream_t stream);
+
+size_t rohm_guidance_workspace_bytes(int B, int T);
+
+/* guide_skating_with_smpl (model/posenet.py:196-257, compute_grad='x_0'): x0 [B,294,1,T] normalised
+ * prediction, mean294/std294 the dataset statistics -> grad_out [B,294,1,T] = d(-loss)/dx0 with channels
+ * [0,22) and [290,294) zeroed.  counts2 (device float[2]) receives the two skating-mask counts
+ * (abs-trajectory, SMPL-X recovery); both zero <=> the reference returns a 0-d zero, and grad_out is
+ * then all zeros. */
+int rohm_guidance_skating_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                               int B, int T, float* grad_out, float* counts2, void* ws, size_t ws_bytes,
+                               rohm_stream_t stream);
+
+/* guide_2d_projection_with_smpl (model/posenet.py:260-317): transf_matrix [B,4,4] (affine, inverted on the
+ * device), cam_R [3,3], cam_t [3], focal / center [B,2], kp2d [B, kp_frames, 22, 3] (u, v, confidence). */
+int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                              const float* transf_matrix, const float* cam_R, const float* cam_t,
+                              const float* focal, const float* center, const float* kp2d, int kp_frames, int B,
+                              int T, float* grad_out, void* ws, size_t ws_bytes, rohm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

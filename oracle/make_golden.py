@@ -93,6 +93,34 @@ def main():
                                      compute_loss=False)
             np.savez_compressed(os.path.join(OUT, 'trajnet_loop100.npz'), weight_seed=21, cond_seed=204,
                                 torch_seed=4321, steps=100, y=y.numpy())
+    # ---- geometry + guidance: the reference's own functions around the oracle body model ----------------
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    refload.set_body_model(body)
+    mean, std = synth.synthetic_stats(0)
+
+    class GDS:
+        pose_feat_dim, traj_feat_dim, joints_num = 272, 22, 22
+        Mean, Std = mean, std
+        cam_R = torch.tensor(synth.SYNTH_CAM_R)
+        cam_t = torch.tensor(synth.SYNTH_CAM_T)
+    gnet = ref.posenet.PoseNet(GDS(), 294, latent_dim=64, ff_size=64, num_layers=1, num_heads=1, traj_feat_dim=22,
+                               device='cpu').eval()
+    gnet.smplx_model = body
+    x0 = synth.plausible_motion(3, 2, 143, mean, std)
+    full = x0[:, :, 0].permute(0, 2, 1) * torch.from_numpy(std) + torch.from_numpy(mean)
+    d = G.split_repr(full)
+    j_abs = ref.motion_repr.recover_from_repr_smpl(d, recover_mode='joint_abs_traj', smplx_model=body)
+    j_smpl = ref.motion_repr.recover_from_repr_smpl(d, recover_mode='smplx_params', smplx_model=body)
+    g_sk = gnet.guide_skating_with_smpl({}, {'pred_xstart': x0}, None, compute_grad='x_0')
+    cam = synth.synthetic_camera_batch(0, 2)
+    g_2d = gnet.guide_2d_projection_with_smpl(cam, {'pred_xstart': x0}, None, compute_grad='x_0')
+    r6 = seeded(301, 64, 6)
+    Rm = ref.quaternion.rot6d_to_rotmat(r6)
+    aa = ref.konia.rotation_matrix_to_angle_axis(Rm)
+    np.savez_compressed(os.path.join(OUT, 'guidance.npz'), body_seed=0, stats_seed=0, motion_seed=3, cam_seed=0,
+                        j_abs=j_abs.numpy(), j_smpl=j_smpl.numpy(), g_skating=g_sk.numpy(), g_2d=g_2d.numpy(),
+                        r6_seed=301, rotmat=Rm.numpy(), angle_axis=aa.numpy())
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -66,6 +66,16 @@ SIGNATURES = {
     'rohm_posenet_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                            C.c_void_p]),
+    'rohm_smplx_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int]),
+    'rohm_smplx_destroy': (None, [C.c_void_p]),
+    'rohm_smplx_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_void_p]),
+    'rohm_guidance_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'rohm_guidance_skating_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'rohm_guidance_proj2d_grad': (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
 }
 
 

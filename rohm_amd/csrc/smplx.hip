@@ -1,0 +1,645 @@
+// SMPL-X joints-only forward kinematics and the two test-time guidance gradients, with an ANALYTIC backward.
+//
+// Reference: model/posenet.py:196-317 (guide_skating_with_smpl, guide_2d_projection_with_smpl),
+// data_loaders/motion_representation.py:285-398 (recover_from_repr_smpl), data_loaders/common/
+// quaternion.py:482-501 (rot6d_to_rotmat) and the third-party smplx==0.1.28 `lbs`.
+//
+// What the reference does per guided step: full SMPL-X LBS (10 475 vertices, 54 MFLOP / frame) under
+// autograd, although the losses read 4 (skating) or 10 (re-projection) of the first 22 joints.  Those joints
+// depend only on  J_rest = J_regressor.v_template + (J_regressor.shapedirs).beta  and the kinematic chain, so:
+//   * create():  fold J_regressor into a [J,3] template and a [J,3,10] shape basis once (fp64 accumulate);
+//   * per step:  one thread per frame does 6-D -> R (Gram-Schmidt), FK, loss gradient and the hand-derived
+//                reverse pass, reading the [B, 294, 1, T] tensor with T-contiguous (coalesced) accesses and
+//                writing the full 294-channel gradient column (zeros where the reference zeroes).
+// The reference goes R -> quaternion -> axis-angle -> Rodrigues between Gram-Schmidt and FK; that round trip is
+// the identity on SO(3) and its Jacobian restricted to the tangent space is the identity too, so FK consumes
+// the Gram-Schmidt matrices directly (agreement with the full chain is checked against the oracle).
+#include <vector>
+#include "common.h"
+
+namespace rohm {
+constexpr int NJ = 22;          // body joints used by the hot path
+constexpr int NBETA = 10;
+constexpr int C_TOTAL = 294;    // utils/other_utils.py:17-37
+// channel offsets of the 294-d representation
+constexpr int CH_ROOT_ANG = 0, CH_ROOT_POS = 2, CH_ROOT_H = 6, CH_ROT6D = 7, CH_TRANS = 16, CH_LOCAL = 22,
+              CH_POSE6D = 154, CH_BETAS = 280, CH_CONTACT = 290;
+}  // namespace rohm
+
+struct rohm_smplx {
+    int V, J, device;
+    float* d_Jt;       // [J, 3]        J_regressor . v_template
+    float* d_Js;       // [J, 3, 10]    J_regressor . shapedirs[:, :, :10]
+    int* d_parents;    // [J]
+    int parents[64];
+};
+
+namespace rohm {
+
+struct Mat3 { float m[9]; };
+
+__device__ __forceinline__ void mat_mul(const float* a, const float* b, float* c) {   // c = a b
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+__device__ __forceinline__ void mat_vec(const float* a, const float* v, float* o) {   // o = a v
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = a[i * 3] * v[0] + a[i * 3 + 1] * v[1] + a[i * 3 + 2] * v[2];
+}
+__device__ __forceinline__ void matT_vec(const float* a, const float* v, float* o) {  // o = a^T v
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = a[i] * v[0] + a[3 + i] * v[1] + a[6 + i] * v[2];
+}
+
+// Gram-Schmidt of the interleaved 6-D vector x = (a1x a2x a1y a2y a1z a2z) (quaternion.py:494-501).
+// R columns are b1, b2, b3; R is row-major.
+__device__ __forceinline__ void rot6d_fwd(const float* x, float* R) {
+    const float a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+    const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    const float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { R[i * 3] = b1[i]; R[i * 3 + 1] = b2[i]; R[i * 3 + 2] = b3[i]; }
+}
+
+// Reverse pass of rot6d_fwd: dR (row-major, dL/dR) -> dx[6].
+__device__ __forceinline__ void rot6d_bwd(const float* x, const float* dR, float* dx) {
+    const float a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+    const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    const float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    float g1[3] = {dR[0], dR[3], dR[6]}, g2[3] = {dR[1], dR[4], dR[7]};
+    const float g3[3] = {dR[2], dR[5], dR[8]};
+    // b3 = b1 x b2:  db1 += b2 x g3,  db2 += g3 x b1
+    g1[0] += b2[1] * g3[2] - b2[2] * g3[1]; g1[1] += b2[2] * g3[0] - b2[0] * g3[2]; g1[2] += b2[0] * g3[1] - b2[1] * g3[0];
+    g2[0] += g3[1] * b1[2] - g3[2] * b1[1]; g2[1] += g3[2] * b1[0] - g3[0] * b1[2]; g2[2] += g3[0] * b1[1] - g3[1] * b1[0];
+    // b2 = u / |u|
+    const float s2 = b2[0] * g2[0] + b2[1] * g2[1] + b2[2] * g2[2];
+    const float du[3] = {(g2[0] - s2 * b2[0]) / n2, (g2[1] - s2 * b2[1]) / n2, (g2[2] - s2 * b2[2]) / n2};
+    // u = a2 - (b1.a2) b1
+    const float sb = du[0] * b1[0] + du[1] * b1[1] + du[2] * b1[2];
+    const float da2[3] = {du[0] - sb * b1[0], du[1] - sb * b1[1], du[2] - sb * b1[2]};
+    // d/db1 of u = a2 - (b1.a2) b1 contracted with du:  -(d du + (b1.du) a2)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g1[i] += -d * du[i] - sb * a2[i];
+    // b1 = a1 / |a1|
+    const float s1 = b1[0] * g1[0] + b1[1] * g1[1] + b1[2] * g1[2];
+    const float da1[3] = {(g1[0] - s1 * b1[0]) / n1, (g1[1] - s1 * b1[1]) / n1, (g1[2] - s1 * b1[2]) / n1};
+    dx[0] = da1[0]; dx[2] = da1[1]; dx[4] = da1[2];
+    dx[1] = da2[0]; dx[3] = da2[1]; dx[5] = da2[2];
+}
+
+// Rodrigues as smplx.lbs.batch_rodrigues: angle = |r + 1e-8|, R = I + sin K + (1 - cos) K^2.
+__device__ __forceinline__ void rodrigues(const float* r, float* R) {
+    const float ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
+    const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float x = r[0] / ang, y = r[1] / ang, z = r[2] / ang;
+    const float s = sinf(ang), c1 = 1.f - cosf(ang);
+    // K = [[0,-z,y],[z,0,-x],[-y,x,0]];  K^2 = r r^T - |dir|^2 I (dir may be slightly non-unit, keep exact form)
+    const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+    float K2[9];
+    mat_mul(K, K, K2);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.f : 0.f) + s * K[i] + c1 * K2[i];
+}
+
+struct FkCtx {
+    float R[NJ][9];     // local rotations
+    float G[NJ][9];     // world rotations
+    float Jr[NJ][3];    // rest joints for this frame's betas
+    float P[NJ][3];     // posed joints (without transl)
+};
+
+__device__ __forceinline__ void rest_joints(const float* __restrict__ Jt, const float* __restrict__ Js,
+                                            const float* beta, float (*Jr)[3]) {
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = Jt[j * 3 + c];
+#pragma unroll
+            for (int k = 0; k < NBETA; ++k) v = fmaf(Js[(j * 3 + c) * NBETA + k], beta[k], v);
+            Jr[j][c] = v;
+        }
+}
+
+__device__ __forceinline__ void fk_forward(FkCtx& f, const int* __restrict__ parents) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) f.G[0][i] = f.R[0][i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f.P[0][c] = f.Jr[0][c];
+    for (int j = 1; j < NJ; ++j) {
+        const int p = parents[j];
+        mat_mul(f.G[p], f.R[j], f.G[j]);
+        const float off[3] = {f.Jr[j][0] - f.Jr[p][0], f.Jr[j][1] - f.Jr[p][1], f.Jr[j][2] - f.Jr[p][2]};
+        float w[3];
+        mat_vec(f.G[p], off, w);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f.P[j][c] = f.P[p][c] + w[c];
+    }
+}
+
+// Reverse pass of fk_forward.  gP[j] = dL/dP[j] on entry (overwritten).  Outputs dR[j] (dL/dR_j, j >= 1; the
+// global orientation lives in a zeroed channel range) and dJr (dL/dJrest).
+__device__ __forceinline__ void fk_backward(const FkCtx& f, const int* __restrict__ parents, float (*gP)[3],
+                                            float (*dR)[9], float (*dJr)[3]) {
+    float dG[NJ][9];
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dG[j][i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dJr[j][c] = 0.f;
+    }
+    for (int j = NJ - 1; j >= 1; --j) {
+        const int p = parents[j];
+        // P[j] = P[p] + G[p] off
+        const float off[3] = {f.Jr[j][0] - f.Jr[p][0], f.Jr[j][1] - f.Jr[p][1], f.Jr[j][2] - f.Jr[p][2]};
+        float doff[3];
+        matT_vec(f.G[p], gP[j], doff);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gP[p][c] += gP[j][c];
+            dJr[j][c] += doff[c];
+            dJr[p][c] -= doff[c];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dG[p][a * 3 + b] += gP[j][a] * off[b];
+        // G[j] = G[p] R[j]:  dG[p] += dG[j] R[j]^T,  dR[j] = G[p]^T dG[j]
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float s = 0.f, r = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    s += dG[j][a * 3 + k] * f.R[j][b * 3 + k];
+                    r += f.G[p][k * 3 + a] * dG[j][k * 3 + b];
+                }
+                dG[p][a * 3 + b] += s;
+                dR[j][a * 3 + b] = r;
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dJr[0][c] += gP[0][c];
+}
+
+// Loads + de-normalises the channels the SMPL-X path needs for frame (b, t) and runs FK.
+struct FrameIn {
+    float x6[NJ][6];     // 6-D rotations (0 = global orient)
+    float beta[NBETA];
+    float trans[3];
+};
+
+__device__ __forceinline__ float ld(const float* __restrict__ x0, const float* __restrict__ mean,
+                                    const float* __restrict__ stdv, size_t base, int T, int c) {
+    return x0[base + (size_t)c * T] * stdv[c] + mean[c];
+}
+
+__device__ __forceinline__ void load_frame(const float* __restrict__ x0, const float* __restrict__ mean,
+                                           const float* __restrict__ stdv, size_t base, int T, FrameIn& in) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in.x6[0][k] = ld(x0, mean, stdv, base, T, CH_ROT6D + k);
+    for (int j = 1; j < NJ; ++j)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in.x6[j][k] = ld(x0, mean, stdv, base, T, CH_POSE6D + (j - 1) * 6 + k);
+#pragma unroll
+    for (int k = 0; k < NBETA; ++k) in.beta[k] = ld(x0, mean, stdv, base, T, CH_BETAS + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) in.trans[k] = ld(x0, mean, stdv, base, T, CH_TRANS + k);
+}
+
+__device__ __forceinline__ void smplx_fk(const FrameIn& in, const float* Jt, const float* Js, const int* parents,
+                                         FkCtx& f) {
+    for (int j = 0; j < NJ; ++j) rot6d_fwd(in.x6[j], f.R[j]);
+    rest_joints(Jt, Js, in.beta, f.Jr);
+    fk_forward(f, parents);
+}
+
+// abs-trajectory joint j >= 1 (recover_from_repr_smpl 'joint_abs_traj'): qrot(qinv(q), v) + (x, y, 0),
+// q = (cos a, 0, 0, sin a).  With u = (0, 0, -sin a), w = cos a:  v' = v + 2 (w (u x v) + u x (u x v)).
+__device__ __forceinline__ void abs_joint(float ang, const float* pos, const float* v, float* o) {
+    const float w = cosf(ang), uz = -sinf(ang);
+    const float uv[3] = {-uz * v[1], uz * v[0], 0.f};
+    const float uuv[3] = {-uz * uv[1], uz * uv[0], 0.f};
+    o[0] = v[0] + 2.f * (w * uv[0] + uuv[0]) + pos[0];
+    o[1] = v[1] + 2.f * (w * uv[1] + uuv[1]) + pos[1];
+    o[2] = v[2];
+}
+// transpose of the linear map above applied to g (gradient wrt v)
+__device__ __forceinline__ void abs_joint_T(float ang, const float* g, float* o) {
+    const float w = cosf(ang), uz = sinf(ang);   // conjugate quaternion
+    const float uv[3] = {-uz * g[1], uz * g[0], 0.f};
+    const float uuv[3] = {-uz * uv[1], uz * uv[0], 0.f};
+    o[0] = g[0] + 2.f * (w * uv[0] + uuv[0]);
+    o[1] = g[1] + 2.f * (w * uv[1] + uuv[1]);
+    o[2] = g[2];
+}
+
+__constant__ int kFoot[4] = {7, 10, 8, 11};                       // model/posenet.py:31
+__constant__ int kProj[10] = {16, 18, 20, 17, 19, 21, 4, 5, 7, 8}; // model/posenet.py:308
+
+// ---------------------------------------------------------------------------------------- skating guidance
+// pass 1: foot joints of both recoveries for every frame -> feet[B, T, 2, 4, 3]
+__global__ __launch_bounds__(64) void skating_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, const float* __restrict__ Jt,
+                                                         const float* __restrict__ Js, const int* __restrict__ parents,
+                                                         float* __restrict__ feet, int B, int T) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * T) return;
+    const int b = idx / T, t = idx % T;
+    const size_t base = (size_t)b * C_TOTAL * T + t;
+    FrameIn in;
+    load_frame(x0, mean, stdv, base, T, in);
+    FkCtx f;
+    smplx_fk(in, Jt, Js, parents, f);
+    const float ang = ld(x0, mean, stdv, base, T, CH_ROOT_ANG);
+    const float pos[3] = {ld(x0, mean, stdv, base, T, CH_ROOT_POS), ld(x0, mean, stdv, base, T, CH_ROOT_POS + 1),
+                          ld(x0, mean, stdv, base, T, CH_ROOT_H)};
+    float* o = feet + (size_t)idx * 24;
+    for (int k = 0; k < 4; ++k) {
+        const int j = kFoot[k];
+        const float v[3] = {ld(x0, mean, stdv, base, T, CH_LOCAL + 3 * j), ld(x0, mean, stdv, base, T, CH_LOCAL + 3 * j + 1),
+                            ld(x0, mean, stdv, base, T, CH_LOCAL + 3 * j + 2)};
+        float a[3];
+        abs_joint(ang, pos, v, a);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o[k * 3 + c] = a[c];
+            o[12 + k * 3 + c] = f.P[j][c] + in.trans[c];
+        }
+    }
+}
+
+// pass 2: mask counts of both recoveries (posenet.py:224-246).  counts[0] = abs-traj, counts[1] = smplx.
+__global__ __launch_bounds__(256) void skating_count_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
+                                                            const float* __restrict__ stdv,
+                                                            const float* __restrict__ feet, float* __restrict__ counts,
+                                                            int B, int T) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float c0 = 0.f, c1 = 0.f;
+    if (idx < B * (T - 1) * 4) {
+        const int k = idx % 4, t = (idx / 4) % (T - 1), b = idx / (4 * (T - 1));
+        const size_t base = (size_t)b * C_TOTAL * T + t;
+        const bool contact = ld(x0, mean, stdv, base, T, CH_CONTACT + k) > 0.5f;
+        const float* f0 = feet + ((size_t)b * T + t) * 24;
+        const float* f1 = f0 + 24;
+#pragma unroll
+        for (int path = 0; path < 2; ++path) {
+            const float vx = (f1[path * 12 + k * 3] - f0[path * 12 + k * 3]) * 30.f;
+            const float vy = (f1[path * 12 + k * 3 + 1] - f0[path * 12 + k * 3 + 1]) * 30.f;
+            const float vz = (f1[path * 12 + k * 3 + 2] - f0[path * 12 + k * 3 + 2]) * 30.f;
+            const float n = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float m = (contact && (n - 0.1f > 0.f)) ? 1.f : 0.f;
+            if (path == 0) c0 = m; else c1 = m;
+        }
+    }
+    // counts are small integers: fp32 atomic accumulation is exact and order-independent
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (c0 != 0.f) atomicAdd(&counts[0], c0);
+        if (c1 != 0.f) atomicAdd(&counts[1], c1);
+    }
+}
+
+// d(-loss)/dJ_foot for frame t of one recovery: the frame appears in the pairs (t-1, t) and (t, t+1).
+__device__ __forceinline__ void skating_djoint(const float* __restrict__ x0, const float* __restrict__ mean,
+                                               const float* __restrict__ stdv, const float* __restrict__ feet,
+                                               int b, int t, int T, int path, int k, float inv_cnt, float* g) {
+    g[0] = g[1] = g[2] = 0.f;
+    if (inv_cnt == 0.f) return;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int t0 = t - 1 + s;                 // pair (t0, t0 + 1)
+        if (t0 < 0 || t0 + 1 >= T) continue;
+        const size_t base = (size_t)b * C_TOTAL * T + t0;
+        if (!(ld(x0, mean, stdv, base, T, CH_CONTACT + k) > 0.5f)) continue;
+        const float* f0 = feet + ((size_t)b * T + t0) * 24 + path * 12 + k * 3;
+        const float* f1 = f0 + 24;
+        const float v[3] = {(f1[0] - f0[0]) * 30.f, (f1[1] - f0[1]) * 30.f, (f1[2] - f0[2]) * 30.f};
+        const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (!(n - 0.1f > 0.f)) continue;
+        // loss = sum(mask n) / cnt;  dn/dJ[t0+1] = +30 v/n, dn/dJ[t0] = -30 v/n;  we return d(-loss)
+        const float sgn = (s == 0) ? -1.f : 1.f;   // this frame is J[t0+1] when s == 0
+        const float sc = sgn * 30.f * inv_cnt / n;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] += sc * v[c];
+    }
+}
+
+// Writes one gradient column (all 294 channels of frame (b, t)) from the SMPL-X reverse pass results.
+__device__ __forceinline__ void write_column(float* __restrict__ grad, const float* __restrict__ stdv, size_t base, int T,
+                                             const float* dlocal /*[NJ*3] or null*/, const float (*d6)[6],
+                                             const float* dbeta) {
+    for (int c = 0; c < C_TOTAL; ++c) {
+        float v = 0.f;
+        if (c >= CH_LOCAL && c < CH_LOCAL + NJ * 3) v = dlocal ? dlocal[c - CH_LOCAL] : 0.f;
+        else if (c >= CH_POSE6D && c < CH_POSE6D + 126) v = d6[1 + (c - CH_POSE6D) / 6][(c - CH_POSE6D) % 6];
+        else if (c >= CH_BETAS && c < CH_BETAS + NBETA) v = dbeta[c - CH_BETAS];
+        // channels [0, 22) and [290, 294) are zeroed by the reference (posenet.py:251-252); local_vel never
+        // enters either recovery.
+        grad[base + (size_t)c * T] = v * stdv[c];
+    }
+}
+
+// pass 3: gradient column of every frame
+__global__ __launch_bounds__(64) void skating_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, const float* __restrict__ Jt,
+                                                         const float* __restrict__ Js, const int* __restrict__ parents,
+                                                         const float* __restrict__ feet, const float* __restrict__ counts,
+                                                         float* __restrict__ grad, int B, int T) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * T) return;
+    const int b = idx / T, t = idx % T;
+    const size_t base = (size_t)b * C_TOTAL * T + t;
+    const float inv0 = counts[0] > 0.f ? 1.f / counts[0] : 0.f;
+    const float inv1 = counts[1] > 0.f ? 1.f / counts[1] : 0.f;
+    // abs-trajectory recovery: only local_positions of the foot joints receive gradient
+    float dlocal[NJ * 3];
+    for (int i = 0; i < NJ * 3; ++i) dlocal[i] = 0.f;
+    const float ang = ld(x0, mean, stdv, base, T, CH_ROOT_ANG);
+    for (int k = 0; k < 4; ++k) {
+        float g[3], gl[3];
+        skating_djoint(x0, mean, stdv, feet, b, t, T, 0, k, inv0, g);
+        abs_joint_T(ang, g, gl);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dlocal[kFoot[k] * 3 + c] = gl[c];
+    }
+    // SMPL-X recovery
+    FrameIn in;
+    load_frame(x0, mean, stdv, base, T, in);
+    FkCtx f;
+    smplx_fk(in, Jt, Js, parents, f);
+    float gP[NJ][3];
+    for (int j = 0; j < NJ; ++j) gP[j][0] = gP[j][1] = gP[j][2] = 0.f;
+    for (int k = 0; k < 4; ++k) skating_djoint(x0, mean, stdv, feet, b, t, T, 1, k, inv1, gP[kFoot[k]]);
+    float dR[NJ][9], dJr[NJ][3], d6[NJ][6], dbeta[NBETA];
+    fk_backward(f, parents, gP, dR, dJr);
+    for (int j = 1; j < NJ; ++j) rot6d_bwd(in.x6[j], dR[j], d6[j]);
+    for (int k = 0; k < NBETA; ++k) {
+        float s = 0.f;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s = fmaf(dJr[j][c], Js[(j * 3 + c) * NBETA + k], s);
+        dbeta[k] = s;
+    }
+    write_column(grad, stdv, base, T, dlocal, d6, dbeta);
+}
+
+// ---------------------------------------------------------------------------------------- 2-D re-projection
+__device__ __forceinline__ void inv3(const float* a, float* o) {
+    const float c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const float det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const float id = 1.f / det;
+    o[0] = c00 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    o[3] = c01 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    o[6] = c02 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+// cam2[b] = {Rc (3x3 of inv(transf_matrix)), Tc (3), Ri = inv(cam_R) (9)}: 21 floats per clip.
+// transf_matrix is affine ([R t; 0 1]), so inv = [R^-1, -R^-1 t] (torch.linalg.inv, posenet.py:286).
+__global__ void proj_prep_kernel(const float* __restrict__ transf, const float* __restrict__ camR, float* __restrict__ cam2,
+                                 int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* m = transf + (size_t)b * 16;
+    const float R[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+    const float tr[3] = {m[3], m[7], m[11]};
+    float* o = cam2 + (size_t)b * 21;
+    inv3(R, o);
+    float tt[3];
+    mat_vec(o, tr, tt);
+    o[9] = -tt[0]; o[10] = -tt[1]; o[11] = -tt[2];
+    inv3(camR, o + 12);
+}
+
+__global__ __launch_bounds__(64) void proj2d_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
+                                                    const float* __restrict__ stdv, const float* __restrict__ Jt,
+                                                    const float* __restrict__ Js, const int* __restrict__ parents,
+                                                    const float* __restrict__ cam2, const float* __restrict__ camT,
+                                                    const float* __restrict__ focal, const float* __restrict__ center,
+                                                    const float* __restrict__ kp2d, int kp_frames,
+                                                    float* __restrict__ grad, int B, int T) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * T) return;
+    const int b = idx / T, t = idx % T;
+    const size_t base = (size_t)b * C_TOTAL * T + t;
+    FrameIn in;
+    load_frame(x0, mean, stdv, base, T, in);
+    FkCtx f;
+    smplx_fk(in, Jt, Js, parents, f);
+    const float* Rc = cam2 + (size_t)b * 21;
+    const float* Tc = Rc + 9;
+    const float* Ri = Rc + 12;
+    const float fx = focal[b * 2], fy = focal[b * 2 + 1], cx = center[b * 2], cy = center[b * 2 + 1];
+    const float inv_n = 1.f / ((float)B * (float)T * 20.f);      // .mean() over B*T*10*2 (posenet.py:308-309)
+    float gP[NJ][3];
+    for (int j = 0; j < NJ; ++j) gP[j][0] = gP[j][1] = gP[j][2] = 0.f;
+    for (int k = 0; k < 10; ++k) {
+        const int j = kProj[k];
+        const float p[3] = {f.P[j][0] + in.trans[0], f.P[j][1] + in.trans[1], f.P[j][2] + in.trans[2]};
+        float sc[3], cm[3];
+        mat_vec(Rc, p, sc);
+        const float d[3] = {sc[0] + Tc[0] - camT[0], sc[1] + Tc[1] - camT[1], sc[2] + Tc[2] - camT[2]};
+        mat_vec(Ri, d, cm);
+        const float iz = 1.f / cm[2];
+        const float u = fx * (cm[0] * iz) + cx, v = fy * (cm[1] * iz) + cy;
+        const float* kp = kp2d + (((size_t)b * kp_frames + t) * NJ + j) * 3;
+        const float conf = kp[2];
+        const float du = u - kp[0], dv = v - kp[1];
+        // d(-mean |.| conf): -sign(diff) conf / N
+        const float gu = -((du > 0.f) - (du < 0.f)) * conf * inv_n;
+        const float gv = -((dv > 0.f) - (dv < 0.f)) * conf * inv_n;
+        const float gc[3] = {gu * fx * iz, gv * fy * iz, -(gu * fx * cm[0] + gv * fy * cm[1]) * iz * iz};
+        float gs[3];
+        matT_vec(Ri, gc, gs);
+        matT_vec(Rc, gs, gP[j]);
+    }
+    float dR[NJ][9], dJr[NJ][3], d6[NJ][6], dbeta[NBETA];
+    fk_backward(f, parents, gP, dR, dJr);
+    for (int j = 1; j < NJ; ++j) rot6d_bwd(in.x6[j], dR[j], d6[j]);
+    for (int k = 0; k < NBETA; ++k) {
+        float s = 0.f;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s = fmaf(dJr[j][c], Js[(j * 3 + c) * NBETA + k], s);
+        dbeta[k] = s;
+    }
+    write_column(grad, stdv, base, T, nullptr, d6, dbeta);
+}
+
+// ---------------------------------------------------------------------------------------- body-model forward
+// joints[n, 0:n_out] of smplx.SMPLX.forward from axis-angle poses (motion_representation.py:379-396):
+// pose [N, n_pose, 3] (global orient first, joints >= n_pose have zero rotation), betas [N,10], transl [N,3].
+__global__ __launch_bounds__(64) void smplx_joints_kernel(const float* __restrict__ pose, int n_pose,
+                                                          const float* __restrict__ betas,
+                                                          const float* __restrict__ transl,
+                                                          const float* __restrict__ Jt, const float* __restrict__ Js,
+                                                          const int* __restrict__ parents, float* __restrict__ out,
+                                                          int n_out, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    FkCtx f;
+    for (int j = 0; j < NJ; ++j) {
+        float r[3] = {0.f, 0.f, 0.f};
+        if (j < n_pose) { r[0] = pose[((size_t)n * n_pose + j) * 3]; r[1] = pose[((size_t)n * n_pose + j) * 3 + 1]; r[2] = pose[((size_t)n * n_pose + j) * 3 + 2]; }
+        rodrigues(r, f.R[j]);
+    }
+    float beta[NBETA];
+    for (int k = 0; k < NBETA; ++k) beta[k] = betas[(size_t)n * NBETA + k];
+    rest_joints(Jt, Js, beta, f.Jr);
+    fk_forward(f, parents);
+    for (int j = 0; j < n_out; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((size_t)n * n_out + j) * 3 + c] = f.P[j][c] + transl[(size_t)n * 3 + c];
+}
+
+// fold of the joint regressor: one block per (joint, coord[, beta]) row, fp64 accumulation
+__global__ __launch_bounds__(256) void fold_regressor_kernel(const float* __restrict__ Jreg, const float* __restrict__ src,
+                                                             int src_stride, int src_off, int V, float* __restrict__ out,
+                                                             int rows_per_joint) {
+    // out[j * rows_per_joint + r] = sum_v Jreg[j, v] * src[(v*3 + c) * src_stride + src_off + k], r = c*K + k
+    const int row = blockIdx.x;
+    const int j = row / rows_per_joint, r = row % rows_per_joint;
+    const int K = rows_per_joint / 3, c = r / K, k = r % K;
+    double s = 0.0;
+    for (int v = threadIdx.x; v < V; v += blockDim.x)
+        s += (double)Jreg[(size_t)j * V + v] * (double)src[((size_t)v * 3 + c) * src_stride + src_off + k];
+    __shared__ double sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[row] = (float)sh[0];
+}
+
+}  // namespace rohm
+
+using namespace rohm;
+
+extern "C" {
+
+int rohm_smplx_create(rohm_smplx_t** out, const float* v_template, const float* shapedirs, int n_shape_total,
+                      const float* J_regressor, const int32_t* parents, int V, int J, int device) {
+    ROHM_ARG_CHECK(out && v_template && shapedirs && J_regressor && parents, "smplx_create: null argument");
+    ROHM_ARG_CHECK(J >= NJ && J <= 64 && V > 0 && n_shape_total >= NBETA, "smplx_create: bad sizes (J=%d V=%d)", J, V);
+    ROHM_HIP_CHECK(hipSetDevice(device));
+    rohm_smplx* h = new rohm_smplx();
+    h->V = V; h->J = J; h->device = device;
+    float *d_vt = nullptr, *d_sd = nullptr, *d_jr = nullptr;
+    auto fail = [&](const char* what, hipError_t e) {
+        set_error("smplx_create: %s: %s", what, hipGetErrorString(e));
+        if (d_vt) (void)hipFree(d_vt);
+        if (d_sd) (void)hipFree(d_sd);
+        if (d_jr) (void)hipFree(d_jr);
+        if (h->d_Jt) (void)hipFree(h->d_Jt);
+        if (h->d_Js) (void)hipFree(h->d_Js);
+        if (h->d_parents) (void)hipFree(h->d_parents);
+        delete h;
+        return ROHM_ERR_HIP;
+    };
+    hipError_t e;
+#define TRY(x) if ((e = (x)) != hipSuccess) return fail(#x, e)
+    TRY(hipMalloc(&d_vt, (size_t)V * 3 * sizeof(float)));
+    TRY(hipMalloc(&d_sd, (size_t)V * 3 * n_shape_total * sizeof(float)));
+    TRY(hipMalloc(&d_jr, (size_t)J * V * sizeof(float)));
+    TRY(hipMalloc(&h->d_Jt, (size_t)J * 3 * sizeof(float)));
+    TRY(hipMalloc(&h->d_Js, (size_t)J * 3 * NBETA * sizeof(float)));
+    TRY(hipMalloc(&h->d_parents, (size_t)J * sizeof(int)));
+    TRY(hipMemcpy(d_vt, v_template, (size_t)V * 3 * sizeof(float), hipMemcpyDefault));
+    TRY(hipMemcpy(d_sd, shapedirs, (size_t)V * 3 * n_shape_total * sizeof(float), hipMemcpyDefault));
+    TRY(hipMemcpy(d_jr, J_regressor, (size_t)J * V * sizeof(float), hipMemcpyDefault));
+    TRY(hipMemcpy(h->d_parents, parents, (size_t)J * sizeof(int), hipMemcpyDefault));
+    TRY(hipMemcpy(h->parents, parents, (size_t)J * sizeof(int), hipMemcpyDefault));
+    for (int j = 1; j < NJ; ++j)
+        if (h->parents[j] < 0 || h->parents[j] >= j) {
+            set_error("smplx_create: parents[%d] = %d is not an earlier joint", j, h->parents[j]);
+            return fail("kinematic tree", hipSuccess);
+        }
+    hipLaunchKernelGGL(fold_regressor_kernel, dim3(J * 3), dim3(256), 0, 0, d_jr, d_vt, 1, 0, V, h->d_Jt, 3);
+    hipLaunchKernelGGL(fold_regressor_kernel, dim3(J * 3 * NBETA), dim3(256), 0, 0, d_jr, d_sd, n_shape_total, 0, V,
+                       h->d_Js, 3 * NBETA);
+    TRY(hipDeviceSynchronize());
+#undef TRY
+    (void)hipFree(d_vt); (void)hipFree(d_sd); (void)hipFree(d_jr);
+    *out = h;
+    return ROHM_OK;
+}
+
+void rohm_smplx_destroy(rohm_smplx_t* h) {
+    if (!h) return;
+    (void)hipFree(h->d_Jt); (void)hipFree(h->d_Js); (void)hipFree(h->d_parents);
+    delete h;
+}
+
+int rohm_smplx_joints(const rohm_smplx_t* h, const float* pose, int n_pose, const float* betas, const float* transl,
+                      int N, float* joints, int n_out, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && pose && betas && transl && joints, "smplx_joints: null argument");
+    ROHM_ARG_CHECK(n_pose >= 1 && n_out >= 1 && n_out <= NJ, "smplx_joints: n_out must be in [1, %d]", NJ);
+    if (N <= 0) return ROHM_OK;
+    prof::Scope ps("smplx_joints", 0.0, 4.0 * N * (n_pose * 3 + 13 + n_out * 3), (hipStream_t)stream);
+    hipLaunchKernelGGL(smplx_joints_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, n_pose, betas,
+                       transl, h->d_Jt, h->d_Js, h->d_parents, joints, n_out, N);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+size_t rohm_guidance_workspace_bytes(int B, int T) {
+    if (B <= 0 || T <= 0) return 0;
+    return ((size_t)B * T * 24 + (size_t)B * 21 + 64) * sizeof(float);
+}
+
+int rohm_guidance_skating_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                               int B, int T, float* grad_out, float* counts2, void* ws, size_t ws_bytes,
+                               rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && x0 && mean294 && std294 && grad_out && counts2 && ws, "guidance_skating: null argument");
+    ROHM_ARG_CHECK(B > 0 && T > 1, "guidance_skating: need B > 0 and T > 1");
+    ROHM_ARG_CHECK(ws_bytes >= rohm_guidance_workspace_bytes(B, T), "guidance_skating: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* feet = (float*)ws;
+    prof::Scope ps("guidance_skating", 0.0, 8.0 * B * T * C_TOTAL, s);
+    ROHM_HIP_CHECK(hipMemsetAsync(counts2, 0, 2 * sizeof(float), s));
+    const int nf = B * T;
+    hipLaunchKernelGGL(skating_fwd_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
+                       h->d_parents, feet, B, T);
+    const int np = B * (T - 1) * 4;
+    hipLaunchKernelGGL(skating_count_kernel, dim3((np + 255) / 256), dim3(256), 0, s, x0, mean294, std294, feet,
+                       counts2, B, T);
+    hipLaunchKernelGGL(skating_bwd_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
+                       h->d_parents, feet, counts2, grad_out, B, T);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                              const float* transf_matrix, const float* cam_R, const float* cam_t, const float* focal,
+                              const float* center, const float* kp2d, int kp_frames, int B, int T, float* grad_out,
+                              void* ws, size_t ws_bytes, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && x0 && mean294 && std294 && transf_matrix && cam_R && cam_t && focal && center && kp2d &&
+                       grad_out && ws, "guidance_proj2d: null argument");
+    ROHM_ARG_CHECK(B > 0 && T > 0 && kp_frames >= T, "guidance_proj2d: keypoints must cover T frames");
+    ROHM_ARG_CHECK(ws_bytes >= rohm_guidance_workspace_bytes(B, T), "guidance_proj2d: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* cam2 = (float*)ws + (size_t)B * T * 24;
+    prof::Scope ps("guidance_proj2d", 0.0, 8.0 * B * T * C_TOTAL, s);
+    hipLaunchKernelGGL(proj_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, transf_matrix, cam_R, cam2, B);
+    const int nf = B * T;
+    hipLaunchKernelGGL(proj2d_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
+                       h->d_parents, cam2, cam_t, focal, center, kp2d, kp_frames, grad_out, B, T);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+}  // extern "C"

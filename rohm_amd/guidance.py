@@ -1,0 +1,77 @@
+"""Test-time guidance gradients (model/posenet.py:196-317) through the analytic HIP kernels.
+
+`guide_skating` / `guide_2d_projection` are what `PoseNet.guide_*_with_smpl` dispatch to.  They return the
+gradient tensor [B, 294, 1, T] (d(-loss)/dx0, channels [0,22) and [290,294) zero).  Where the reference
+returns a 0-d zero (no active skating constraint anywhere in the batch) the kernels return an all-zero
+tensor: numerically identical in `mean + w * variance * grad`, and it avoids the reference's three host
+syncs per step.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .body_model import native_for
+
+
+def _stats(model, device):
+    cache = model.__dict__.setdefault('_rohm_stats', {})
+    key = str(device)
+    if key not in cache:
+        mean = torch.from_numpy(np.asarray(model.dataset.Mean, dtype=np.float32)).to(device).contiguous()
+        std = torch.from_numpy(np.asarray(model.dataset.Std, dtype=np.float32)).to(device).contiguous()
+        if mean.numel() != 294 or std.numel() != 294:
+            raise ValueError('dataset.Mean / dataset.Std must have 294 entries')
+        cache[key] = (mean, std)
+    return cache[key]
+
+
+def _x0(batch, out, compute_grad):
+    if compute_grad == 'x_0':
+        x = out['pred_xstart']
+    elif compute_grad == 'x_t':
+        x = batch['x_t']
+    else:
+        raise ValueError(f'unknown compute_grad {compute_grad!r}')
+    _lib.require_hip(x)
+    if x.dim() != 4 or x.shape[1] != 294 or x.shape[2] != 1:
+        raise ValueError(f'expected [B, 294, 1, T], got {tuple(x.shape)}')
+    return x.detach().float().contiguous()
+
+
+def guide_skating(model, batch, out, denoise_t, compute_grad='x_t', return_counts=False):
+    if model.smplx_model is None:
+        raise RuntimeError('PoseNet.smplx_model is not set: guidance needs a body model')
+    x = _x0(batch, out, compute_grad)
+    B, _, _, T = x.shape
+    nat = native_for(model.smplx_model, x.device)
+    mean, std = _stats(model, x.device)
+    grad = torch.empty_like(x)
+    counts = torch.empty(2, device=x.device, dtype=torch.float32)
+    ws = nat.workspace(B, T)
+    check(lib().rohm_guidance_skating_grad(nat.handle, ptr(x), ptr(mean), ptr(std), B, T, ptr(grad), ptr(counts),
+                                           ptr(ws), ws.numel(), stream_ptr(x.device)), 'rohm_guidance_skating_grad')
+    return (grad, counts) if return_counts else grad
+
+
+def guide_2d_projection(model, batch, out, denoise_t, compute_grad='x_t'):
+    if model.smplx_model is None:
+        raise RuntimeError('PoseNet.smplx_model is not set: guidance needs a body model')
+    x = _x0(batch, out, compute_grad)
+    B, _, _, T = x.shape
+    dev = x.device
+    nat = native_for(model.smplx_model, dev)
+    mean, std = _stats(model, dev)
+    f32 = lambda t: torch.as_tensor(t).to(device=dev, dtype=torch.float32).contiguous()
+    tm, focal, center, kp = (f32(batch[k]) for k in ('transf_matrix', 'focal_length', 'camera_center', 'keypoints_2d'))
+    cam_R, cam_t = f32(model.dataset.cam_R), f32(model.dataset.cam_t).reshape(-1)
+    if kp.shape[1] < T or kp.shape[2] != 22 or kp.shape[3] != 3:
+        raise ValueError(f'keypoints_2d must be [B, >=T, 22, 3], got {tuple(kp.shape)}')
+    grad = torch.empty_like(x)
+    ws = nat.workspace(B, T)
+    check(lib().rohm_guidance_proj2d_grad(nat.handle, ptr(x), ptr(mean), ptr(std), ptr(tm), ptr(cam_R), ptr(cam_t),
+                                          ptr(focal), ptr(center), ptr(kp), kp.shape[1], B, T, ptr(grad), ptr(ws),
+                                          ws.numel(), stream_ptr(dev)), 'rohm_guidance_proj2d_grad')
+    return grad

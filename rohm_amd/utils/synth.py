@@ -210,3 +210,56 @@ def synthetic_stats(seed=0, dim=294):
     mean = (rng.standard_normal(dim) * 0.05).astype(np.float32)
     std = rng.uniform(0.5, 1.5, size=dim).astype(np.float32)
     return mean, std
+
+
+def _rodrigues_np(aa):
+    """Axis-angle [N,3] -> rotation matrices [N,3,3] (float64 numpy)."""
+    aa = np.asarray(aa, dtype=np.float64)
+    ang = np.linalg.norm(aa, axis=1, keepdims=True)
+    ax = aa / np.maximum(ang, 1e-12)
+    K = np.zeros((aa.shape[0], 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0] = -ax[:, 2], ax[:, 1], ax[:, 2]
+    K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -ax[:, 0], -ax[:, 1], ax[:, 0]
+    s, c = np.sin(ang)[:, :, None], np.cos(ang)[:, :, None]
+    return np.eye(3)[None] + s * K + (1 - c) * (K @ K)
+
+
+def plausible_motion(seed, B, T, mean, std, angle_scale=0.4, trans_z=3.0):
+    """Normalised x0 [B, 294, 1, T] whose de-normalised content is a plausible body: joint rotations of
+    ~`angle_scale` rad written as interleaved 6-D vectors (first two columns of R, as get_repr_smplx stores
+    them, motion_representation.py:248,261), the body ~`trans_z` m along +z (in front of a camera), contact
+    labels well away from the 0.5 threshold, everything else small Gaussian."""
+    g = _rng(seed)
+    full = (g.standard_normal((B, T, 294)) * 0.3).astype(np.float32)
+
+    def six_d(aa):
+        R = _rodrigues_np(aa.reshape(-1, 3))
+        return R[:, :, :2].reshape(-1, 6).astype(np.float32)
+    full[..., 7:13] = six_d(g.standard_normal((B, T, 3)) * angle_scale).reshape(B, T, 6)
+    full[..., 154:280] = six_d(g.standard_normal((B, T, 21, 3)) * angle_scale).reshape(B, T, 126)
+    full[..., 16:19] = np.stack([g.standard_normal((B, T)) * 0.3, g.standard_normal((B, T)) * 0.3,
+                                 trans_z + 0.2 * g.standard_normal((B, T))], -1)
+    full[..., 290:294] = (g.uniform(size=(B, T, 4)) > 0.5).astype(np.float32) * 0.9 + 0.05
+    x = (full - mean) / std
+    return torch.from_numpy(x.astype(np.float32)).permute(0, 2, 1).unsqueeze(2).contiguous()
+
+
+def synthetic_camera_batch(seed, B, frames=145):
+    """PROX-like guidance inputs (SURVEY.md §8d cfg 4): Kinect-colour intrinsics
+    (utils/get_occlusion_mask.py:64-68), rigid cano->scene transforms, OpenPose-style keypoints."""
+    g = _rng(seed + 31)
+    tm = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    tm[:, :3, :3] = _rodrigues_np(g.standard_normal((B, 3)) * 0.2).astype(np.float32)
+    tm[:, :3, 3] = (g.standard_normal((B, 3)) * 0.2).astype(np.float32)
+    kp = np.concatenate([g.uniform(size=(B, frames, 22, 2)) * np.array([1920., 1080.]),
+                         g.uniform(size=(B, frames, 22, 1))], -1).astype(np.float32)
+    return {
+        'transf_matrix': torch.from_numpy(tm),
+        'focal_length': torch.tensor([[1060.53, 1060.38]], dtype=torch.float32).repeat(B, 1),
+        'camera_center': torch.tensor([[951.30, 536.77]], dtype=torch.float32).repeat(B, 1),
+        'keypoints_2d': torch.from_numpy(kp),
+    }
+
+
+SYNTH_CAM_R = [[0.99, 0.1, 0.05], [-0.1, 0.98, 0.02], [-0.04, -0.03, 1.0]]
+SYNTH_CAM_T = [[0.1, -0.2, 0.3]]

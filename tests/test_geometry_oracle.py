@@ -1,0 +1,100 @@
+"""CPU: geometry / guidance restatement vs what the reference's own functions produced (golden), plus the
+equivalence the HIP kernels rely on (skipping the R -> quaternion -> axis-angle -> Rodrigues round trip)."""
+import numpy as np
+import torch
+
+from helpers import golden, max_abs, seeded
+from oracle import geometry as G
+from rohm_amd.utils import synth
+
+
+def _setup():
+    g = golden('guidance.npz')
+    body = G.BodyModel(synth.synthetic_smplx_tensors(int(g['body_seed'])))
+    mean, std = synth.synthetic_stats(int(g['stats_seed']))
+    x0 = synth.plausible_motion(int(g['motion_seed']), 2, 143, mean, std)
+    return g, body, torch.from_numpy(mean), torch.from_numpy(std), x0
+
+
+def test_rotation_helpers_match_reference():
+    g = golden('guidance.npz')
+    r6 = seeded(int(g['r6_seed']), 64, 6)
+    R = G.rot6d_to_rotmat(r6)
+    assert max_abs(R, torch.from_numpy(g['rotmat'])) < 1e-6
+    assert max_abs(G.rotation_matrix_to_angle_axis(R), torch.from_numpy(g['angle_axis'])) < 1e-5
+    # Gram-Schmidt output is a rotation; Rodrigues(angle-axis(R)) gives R back
+    assert max_abs(R.transpose(1, 2) @ R, torch.eye(3).expand(64, 3, 3)) < 1e-5
+    assert max_abs(G.batch_rodrigues(G.rotation_matrix_to_angle_axis(R)), R) < 1e-5
+
+
+def test_recover_from_repr_matches_reference():
+    g, body, mean, std, x0 = _setup()
+    d = G.split_repr(x0[:, :, 0].permute(0, 2, 1) * std + mean)
+    assert max_abs(G.joints_from_abs_traj(d), torch.from_numpy(g['j_abs'])) < 1e-5
+    assert max_abs(G.joints_from_smplx(d, body), torch.from_numpy(g['j_smpl'])) < 1e-5
+
+
+def test_guidance_gradients_match_reference():
+    g, body, mean, std, x0 = _setup()
+    gs = G.guide_skating(x0, mean, std, body)
+    ref = torch.from_numpy(g['g_skating'])
+    assert max_abs(gs, ref) < 1e-6 * max(1.0, float(ref.abs().max()))
+    # SURVEY §4 invariants: zero on trajectory / contact channels; abs-traj recovery only touches foot joints
+    assert float(gs[:, :22].abs().max()) == 0.0 and float(gs[:, 290:].abs().max()) == 0.0
+    nz = torch.nonzero(gs.abs().amax(dim=(0, 2, 3))).flatten().tolist()
+    assert set(c for c in nz if c < 154) <= set(range(43, 49)) | set(range(52, 58))
+    cam = synth.synthetic_camera_batch(int(g['cam_seed']), 2)
+    g2 = G.guide_2d_projection(x0, mean, std, body, cam['transf_matrix'], cam['focal_length'], cam['camera_center'],
+                               cam['keypoints_2d'], torch.tensor(synth.SYNTH_CAM_R), torch.tensor(synth.SYNTH_CAM_T))
+    ref2 = torch.from_numpy(g['g_2d'])
+    assert max_abs(g2, ref2) < 1e-5 * float(ref2.abs().max())
+    nz2 = torch.nonzero(g2.abs().amax(dim=(0, 2, 3))).flatten().tolist()
+    assert min(nz2) >= 154 and max(nz2) <= 289
+
+
+def test_direct_fk_equals_axis_angle_round_trip():
+    """What the kernels skip: R -> q -> axis-angle -> Rodrigues is the identity on SO(3), and so is its
+    tangent map, so joints AND gradients agree to fp32 rounding -- including tiny and near-pi angles."""
+    _, body, mean, std, _ = _setup()
+    m, s = mean.numpy(), std.numpy()
+    for scale in (1e-4, 0.4, 3.0):
+        x0 = synth.plausible_motion(11, 2, 40, m, s, angle_scale=scale)
+        d = G.split_repr(x0[:, :, 0].permute(0, 2, 1) * std + mean)
+        a, b = G.joints_from_smplx(d, body), G.joints_from_smplx(d, body, through_axis_angle=False)
+        assert max_abs(a, b) < 5e-6, scale
+        ga = G.guide_skating(x0, mean, std, body)
+        gb = G.guide_skating(x0, mean, std, body, through_axis_angle=False)
+        assert max_abs(ga, gb) < 1e-4 * float(ga.abs().max()), scale   # fp32 noise of the chain itself
+    # fp64 arbitration on the ill-conditioned re-projection gradient: the direct path is as close to the
+    # float64 truth as the reference's own fp32 chain
+    body64 = G.BodyModel(synth.synthetic_smplx_tensors(0), dtype=torch.float64)
+    x0 = synth.plausible_motion(12, 2, 40, m, s)
+    cam = synth.synthetic_camera_batch(1, 2)
+    args = (cam['transf_matrix'], cam['focal_length'], cam['camera_center'], cam['keypoints_2d'],
+            torch.tensor(synth.SYNTH_CAM_R), torch.tensor(synth.SYNTH_CAM_T))
+    t64 = G.guide_2d_projection(x0.double(), mean.double(), std.double(), body64, *[a.double() for a in args])
+    chain = G.guide_2d_projection(x0, mean, std, body, *args)
+    direct = G.guide_2d_projection(x0, mean, std, body, *args, through_axis_angle=False)
+    scale = float(t64.abs().max())
+    assert max_abs(chain, t64) < 1e-3 * scale and max_abs(direct, t64) < 1e-3 * scale
+
+
+def test_smplx_restatement_self_consistency():
+    """smplx==0.1.28 is not available: self-consistency only (parity unpinned, see oracle/__init__.py)."""
+    t = synth.synthetic_smplx_tensors(0)
+    body = G.BodyModel(t)
+    N = 3
+    betas = seeded(1, N, 10)
+    z3 = torch.zeros(N, 3)
+    out = body(betas=betas, global_orient=z3, body_pose=torch.zeros(N, 63), transl=seeded(2, N, 3))
+    v_shaped = t['v_template'][None] + torch.einsum('bl,mkl->bmk', torch.cat([betas, torch.zeros(N, 10)], 1), t['shapedirs'])
+    J = torch.einsum('bik,ji->bjk', v_shaped, t['J_regressor'])
+    # zero pose: joints = regressed rest joints + transl, vertices = shaped template + transl
+    assert max_abs(out.joints[:, :55], J + seeded(2, N, 3)[:, None]) < 1e-5
+    assert max_abs(out.vertices, v_shaped + seeded(2, N, 3)[:, None]) < 1e-5
+    # a global rotation moves every joint rigidly about the pelvis
+    aa = torch.tensor([[0.3, -0.2, 0.5]]).repeat(N, 1)
+    out2 = body(betas=betas, global_orient=aa, body_pose=torch.zeros(N, 63), transl=torch.zeros(N, 3))
+    R = G.batch_rodrigues(aa)
+    exp = (R @ (J - J[:, :1]).transpose(1, 2)).transpose(1, 2) + J[:, :1]
+    assert max_abs(out2.joints[:, :55], exp) < 1e-5
