@@ -151,6 +151,39 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
                              const float* coef, const float* noise, float* x0_last, int n_steps, int B,
                              int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
 
+/* ------------------------------------------------------------------------- TrajNet / TrajControl
+ * model/trajnet.py:10-275 + model/heads.py:12-106: conv U-Net x0-predictor of the 13-channel trajectory,
+ * optional ControlNet branch conditioned on PoseNet's 272-channel local pose. */
+typedef struct rohm_trajnet rohm_trajnet_t;
+typedef struct {
+    const float* data; /* host or device */
+    size_t numel;
+} rohm_tensor_ref;
+/* The parameter tensors in the reference's state_dict order (model/trajnet.py; `controlnet.*` first when
+ * trajcontrol): every `weight` immediately followed by its `bias`; 186 tensors, +84 with TrajControl.
+ * Conv weights are [C_out, C_in, k] (ConvTranspose1d: [C_in, C_out, k]) exactly as stored in a checkpoint. */
+typedef struct {
+    const rohm_tensor_ref* tensors;
+    int n_tensors;
+} rohm_trajnet_weights;
+
+int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* w, int mid_dim, int time_dim,
+                        int c_traj, int c_ctrl, int trajcontrol, int device);
+void rohm_trajnet_destroy(rohm_trajnet_t* h);
+size_t rohm_trajnet_workspace_bytes(const rohm_trajnet_t* h, int B, int T);
+
+/* TrajNet.forward (model/trajnet.py:177-275): x_t, cond [B, T, c_traj], control_cond [B, T, c_ctrl] (NULL
+ * without TrajControl), t int64[B] -> x0_out [B, T, c_traj].  T must be a multiple of 16. */
+int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float* cond, const float* control_cond,
+                         const int64_t* t, float* x0_out, int B, int T, void* ws, size_t ws_bytes,
+                         rohm_stream_t stream);
+
+/* Device-resident DDPM loop (diffusion/gaussian_diffusion_trajnet.py:559-627, 440-466); arguments as
+ * rohm_posenet_sample_loop with tensors of shape [B, T, c_traj]. */
+int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* cond, const float* control_cond,
+                             const int64_t* t_model, const float* coef, const float* noise, float* x0_last,
+                             int n_steps, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
+
 /* ------------------------------------------------------------------------- SMPL-X + guidance
  * Joints-only SMPL-X (third-party smplx==0.1.28 `SMPLX.forward` / `lbs`, called from
  * data_loaders/motion_representation.py:389) and the two test-time guidance gradients of

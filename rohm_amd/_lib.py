@@ -35,6 +35,14 @@ class PoseNetWeights(C.Structure):
                 ('layers', C.POINTER(LayerWeights))]
 
 
+class TensorRef(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('numel', C.c_size_t)]
+
+
+class TrajNetWeights(C.Structure):
+    _fields_ = [('tensors', C.POINTER(TensorRef)), ('n_tensors', C.c_int)]
+
+
 class ProfileRow(C.Structure):
     _fields_ = [('name', C.c_char * 48), ('launches', C.c_uint64), ('total_ms', C.c_double),
                 ('flops', C.c_double), ('bytes', C.c_double)]
@@ -66,6 +74,15 @@ SIGNATURES = {
     'rohm_posenet_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                            C.c_void_p]),
+    'rohm_trajnet_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(TrajNetWeights), C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int]),
+    'rohm_trajnet_destroy': (None, [C.c_void_p]),
+    'rohm_trajnet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'rohm_trajnet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'rohm_trajnet_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]),
     'rohm_smplx_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int]),
     'rohm_smplx_destroy': (None, [C.c_void_p]),

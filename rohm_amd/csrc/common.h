@@ -88,6 +88,15 @@ struct GemmParams {
     // EPI_OUT_T: rows = output channels (M = c_out), cols = tokens n -> (b = n / S, tok = n % S);
     // writes out[b][ch_off + m][tok-1] for tok >= 1 (T = S - 1 frames).
     int ch_off; int C_total; int T;
+    // ---- conv-as-GEMM (trajnet.hip): the A operand is gathered from a channels-last activation
+    // x[B, t_in, lda] with one K segment of cin_pad channels per tap:
+    //   row m = b*conv_tq + tq,   k = j*cin_pad + ci   ->   x[b][tq*conv_stride + conv_off[j]][ci]
+    // (zeros outside [0, conv_tin)); conv_taps == 0 means a plain GEMM.  The output row is
+    // m*(orow_mul_m1 + 1) + orow_add (interleaved phases of a transposed convolution).
+    int conv_taps, conv_cin_pad, conv_tin, conv_tq, conv_stride;
+    int conv_off[5];
+    const float* zero_page;      // >= 128 B of zeros (source of padded taps)
+    int orow_mul_m1, orow_add;
 };
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);

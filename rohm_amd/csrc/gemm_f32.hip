@@ -37,7 +37,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <int BN, int EPI, int VAR = 0, bool FULL = false>
+template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int WN = BN / 4;        // columns per wave
     constexpr int NCB = WN / 16;      // 16-wide column blocks per wave (2 or 1)
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // Rows past M / N are clamped to a valid row: they only feed accumulator rows / columns that the
     // epilogue never stores, so no zero fill is needed and there is no predicated load.
     const float* a_src[A_ITERS];
+    int a_b[A_ITERS], a_tq[A_ITERS], a_slot[A_ITERS];      // conv gather: clip, output frame, 16-B slot
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
         const int u = tid + i * 256;
@@ -73,7 +74,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const int slot = (u & 7) ^ ((row >> 1) & 7);
         const int grow = (m0 + row < p.M) ? m0 + row : p.M - 1;
         a_src[i] = p.A + (size_t)grow * p.lda + slot * 4;
+        if constexpr (CONV) {
+            a_b[i] = grow / p.conv_tq;
+            a_tq[i] = grow % p.conv_tq;
+            a_slot[i] = slot;
+        }
     }
+    // conv gather: source pointer of unit i for the K chunk starting at k0 (a chunk never straddles taps
+    // because cin_pad is a multiple of 32); taps that fall outside the clip read a page of zeros.
+    auto conv_src = [&](int i, int k0) -> const float* {
+        const int j = k0 / p.conv_cin_pad, ci0 = k0 - j * p.conv_cin_pad;
+        const int tin = a_tq[i] * p.conv_stride + p.conv_off[j];
+        const bool ok = (tin >= 0) && (tin < p.conv_tin);
+        return ok ? p.A + ((size_t)a_b[i] * p.conv_tin + tin) * p.lda + ci0 + a_slot[i] * 4
+                  : p.zero_page + a_slot[i] * 4;
+    };
     const float* b_src[B_ITERS];
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             if (i < A_ITERS - 1 || wave_u < A_UNITS - (A_ITERS - 1) * 256)   // last pass: waves 0-1 only
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(CONV ? conv_src(i, k0) : a_src[i] + k0),
                                                  (__attribute__((address_space(3))) void*)(as + (i * 256 + wave_u) * 4),
                                                  16, 0, 0);
         }
@@ -254,7 +269,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : acc[r][c][q]) + tp[q];
                     }
                 }
-                float* cp = p.C + (size_t)m * p.ldc + nb;
+                const size_t crow = CONV ? (size_t)m * (p.orow_mul_m1 + 1) + p.orow_add : (size_t)m;
+                float* cp = p.C + crow * p.ldc + nb;
                 if (vec_ok) {
                     *reinterpret_cast<f32x4*>(cp) = v;
                 } else {
@@ -276,7 +292,7 @@ static int gemm_variant() {
     return v;
 }
 
-template <int BN, int EPI, int VAR = 0, bool FULL = false>
+template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 static int launch_one(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     static int lds_pad = -1;
@@ -291,17 +307,24 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
-        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, EPI, VAR, FULL>),
+        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
     static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv", "gemm_embed",
                                          "gemm_out_t"};
+    if (CONV) {
+        prof::Scope ps(BN == 128 ? "conv_gemm" : "conv_gemm/64", 2.0 * p.M * p.N * p.K,
+                       4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
+        hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);
+        ROHM_LAUNCH_CHECK();
+        return ROHM_OK;
+    }
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64",
                                            "gemm_embed/64", "gemm_out_t/64"};
     prof::Scope ps(BN == 128 ? kNames[EPI] : kNames64[EPI], 2.0 * p.M * p.N * p.K,
                    4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
-    hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL>), dim3(tiles), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
@@ -315,6 +338,14 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
     if (EPI == EPI_EMBED) full = full && (p.ldtab % 4 == 0) && (p.ldtab0 % 4 == 0) && al16(p.tab) && al16(p.tab0);
     if (EPI == EPI_QKV) full = full && (p.qcols % 4 == 0);
     if (EPI == EPI_OUT_T || VAR != 0) full = false;
+    if (p.conv_taps > 0) {
+        if constexpr (EPI == EPI_BIAS && VAR == 0) {
+            return full ? launch_one<BN, EPI, 0, true, true>(p, s) : launch_one<BN, EPI, 0, false, true>(p, s);
+        } else {
+            set_error("gemm: conv gather supports the bias epilogue only");
+            return ROHM_ERR_UNSUPPORTED;
+        }
+    }
     if (full) {
         if constexpr (EPI != EPI_OUT_T && VAR == 0) return launch_one<BN, EPI, 0, true>(p, s);
     }
@@ -345,6 +376,12 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     ROHM_ARG_CHECK(p.lda % 4 == 0 && p.ldw % 4 == 0, "gemm: lda/ldw must be multiples of 4 floats");
     ROHM_ARG_CHECK(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "gemm: A/W must be 16-byte aligned");
     ROHM_ARG_CHECK(p.M > 0 && p.N > 0, "gemm: empty problem");
+    if (p.conv_taps > 0) {
+        ROHM_ARG_CHECK(p.conv_taps <= 5 && p.conv_cin_pad % BK == 0 && p.K == p.conv_taps * p.conv_cin_pad,
+                       "gemm: conv gather needs cin_pad %% 32 == 0 and K == taps * cin_pad");
+        ROHM_ARG_CHECK(p.zero_page && p.conv_tq > 0 && p.conv_tin > 0 && p.M % p.conv_tq == 0,
+                       "gemm: bad conv gather geometry");
+    }
     switch (epi) {
         case EPI_BIAS: return launch_bn<EPI_BIAS>(p, s);
         case EPI_BIAS_GELU: return launch_bn<EPI_BIAS_GELU>(p, s);

@@ -1,0 +1,700 @@
+// TrajNet / TrajControl on MI355X: 1-D conv U-Net denoiser of the 13-channel trajectory
+// (model/trajnet.py:10-275, model/heads.py:12-106) and its 100-step DDPM loop
+// (diffusion/gaussian_diffusion_trajnet.py:440-466, 559-627).
+//
+// Layout: activations are CHANNELS-LAST, row m = b*T_level + t of a [B*T_level, C] matrix -- the layout the
+// drivers already hand over ([B, T, 13] / [B, T, 272]), so there is no 'b h t -> b t h' transpose at all.
+// Every convolution is the fp32-MFMA GEMM of gemm_f32.hip with a tap-gathered A operand (K = taps * C_in;
+// zero padding comes from a page of zeros), channel concatenations are column slices of preallocated wide
+// buffers that the producers write into directly, and GroupNorm + Mish + time bias + residual (+ control
+// residual) are one fused kernel per conv block.  Everything that depends on the timestep only -- the
+// sinusoid -> MLP embedding and the per-block time biases -- is one small launch per step.
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace rohm {
+
+struct ConvW {          // re-laid-out conv weight: [cout, taps * cin_pad] + bias [cout]
+    float* w = nullptr;
+    float* b = nullptr;
+    int cin = 0, cin_pad = 0, cout = 0, taps = 0;
+};
+struct UpW { ConvW even, odd; };          // ConvTranspose1d(k4, s2, p1) as two 2-tap phases
+struct BlockW {                           // Conv1dBlock: conv5 + GroupNorm(8)
+    ConvW conv;
+    float *g = nullptr, *be = nullptr;
+};
+struct ResW {                             // ResidualTemporalBlock
+    BlockW b0, b1;
+    ConvW res;                            // 1x1 when cin != cout (taps == 0 -> absent)
+    bool has_res = false;
+    int tb_off = -1;                      // offset of this block's time bias inside tb_all, -1 = no time input
+    int cin = 0, cout = 0;
+};
+
+}  // namespace rohm
+
+struct rohm_trajnet {
+    int mid, tdim, ctraj, cctrl, control, device;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    float* zero_page = nullptr;
+    // time path
+    float *t_w1T, *t_b1, *t_w3T, *t_b3;   // time_mlp.{1,3} stored [in][out]
+    float *tb_wT, *tb_b;                  // all per-block time Linears stacked: [tdim][tb_total], [tb_total]
+    int tb_total = 0;
+    rohm::ResW cond_enc[4], diff_enc[4], mid_blk[2], dec[4], c_enc[4], c_mid[2];
+    rohm::ConvW cond_down[3], diff_down[4], c_down[4];
+    rohm::UpW up[4];
+    rohm::BlockW final_blk;
+    rohm::ConvW final_conv, c_zero0, c_zero[4], c_zero_mid;
+};
+
+namespace rohm {
+
+__device__ __forceinline__ float mishf(float x) {
+    // x * tanh(softplus(x)), softplus with torch's threshold 20 (model/heads.py:104, nn.Mish)
+    const float sp = (x > 20.f) ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+// pad [rows, cin] -> [rows, cpad] (zeros beyond cin)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       size_t rows, int cin, int cpad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cpad) return;
+    const size_t r = i / cpad;
+    const int c = (int)(i % cpad);
+    dst[i] = (c < cin) ? src[r * cin + c] : 0.f;
+}
+
+// Timestep path of one step: SinusoidalPosEmb(32) -> Linear(32,128) -> Mish -> Linear(128,32)
+// (trajnet.py:120-125, heads.py:57-69), then every block's `Mish -> Linear(32, C_out)` (heads.py:34-38)
+// stacked into one [tb_total] vector.  One block per row (sample, or 1 when the batch shares t).
+__global__ __launch_bounds__(256) void time_path_kernel(const int64_t* __restrict__ t_dev, int64_t t_host, int tdim,
+                                                        const float* __restrict__ w1T, const float* __restrict__ b1,
+                                                        const float* __restrict__ w3T, const float* __restrict__ b3,
+                                                        const float* __restrict__ tbwT, const float* __restrict__ tbb,
+                                                        int tb_total, float* __restrict__ tb_all) {
+    __shared__ float e[64], h[256], te[64];
+    const int tid = threadIdx.x;
+    const float tval = (float)(t_dev ? t_dev[blockIdx.x] : t_host);
+    const int half = tdim / 2;
+    if (tid < tdim) {
+        const int k = tid % half;
+        const float f = expf((float)k * -(logf(10000.f) / (float)(half - 1)));
+        e[tid] = (tid < half) ? sinf(tval * f) : cosf(tval * f);
+    }
+    __syncthreads();
+    const int hid = 4 * tdim;
+    if (tid < hid) {
+        float a = b1[tid];
+        for (int k = 0; k < tdim; ++k) a = fmaf(e[k], w1T[k * hid + tid], a);
+        h[tid] = mishf(a);
+    }
+    __syncthreads();
+    if (tid < tdim) {
+        float a = b3[tid];
+        for (int k = 0; k < hid; ++k) a = fmaf(h[k], w3T[k * tdim + tid], a);
+        te[tid] = mishf(a);            // every consumer applies Mish first (heads.py:35)
+    }
+    __syncthreads();
+    for (int o = tid; o < tb_total; o += blockDim.x) {
+        float a = tbb[o];
+        for (int k = 0; k < tdim; ++k) a = fmaf(te[k], tbwT[(size_t)k * tb_total + o], a);
+        tb_all[(size_t)blockIdx.x * tb_total + o] = a;
+    }
+}
+
+// Fused GroupNorm(8 groups, eps 1e-5, biased variance over (C/8 x T) per sample) -> Mish -> (+ time bias)
+// -> (+ residual) -> (+ second residual), channels-last (heads.py:98-104, 50-54; trajnet.py:240,259-271).
+// One block per (sample, group).
+struct GnArgs {
+    const float* y; int ldy;
+    const float *gamma, *beta;
+    int C, T;
+    const float* tb; int ldtb;          // [rows or 1][...] time bias slice for this block (nullable)
+    const float* res; int ldres;        // residual (nullable)
+    const float* add2; int ldadd2;      // control residual (nullable)
+    float* dst; int lddst;
+    float* dst2; int lddst2;            // optional second destination (skip / concat copy)
+};
+
+__global__ __launch_bounds__(256) void gn_mish_kernel(GnArgs a) {
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int cg = a.C / 8;
+    const int n = cg * a.T;
+    const float* yb = a.y + (size_t)b * a.T * a.ldy + g * cg;
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += yb[(size_t)(i / cg) * a.ldy + (i % cg)];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float mean = red[0] / (float)n;
+    __syncthreads();
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = yb[(size_t)(i / cg) * a.ldy + (i % cg)] - mean;
+        q += d * d;
+    }
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float rstd = 1.0f / sqrtf(red[0] / (float)n + 1e-5f);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / cg, c = g * cg + (i % cg);
+        const size_t row = (size_t)b * a.T + t;
+        float v = (a.y[row * a.ldy + c] - mean) * rstd * a.gamma[c] + a.beta[c];
+        v = mishf(v);
+        if (a.tb) v += a.tb[(size_t)(a.ldtb ? b : 0) * a.ldtb + c];
+        if (a.res) v += a.res[row * a.ldres + c];
+        if (a.add2) v += a.add2[row * a.ldadd2 + c];
+        a.dst[row * a.lddst + c] = v;
+        if (a.dst2) a.dst2[row * a.lddst2 + c] = v;
+    }
+}
+
+// out = a + b over [rows, C] (control residual after the middle blocks, trajnet.py:240)
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+
+// ---- weight re-layout (create time) --------------------------------------------------------------------
+__global__ void relayout_conv_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int k,
+                                     int cin_pad, int tap0, int tap_step, int ntap, int transposed) {
+    // out[co][jj*cin_pad + ci] = w[co][ci][tap0 + jj*tap_step]   (Conv1d, weight [cout, cin, k])
+    //                          = w[ci][co][tap0 + jj*tap_step]   (ConvTranspose1d, weight [cin, cout, k])
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = ntap * cin_pad;
+    if (i >= cout * K) return;
+    const int co = i / K, r = i % K, jj = r / cin_pad, ci = r % cin_pad;
+    float v = 0.f;
+    if (ci < cin) {
+        const int j = tap0 + jj * tap_step;
+        v = transposed ? w[((size_t)ci * cout + co) * k + j] : w[((size_t)co * cin + ci) * k + j];
+    }
+    out[i] = v;
+}
+
+__global__ void transpose2_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc, int ldd,
+                                  int col0) {
+    // dst[c][col0 + r] = src[r][c]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R * Cc) {
+        const int r = i / Cc, c = i % Cc;
+        dst[(size_t)c * ldd + col0 + r] = src[i];
+    }
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------------
+static inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
+
+static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int tin, int tq,
+                     int stride, const int* offs, float* out, int ldo, int orow_mul, int orow_add, hipStream_t s) {
+    GemmParams g{};
+    g.A = x; g.lda = ldx; g.W = w.w; g.ldw = w.taps * w.cin_pad; g.C = out; g.ldc = ldo;
+    g.M = B * tq; g.N = w.cout; g.K = w.taps * w.cin_pad; g.bias = w.b;
+    g.conv_taps = w.taps; g.conv_cin_pad = w.cin_pad; g.conv_tin = tin; g.conv_tq = tq; g.conv_stride = stride;
+    for (int j = 0; j < w.taps; ++j) g.conv_off[j] = offs[j];
+    g.zero_page = h->zero_page; g.orow_mul_m1 = orow_mul - 1; g.orow_add = orow_add;
+    return launch_gemm(g, EPI_BIAS, s);
+}
+static int conv5(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
+                 hipStream_t s) {
+    static const int offs[5] = {-2, -1, 0, 1, 2};
+    return conv_gemm(h, w, x, ldx, B, T, T, 1, offs, out, ldo, 1, 0, s);
+}
+static int conv1(const ConvW& w, const float* x, int ldx, int M, float* out, int ldo, hipStream_t s) {
+    GemmParams g{};
+    g.A = x; g.lda = ldx; g.W = w.w; g.ldw = w.cin_pad; g.C = out; g.ldc = ldo; g.M = M; g.N = w.cout;
+    g.K = w.cin_pad; g.bias = w.b;
+    return launch_gemm(g, EPI_BIAS, s);
+}
+static int down(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
+                hipStream_t s) {   // Conv1d(k3, s2, p1): heads.py:72-78
+    static const int offs[3] = {-1, 0, 1};
+    return conv_gemm(h, w, x, ldx, B, T, T / 2, 2, offs, out, ldo, 1, 0, s);
+}
+static int upsample(const rohm_trajnet* h, const UpW& w, const float* x, int ldx, int B, int Tq, float* out, int ldo,
+                    hipStream_t s) {   // ConvTranspose1d(k4, s2, p1): heads.py:81-87
+    static const int off_even[2] = {0, -1}, off_odd[2] = {1, 0};
+    int rc = conv_gemm(h, w.even, x, ldx, B, Tq, Tq, 1, off_even, out, ldo, 2, 0, s);
+    if (rc) return rc;
+    return conv_gemm(h, w.odd, x, ldx, B, Tq, Tq, 1, off_odd, out, ldo, 2, 1, s);
+}
+static int gn(const BlockW& bw, const float* y, int ldy, int B, int T, const float* tb, int ldtb, const float* res,
+              int ldres, const float* add2, int ldadd2, float* dst, int lddst, float* dst2, int lddst2,
+              hipStream_t s) {
+    GnArgs a{y, ldy, bw.g, bw.be, bw.conv.cout, T, tb, ldtb, res, ldres, add2, ldadd2, dst, lddst, dst2, lddst2};
+    prof::Scope ps("gn_mish", 0.0, 12.0 * B * T * bw.conv.cout, s);
+    hipLaunchKernelGGL(gn_mish_kernel, dim3(B, 8), dim3(256), 0, s, a);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+struct Scratch { float *ya, *hb, *rc; };   // conv output, block-0 activation, 1x1 residual
+
+// ResidualTemporalBlock (heads.py:43-54)
+static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int ldx, int B, int T, const float* tb_all,
+                     int ldtb, const float* add2, int ldadd2, float* dst, int lddst, float* dst2, int lddst2,
+                     const Scratch& sc, hipStream_t s) {
+    int rc;
+    const int co = r.cout;
+    if ((rc = conv5(h, r.b0.conv, x, ldx, B, T, sc.ya, co, s))) return rc;
+    const float* tb = (r.tb_off >= 0) ? tb_all + r.tb_off : nullptr;
+    if ((rc = gn(r.b0, sc.ya, co, B, T, tb, ldtb, nullptr, 0, nullptr, 0, sc.hb, co, nullptr, 0, s))) return rc;
+    if ((rc = conv5(h, r.b1.conv, sc.hb, co, B, T, sc.ya, co, s))) return rc;
+    const float* res = x;
+    int ldres = ldx;
+    if (r.has_res) {
+        if ((rc = conv1(r.res, x, ldx, B * T, sc.rc, co, s))) return rc;
+        res = sc.rc; ldres = co;
+    }
+    return gn(r.b1, sc.ya, co, B, T, nullptr, 0, res, ldres, add2, ldadd2, dst, lddst, dst2, lddst2, s);
+}
+
+// ---- workspace ---------------------------------------------------------------------------------------------
+struct TWs {
+    float *xin, *cin, *ctl;                 // padded inputs [M,32], [M,32], [M,288]
+    float *cat[4], *dcat[4], *ccat[4];      // concat buffers (see forward)
+    float *cdn[3], *ddn[4], *kdn[4];        // outputs of the down convs (cond / diff / control)
+    float *mid_a, *mid_b, *kmid_a, *kmid_b;
+    float *d[4];                            // decoder block outputs
+    float *cz, *ctrl[4], *ctrl_mid;         // control residuals
+    float *fin;                             // final conv block output [M, 32]
+    float *tb_all;                          // [B or 1][tb_total]
+    Scratch sc;
+    float *x0, *cond_keep;                  // loop: network output [B,T,13]
+    size_t floats;
+};
+
+static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
+    const int m = h->mid;
+    const int ch[4] = {m / 8, m / 4, m / 2, m};
+    TWs w;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += al(n); return p; };
+    const size_t M = (size_t)B * T;
+    w.xin = take(M * 32); w.cin = take(M * 32); w.ctl = take(M * 288);
+    for (int i = 0; i < 4; ++i) {
+        const size_t Mi = M >> i;
+        w.cat[i] = take(Mi * 2 * ch[i]);
+        w.dcat[i] = take(Mi * 2 * ch[i]);
+        w.ccat[i] = take(Mi * 2 * ch[i]);
+        if (i < 3) w.cdn[i] = take((Mi / 2) * ch[i]);
+        w.ddn[i] = take((Mi / 2) * 2 * ch[i]);
+        w.kdn[i] = take((Mi / 2) * 2 * ch[i]);
+        w.d[i] = take(Mi * (i == 0 ? 32 : ch[i - 1]));
+        w.ctrl[i] = take(Mi * (i == 0 ? 32 : ch[i - 1]));
+    }
+    const size_t M16 = M >> 4;
+    w.mid_a = take(M16 * m); w.mid_b = take(M16 * m); w.kmid_a = take(M16 * m); w.kmid_b = take(M16 * m);
+    w.ctrl_mid = take(M16 * m);
+    w.cz = take(M * 32);
+    w.fin = take(M * 32);
+    w.tb_all = take((size_t)B * h->tb_total);
+    w.sc.ya = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
+    w.sc.hb = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
+    w.sc.rc = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
+    w.x0 = take(M * h->ctraj);
+    w.cond_keep = take(16);
+    w.floats = off;
+    return w;
+}
+
+static int check_t(const rohm_trajnet* h, int B, int T) {
+    ROHM_ARG_CHECK(h != nullptr, "trajnet: null handle");
+    ROHM_ARG_CHECK(B > 0, "trajnet: batch must be positive");
+    ROHM_ARG_CHECK(T > 0 && T % 16 == 0, "trajnet: T must be a multiple of 16 (got %d)", T);
+    return ROHM_OK;
+}
+
+// cond encoder (no time input): trajnet.py:192-208.  Writes h_cond[i] into cat[i][:, ch:] and ccat[i][:, ch:].
+static int run_cond_encoder(const rohm_trajnet* h, const TWs& w, int B, int T, hipStream_t s) {
+    const int m = h->mid;
+    const int ch[4] = {m / 8, m / 4, m / 2, m};
+    int rc;
+    const float* x = w.cin;
+    int ldx = 32;
+    for (int i = 0; i < 4; ++i) {
+        const int Ti = T >> i;
+        float* dst = w.cat[i] + ch[i];
+        float* dst2 = h->control ? w.ccat[i] + ch[i] : nullptr;
+        if ((rc = res_block(h, h->cond_enc[i], x, ldx, B, Ti, nullptr, 0, nullptr, 0, dst, 2 * ch[i], dst2, 2 * ch[i],
+                            w.sc, s)))
+            return rc;
+        if (i < 3) {
+            if ((rc = down(h, h->cond_down[i], dst, 2 * ch[i], B, Ti, w.cdn[i], ch[i], s))) return rc;
+            x = w.cdn[i]; ldx = ch[i];
+        }
+    }
+    return ROHM_OK;
+}
+
+// everything that depends on x_t / t (and control_cond): trajnet.py:211-275
+static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int ldtb, float* out, hipStream_t s) {
+    const int m = h->mid;
+    const int ch[4] = {m / 8, m / 4, m / 2, m};
+    const float* tb = w.tb_all;
+    int rc;
+    if (h->control) {   // ControlNet.forward, trajnet.py:43-75
+        if ((rc = conv1(h->c_zero0, w.ctl, 288, B * T, w.cz, 32, s))) return rc;   // cols 13..31 stay zero
+        const float* x = w.cz;
+        int ldx = 32;
+        for (int i = 0; i < 4; ++i) {
+            const int Ti = T >> i;
+            if ((rc = res_block(h, h->c_enc[i], x, ldx, B, Ti, tb, ldtb, nullptr, 0, w.ccat[i], 2 * ch[i], nullptr, 0,
+                                w.sc, s)))
+                return rc;
+            if ((rc = conv1(h->c_zero[i], w.ccat[i], 2 * ch[i], B * Ti, w.ctrl[i], i == 0 ? 32 : ch[i - 1], s)))
+                return rc;
+            if ((rc = down(h, h->c_down[i], w.ccat[i], 2 * ch[i], B, Ti, w.kdn[i], 2 * ch[i], s))) return rc;
+            x = w.kdn[i]; ldx = 2 * ch[i];
+        }
+        const int T16 = T >> 4;
+        if ((rc = res_block(h, h->c_mid[0], w.kdn[3], 2 * m, B, T16, tb, ldtb, nullptr, 0, w.kmid_a, m, nullptr, 0, w.sc, s)))
+            return rc;
+        if ((rc = res_block(h, h->c_mid[1], w.kmid_a, m, B, T16, tb, ldtb, nullptr, 0, w.kmid_b, m, nullptr, 0, w.sc, s)))
+            return rc;
+        if ((rc = conv1(h->c_zero_mid, w.kmid_b, m, B * T16, w.ctrl_mid, m, s))) return rc;
+    }
+    // U-Net encoder
+    const float* x = w.xin;
+    int ldx = 32;
+    for (int i = 0; i < 4; ++i) {
+        const int Ti = T >> i;
+        // output goes to the left half of cat[i] (input of the down conv) and to the right half of dcat[i] (skip)
+        if ((rc = res_block(h, h->diff_enc[i], x, ldx, B, Ti, tb, ldtb, nullptr, 0, w.cat[i], 2 * ch[i],
+                            w.dcat[i] + ch[i], 2 * ch[i], w.sc, s)))
+            return rc;
+        if ((rc = down(h, h->diff_down[i], w.cat[i], 2 * ch[i], B, Ti, w.ddn[i], 2 * ch[i], s))) return rc;
+        x = w.ddn[i]; ldx = 2 * ch[i];
+    }
+    const int T16 = T >> 4;
+    if ((rc = res_block(h, h->mid_blk[0], w.ddn[3], 2 * m, B, T16, tb, ldtb, nullptr, 0, w.mid_a, m, nullptr, 0, w.sc, s)))
+        return rc;
+    if ((rc = res_block(h, h->mid_blk[1], w.mid_a, m, B, T16, tb, ldtb, h->control ? w.ctrl_mid : nullptr, m, w.mid_b, m,
+                        nullptr, 0, w.sc, s)))
+        return rc;
+    // decoder
+    x = w.mid_b; ldx = m;
+    for (int i = 3; i >= 0; --i) {
+        const int Ti = T >> i, Tq = Ti / 2;
+        if ((rc = upsample(h, h->up[i], x, ldx, B, Tq, w.dcat[i], 2 * ch[i], s))) return rc;
+        const int co = (i == 0) ? 32 : ch[i - 1];
+        if ((rc = res_block(h, h->dec[i], w.dcat[i], 2 * ch[i], B, Ti, tb, ldtb, h->control ? w.ctrl[i] : nullptr, co,
+                            w.d[i], co, nullptr, 0, w.sc, s)))
+            return rc;
+        x = w.d[i]; ldx = co;
+    }
+    // head: Conv1dBlock(32, 32, k5) + Conv1d(32, 13, 1)  (trajnet.py:158-161)
+    if ((rc = conv5(h, h->final_blk.conv, w.d[0], 32, B, T, w.sc.ya, 32, s))) return rc;
+    if ((rc = gn(h->final_blk, w.sc.ya, 32, B, T, nullptr, 0, nullptr, 0, nullptr, 0, w.fin, 32, nullptr, 0, s))) return rc;
+    return conv1(h->final_conv, w.fin, 32, B * T, out, h->ctraj, s);
+}
+
+static int run_time_path(const rohm_trajnet* h, const TWs& w, const int64_t* t_dev, int64_t t_host, int B,
+                         hipStream_t s) {
+    const int rows = t_dev ? B : 1;
+    prof::Scope ps("time_path", 0.0, 4.0 * h->tb_total * h->tdim, s);
+    hipLaunchKernelGGL(time_path_kernel, dim3(rows), dim3(256), 0, s, t_dev, t_host, h->tdim, h->t_w1T, h->t_b1, h->t_w3T,
+                       h->t_b3, h->tb_wT, h->tb_b, h->tb_total, w.tb_all);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+static int pad_rows(const float* src, float* dst, size_t rows, int cin, int cpad, hipStream_t s) {
+    const size_t n = rows * cpad;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, cin, cpad);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+}  // namespace rohm
+
+using namespace rohm;
+
+extern "C" {
+
+// Weights arrive as a flat table in the reference's state_dict order (see rohm_hip.h).
+int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, int mid_dim, int time_dim, int c_traj,
+                        int c_ctrl, int trajcontrol, int device) {
+    ROHM_ARG_CHECK(out && wts && wts->tensors, "trajnet_create: null argument");
+    ROHM_ARG_CHECK(mid_dim >= 256 && mid_dim % 256 == 0, "trajnet_create: mid_dim must be a multiple of 256");
+    ROHM_ARG_CHECK(time_dim == 32, "trajnet_create: time_dim must be 32");
+    ROHM_ARG_CHECK(c_traj > 0 && c_traj <= 32 && c_ctrl > 0 && c_ctrl <= 288, "trajnet_create: bad channel counts");
+    ROHM_HIP_CHECK(hipSetDevice(device));
+    rohm_trajnet* h = new rohm_trajnet();
+    h->mid = mid_dim; h->tdim = time_dim; h->ctraj = c_traj; h->cctrl = c_ctrl; h->control = trajcontrol ? 1 : 0;
+    h->device = device;
+    const int m = mid_dim;
+    const int ch[4] = {m / 8, m / 4, m / 2, m};
+
+    // ---- plan: walk the architecture twice (size, then fill) with the same code ------------------------------
+    int cursor = 0;                       // index into wts->tensors
+    size_t total = 0;
+    float* base = nullptr;
+    std::vector<float*> staged;           // device staging copies of source tensors (freed at the end)
+    bool ok = true;
+    std::string err;
+    auto next = [&](size_t expect_elems) -> const float* {
+        if (cursor >= wts->n_tensors) { ok = false; err = "weight table too short"; return nullptr; }
+        const rohm_tensor_ref& t = wts->tensors[cursor++];
+        if (t.numel != expect_elems) {
+            ok = false;
+            char buf[160];
+            snprintf(buf, sizeof(buf), "tensor %d has %zu elements, expected %zu", cursor - 1, (size_t)t.numel, expect_elems);
+            err = buf;
+            return nullptr;
+        }
+        return t.data;
+    };
+    auto arena_take = [&](size_t n) { float* p = base ? base + total : nullptr; total += al(n); return p; };
+    auto stage = [&](const float* src, size_t n) -> float* {   // device copy of a (host or device) tensor
+        float* d = nullptr;
+        if (hipMalloc(&d, n * sizeof(float)) != hipSuccess) { ok = false; err = "hipMalloc(staging) failed"; return nullptr; }
+        staged.push_back(d);
+        if (hipMemcpy(d, src, n * sizeof(float), hipMemcpyDefault) != hipSuccess) { ok = false; err = "hipMemcpy failed"; }
+        return d;
+    };
+    auto pad32 = [](int c) { return (c + 31) / 32 * 32; };
+    // conv: weight [cout, cin, k] (or [cin, cout, k] when transposed) + bias [cout]
+    auto load_conv = [&](ConvW& c, int cout, int cin, int k, int tap0, int tap_step, int ntap, bool transposed,
+                         const float* wsrc, const float* bsrc) {
+        c.cout = cout; c.cin = cin; c.cin_pad = pad32(cin); c.taps = (k == 1) ? 0 : ntap;
+        const int K = ntap * c.cin_pad;
+        c.w = arena_take((size_t)cout * K);
+        c.b = arena_take(cout);
+        if (base && ok) {
+            float* dw = stage(wsrc, (size_t)cout * cin * k);
+            if (!ok) return;
+            const int n = cout * K;
+            hipLaunchKernelGGL(relayout_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dw, c.w, cout, cin, k,
+                               c.cin_pad, tap0, tap_step, ntap, transposed ? 1 : 0);
+            if (hipMemcpy(c.b, bsrc, cout * sizeof(float), hipMemcpyDefault) != hipSuccess) { ok = false; err = "bias copy"; }
+        }
+    };
+    auto conv_std = [&](ConvW& c, int cout, int cin, int k) {
+        const float* wsrc = next((size_t)cout * cin * k);
+        const float* bsrc = next(cout);
+        if (!ok) return;
+        load_conv(c, cout, cin, k, 0, 1, k, false, wsrc, bsrc);
+    };
+    auto vec = [&](float*& dst, int n) {
+        const float* src = next(n);
+        dst = arena_take(n);
+        if (base && ok && hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDefault) != hipSuccess) { ok = false; err = "vector copy"; }
+    };
+    std::vector<std::pair<const float*, const float*>> tb_src;   // (weight [cout, tdim], bias) per time block
+    std::vector<int> tb_cout;
+    int tb_total = 0;
+    auto block = [&](BlockW& b, int cin, int cout) {
+        conv_std(b.conv, cout, cin, 5);
+        vec(b.g, cout);
+        vec(b.be, cout);
+    };
+    auto resblk = [&](ResW& r, int cin, int cout, bool input_t) {
+        r.cin = cin; r.cout = cout;
+        block(r.b0, cin, cout);
+        block(r.b1, cout, cout);
+        if (input_t) {
+            const float* tw = next((size_t)cout * time_dim);
+            const float* tbias = next(cout);
+            r.tb_off = tb_total;
+            tb_total += cout;
+            tb_src.push_back({tw, tbias});
+            tb_cout.push_back(cout);
+        }
+        r.has_res = (cin != cout);
+        if (r.has_res) conv_std(r.res, cout, cin, 1);
+    };
+    const float *w1 = nullptr, *b1 = nullptr, *w3 = nullptr, *b3 = nullptr;
+    const float* upw[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float* upb[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    for (int pass = 0; pass < 2 && ok; ++pass) {
+        cursor = 0; total = 0; tb_total = 0; tb_src.clear(); tb_cout.clear();
+        // --- state_dict order of model/trajnet.py (controlnet.* first when present) ---
+        if (h->control) {
+            conv_std(h->c_zero0, c_traj, c_ctrl, 1);
+            int cin = c_traj;
+            for (int i = 0; i < 4 && ok; ++i) {
+                resblk(h->c_enc[i], cin, ch[i], true);
+                conv_std(h->c_zero[i], i == 0 ? 32 : ch[i - 1], ch[i], 1);
+                conv_std(h->c_down[i], 2 * ch[i], 2 * ch[i], 3);
+                cin = 2 * ch[i];
+            }
+            resblk(h->c_mid[0], 2 * m, m, true);
+            resblk(h->c_mid[1], m, m, true);
+            conv_std(h->c_zero_mid, m, m, 1);
+        }
+        w1 = next((size_t)4 * time_dim * time_dim); b1 = next(4 * time_dim);
+        w3 = next((size_t)time_dim * 4 * time_dim); b3 = next(time_dim);
+        {
+            int cin = c_traj;
+            for (int i = 0; i < 4 && ok; ++i) {
+                resblk(h->diff_enc[i], cin, ch[i], true);
+                conv_std(h->diff_down[i], 2 * ch[i], 2 * ch[i], 3);
+                cin = 2 * ch[i];
+            }
+        }
+        resblk(h->mid_blk[0], 2 * m, m, true);
+        resblk(h->mid_blk[1], m, m, true);
+        for (int i = 3; i >= 0 && ok; --i) {          // upsample4, dec4, ..., upsample1, dec1
+            upw[i] = next((size_t)ch[i] * ch[i] * 4);
+            upb[i] = next(ch[i]);
+            if (ok) {
+                load_conv(h->up[i].even, ch[i], ch[i], 4, 1, 2, 2, true, upw[i], upb[i]);   // taps j = 1, 3
+                load_conv(h->up[i].odd, ch[i], ch[i], 4, 0, 2, 2, true, upw[i], upb[i]);    // taps j = 0, 2
+            }
+            resblk(h->dec[i], 2 * ch[i], i == 0 ? 32 : ch[i - 1], true);
+        }
+        block(h->final_blk, 32, 32);
+        conv_std(h->final_conv, c_traj, 32, 1);
+        {
+            int cin = c_traj;   // cond_dim == traj_feat_dim in every driver (test_amass_full.py:151-153)
+            for (int i = 0; i < 4 && ok; ++i) {
+                resblk(h->cond_enc[i], cin, ch[i], false);
+                ConvW dummy;
+                conv_std(i < 3 ? h->cond_down[i] : dummy, ch[i], ch[i], 3);   // cond_downsample4 exists but is never called
+                cin = ch[i];
+            }
+        }
+        if (ok && cursor != wts->n_tensors) { ok = false; err = "weight table has extra tensors"; }
+        // time path storage
+        h->tb_total = tb_total;
+        h->t_w1T = arena_take((size_t)time_dim * 4 * time_dim); h->t_b1 = arena_take(4 * time_dim);
+        h->t_w3T = arena_take((size_t)4 * time_dim * time_dim); h->t_b3 = arena_take(time_dim);
+        h->tb_wT = arena_take((size_t)time_dim * tb_total); h->tb_b = arena_take(tb_total);
+        h->zero_page = arena_take(64);
+        if (pass == 0 && ok) {
+            const size_t bytes = total * sizeof(float);
+            hipError_t e = hipMalloc(&h->arena, bytes);
+            if (e != hipSuccess) { ok = false; err = std::string("hipMalloc(arena) failed: ") + hipGetErrorString(e); break; }
+            if (hipMemset(h->arena, 0, bytes) != hipSuccess) { ok = false; err = "hipMemset failed"; break; }
+            base = h->arena;
+        } else if (ok) {
+            // fill the time path
+            float* d1 = stage(w1, (size_t)4 * time_dim * time_dim);
+            float* d3 = stage(w3, (size_t)time_dim * 4 * time_dim);
+            if (ok) {
+                const int n1 = 4 * time_dim * time_dim;
+                hipLaunchKernelGGL(transpose2_kernel, dim3((n1 + 255) / 256), dim3(256), 0, 0, d1, h->t_w1T, 4 * time_dim,
+                                   time_dim, 4 * time_dim, 0);
+                hipLaunchKernelGGL(transpose2_kernel, dim3((n1 + 255) / 256), dim3(256), 0, 0, d3, h->t_w3T, time_dim,
+                                   4 * time_dim, time_dim, 0);
+                (void)hipMemcpy(h->t_b1, b1, 4 * time_dim * sizeof(float), hipMemcpyDefault);
+                (void)hipMemcpy(h->t_b3, b3, time_dim * sizeof(float), hipMemcpyDefault);
+                int col = 0;
+                for (size_t k = 0; k < tb_src.size() && ok; ++k) {
+                    const int co = tb_cout[k];
+                    float* dw = stage(tb_src[k].first, (size_t)co * time_dim);
+                    if (!ok) break;
+                    const int n = co * time_dim;
+                    hipLaunchKernelGGL(transpose2_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dw, h->tb_wT, co, time_dim,
+                                       tb_total, col);
+                    (void)hipMemcpy(h->tb_b + col, tb_src[k].second, co * sizeof(float), hipMemcpyDefault);
+                    col += co;
+                }
+            }
+        }
+    }
+    hipError_t se = hipDeviceSynchronize();
+    for (float* d : staged) (void)hipFree(d);
+    if (ok && se != hipSuccess) { ok = false; err = hipGetErrorString(se); }
+    if (!ok) {
+        set_error("trajnet_create: %s", err.c_str());
+        if (h->arena) (void)hipFree(h->arena);
+        delete h;
+        return ROHM_ERR_ARG;
+    }
+    *out = h;
+    return ROHM_OK;
+}
+
+void rohm_trajnet_destroy(rohm_trajnet_t* h) {
+    if (!h) return;
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+}
+
+size_t rohm_trajnet_workspace_bytes(const rohm_trajnet_t* h, int B, int T) {
+    if (!h || B <= 0 || T <= 0 || T % 16) return 0;
+    return carve_t(h, B, T, nullptr).floats * sizeof(float);
+}
+
+int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float* cond, const float* control_cond,
+                         const int64_t* t, float* x0_out, int B, int T, void* ws, size_t ws_bytes,
+                         rohm_stream_t stream) {
+    int rc = check_t(h, B, T);
+    if (rc) return rc;
+    ROHM_ARG_CHECK(x_t && cond && t && x0_out && ws, "trajnet_forward: null argument");
+    ROHM_ARG_CHECK(!h->control || control_cond, "trajnet_forward: TrajControl needs control_cond");
+    ROHM_ARG_CHECK(((uintptr_t)ws % 256) == 0, "trajnet_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    TWs w = carve_t(h, B, T, (float*)ws);
+    if (w.floats * sizeof(float) > ws_bytes) {
+        set_error("trajnet_forward: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
+        return ROHM_ERR_WORKSPACE;
+    }
+    const size_t M = (size_t)B * T;
+    if ((rc = pad_rows(x_t, w.xin, M, h->ctraj, 32, s))) return rc;
+    if ((rc = pad_rows(cond, w.cin, M, h->ctraj, 32, s))) return rc;
+    if (h->control) {
+        if ((rc = pad_rows(control_cond, w.ctl, M, h->cctrl, 288, s))) return rc;
+        ROHM_HIP_CHECK(hipMemsetAsync(w.cz, 0, M * 32 * sizeof(float), s));
+    }
+    if ((rc = run_time_path(h, w, t, 0, B, s))) return rc;
+    if ((rc = run_cond_encoder(h, w, B, T, s))) return rc;
+    return run_denoiser(h, w, B, T, h->tb_total, x0_out, s);
+}
+
+int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* cond, const float* control_cond,
+                             const int64_t* t_model, const float* coef, const float* noise, float* x0_last,
+                             int n_steps, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream) {
+    int rc = check_t(h, B, T);
+    if (rc) return rc;
+    ROHM_ARG_CHECK(x && cond && t_model && coef && ws, "trajnet_sample_loop: null argument");
+    ROHM_ARG_CHECK(!h->control || control_cond, "trajnet_sample_loop: TrajControl needs control_cond");
+    ROHM_ARG_CHECK(((uintptr_t)ws % 256) == 0, "trajnet_sample_loop: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    TWs w = carve_t(h, B, T, (float*)ws);
+    if (w.floats * sizeof(float) > ws_bytes) {
+        set_error("trajnet_sample_loop: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
+        return ROHM_ERR_WORKSPACE;
+    }
+    const size_t M = (size_t)B * T, n = M * h->ctraj;
+    // cond / control_cond do not change over the loop: pad them and run the (time-free) cond encoder once
+    if ((rc = pad_rows(cond, w.cin, M, h->ctraj, 32, s))) return rc;
+    if (h->control) {
+        if ((rc = pad_rows(control_cond, w.ctl, M, h->cctrl, 288, s))) return rc;
+        ROHM_HIP_CHECK(hipMemsetAsync(w.cz, 0, M * 32 * sizeof(float), s));
+    }
+    if ((rc = run_cond_encoder(h, w, B, T, s))) return rc;
+    for (int i = 0; i < n_steps; ++i) {
+        prof::set_step(i);
+        const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
+        ROHM_ARG_CHECK(sigma == 0.f || noise, "trajnet_sample_loop: noise is required when sigma != 0");
+        if ((rc = pad_rows(x, w.xin, M, h->ctraj, 32, s))) return rc;
+        if ((rc = run_time_path(h, w, nullptr, t_model[i], B, s))) return rc;
+        float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
+        if ((rc = run_denoiser(h, w, B, T, 0, x0, s))) return rc;
+        if ((rc = launch_ddpm_step(x, x0, noise ? noise + (size_t)i * n : nullptr, nullptr, c1, c2, sigma, 0.f, x, n, s)))
+            return rc;
+    }
+    return ROHM_OK;
+}
+
+}  // extern "C"

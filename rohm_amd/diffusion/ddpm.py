@@ -270,7 +270,7 @@ class DDPMSampler:
                     nz = torch.randn((n,) + tuple(x.shape), device=x.device, dtype=torch.float32)
                 last = (pos + n == len(indices))
                 x0 = raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz,
-                                            want_x0_last=last)
+                                            want_x0_last=last, batch=batch)
                 if last:
                     x0_last = x0
                 pos += n

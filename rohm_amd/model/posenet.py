@@ -194,7 +194,7 @@ class PoseNet(nn.Module):
         return out
 
     # ------------------------------------------------------------------ fused sampling loop
-    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False):
+    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False, batch=None):
         """Run `n = len(t_model)` DDPM steps on the device (rohm_posenet_sample_loop).
 
         x [B,C,1,T] is updated in place; noise [n,B,C,1,T]; coef float32 host array [n,3] of

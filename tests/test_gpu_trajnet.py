@@ -1,0 +1,101 @@
+"""GPU parity of the TrajNet / TrajControl path (through the C ABI) vs the reference's golden outputs and the
+CPU oracle.  Single forwards 2e-4 (51-71 stacked fp32 convolutions); full 100-step sampling 1e-3."""
+import pytest
+import torch
+
+from helpers import cpu_noise_sequence, golden, max_abs, seeded
+from oracle import diffusion as odiff
+from oracle import nets
+from rohm_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+class Args:
+    noise_schedule, sigma_small = 'cosine', True
+
+
+def make_trajnet(seed, ctrl):
+    from rohm_amd.model.trajnet import TrajNet
+    net = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=ctrl, device=DEV)
+    sd = synth.trajnet_state_dict(seed, trajcontrol=ctrl)
+    net.load_state_dict(sd, strict=True)
+    return net.to(DEV).eval(), sd
+
+
+def make_diffusion(steps=100):
+    from rohm_amd.diffusion import gaussian_diffusion_trajnet as gdt
+    from rohm_amd.diffusion.respace import SpacedDiffusionTrajNet
+    from rohm_amd.utils.model_util import create_gaussian_diffusion
+    return create_gaussian_diffusion(Args, gdt, SpacedDiffusionTrajNet, steps, '', device=DEV)
+
+
+@pytest.mark.parametrize('name', ['trajnet_forward.npz', 'trajnet_control_forward.npz'])
+def test_forward_vs_reference_golden(name):
+    g = golden(name)
+    ctrl = 'control' in name
+    net, _ = make_trajnet(int(g['weight_seed']), ctrl)
+    batch = {'x_t': seeded(int(g['x_seed']), 2, 144, 13).to(DEV), 'cond': seeded(int(g['cond_seed']), 2, 144, 13).to(DEV),
+             'control_cond': seeded(int(g['control_seed']), 2, 144, 272).to(DEV)}
+    y = net(batch, torch.from_numpy(g['t']).to(DEV)).cpu()
+    assert max_abs(y, torch.from_numpy(g['y'])) < 2e-4
+
+
+@pytest.mark.parametrize('B,T,ctrl', [(1, 144, False), (3, 144, True), (2, 48, True), (5, 16, False)])
+def test_forward_vs_oracle(B, T, ctrl):
+    net, sd = make_trajnet(40 + B, ctrl)
+    x, c, cc = seeded(1, B, T, 13), seeded(2, B, T, 13), seeded(3, B, T, 272)
+    t = torch.tensor([(37 * i + 3) % 100 for i in range(B)])
+    ref = nets.trajnet_forward(sd, x, c, t, control_cond=cc if ctrl else None, dtype=torch.float64)
+    y = net({'x_t': x.to(DEV), 'cond': c.to(DEV), 'control_cond': cc.to(DEV)}, t.to(DEV)).cpu()
+    assert max_abs(y, ref) < 2e-4
+
+
+def test_zero_control_is_identity_on_gpu():
+    """with zero-initialised control convs TrajControl reproduces the vanilla net exactly."""
+    from rohm_amd.model.trajnet import TrajNet
+    sd_c = synth.trajnet_state_dict(5, trajcontrol=True, zero_convs_random=False)
+    sd_v = {k: v for k, v in sd_c.items() if not k.startswith('controlnet.')}
+    nc = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=True).to(DEV)
+    nv = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=False).to(DEV)
+    nc.load_state_dict(sd_c)
+    nv.load_state_dict(sd_v)
+    batch = {'x_t': seeded(1, 2, 144, 13).to(DEV), 'cond': seeded(2, 2, 144, 13).to(DEV),
+             'control_cond': seeded(3, 2, 144, 272).to(DEV)}
+    t = torch.tensor([42, 7], device=DEV)
+    assert torch.equal(nc(batch, t), nv(batch, t))
+
+
+def test_loop100_vs_reference_golden():
+    """BASELINE.json configs[0]: TrajNet vanilla, one clip, the full 100-step loop; noise = the reference's CPU stream."""
+    g = golden('trajnet_loop100.npz')
+    net, _ = make_trajnet(int(g['weight_seed']), False)
+    cond = seeded(int(g['cond_seed']), 1, 144, 13)
+    x_T, noises = cpu_noise_sequence(int(g['torch_seed']), (1, 144, 13), 100, trajnet_layout=True)
+    for fused in (True, False):
+        diff = make_diffusion()
+        diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+        diff.fused_chunk = 33
+        batch = {'cond': cond.to(DEV)}
+        if fused:
+            _, y = diff.eval_losses(model=net, batch=batch, shape=[1, 144, 13], progress=False, clip_denoised=False,
+                                    timestep_respacing='', cond_fn_with_grad=True, compute_loss=False)
+        else:
+            y = list(diff.p_sample_loop_progressive(net, batch, [1, 144, 13]))[-1]['sample']
+        assert max_abs(y.cpu(), torch.from_numpy(g['y'])) < 1e-3, fused
+
+
+def test_control_loop_vs_oracle():
+    net, sd = make_trajnet(61, True)
+    B = 2
+    cond, cc = seeded(5, B, 144, 13), seeded(6, B, 144, 272)
+    x_T, noises = cpu_noise_sequence(8, (B, 144, 13), 100)
+    diff = make_diffusion()
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    _, y = diff.eval_losses(model=net, batch={'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}, shape=[B, 144, 13],
+                            progress=False, clip_denoised=False, timestep_respacing='', cond_fn_with_grad=True,
+                            compute_loss=False)
+    fn = lambda x, i: nets.trajnet_forward(sd, x, cond, torch.full((B,), i, dtype=torch.int64), control_cond=cc)
+    ref = odiff.p_sample_loop(fn, x_T, noises, odiff.tables(odiff.cosine_betas(100)), list(range(100))[::-1])
+    assert max_abs(y.cpu(), ref) < 1e-3

@@ -65,6 +65,25 @@ def test_posenet_state_dict_contract():
     assert sum(p.numel() for n, p in net.named_parameters() if not n.startswith('smplx_model.')) == 17789200
 
 
+def test_trajnet_state_dict_contract():
+    from rohm_amd.model.trajnet import TrajNet, weight_order
+    for ctrl, n_keys in ((False, 186), (True, 270)):
+        net = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=ctrl, device='cpu')
+        sd = synth.trajnet_state_dict(4, trajcontrol=ctrl)
+        assert list(net.state_dict().keys()) == list(sd.keys()) and len(sd) == n_keys
+        net.load_state_dict(sd, strict=True)
+        assert weight_order(512, 13, ctrl) == list(sd.keys())         # the order the C ABI consumes
+    n_all = sum(p.numel() for p in net.parameters())
+    n_ctrl = sum(p.numel() for n, p in net.named_parameters() if n.startswith('controlnet.'))
+    assert n_ctrl == 15242557 and n_all - n_ctrl == 22582893
+    # zero-initialised control convs (heads.py:12-18)
+    fresh = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=True)
+    assert float(fresh.controlnet.control_zero_conv_mid.weight.abs().max()) == 0.0
+    with pytest.raises(_lib.RohmHipError):
+        fresh({'x_t': torch.zeros(1, 144, 13), 'cond': torch.zeros(1, 144, 13),
+               'control_cond': torch.zeros(1, 144, 272)}, torch.zeros(1, dtype=torch.int64))
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly on CPU tensors instead of silently computing elsewhere."""
     from rohm_amd.model.posenet import PoseNet
