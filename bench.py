@@ -144,7 +144,7 @@ def main():
     diffusion = create_gaussian_diffusion(_Args, gdp, SpacedDiffusionPoseNet, S, '', device=dev)
     cond = synthetic_cond(B, dev, seed=1000 + rank)
     torch.manual_seed(rank)
-    gathered = [torch.empty(B, 294, 1, 143, device=dev) for _ in range(world)] if world > 1 else None
+    from rohm_amd import sharding
 
     def one_pass():
         batch = {'cond': cond}
@@ -152,7 +152,7 @@ def main():
                                       clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
                                       compute_loss=False)
         if world > 1:
-            dist.all_gather(gathered, x0.contiguous())
+            sharding.gather_clips(x0, world * B)      # the path's only exchange: finished clips, RCCL all-gather
         return x0
 
     def sync():

@@ -1,0 +1,71 @@
+"""Clip-level data parallelism for the denoising loops.
+
+Clips are independent in both networks (GroupNorm / attention / LayerNorm never cross the batch dimension),
+so a node runs one process per GPU, every rank denoises a contiguous slice of the batch with its own replica of
+the weights, and the only communication is ONE all-gather of the finished clips per sampling run
+(`torch.distributed` backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).  There is no
+collective inside the networks.
+
+Guidance semantics under sharding: the reference normalises the skating loss by a mask count summed over the
+whole batch (model/posenet.py:231,243) and averages the 2-D loss over it (:309).  `shard_batch` implements
+REPLICA semantics -- each rank behaves exactly like the reference run with batch_size = its local slice --
+which needs no communication; reproducing the reference at the global batch size would need the two mask
+counts all-reduced per guided step (documented in DESIGN.md, not implemented).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def slice_bounds(n, world, rank):
+    """Contiguous, near-equal split of n items: rank r gets [lo, hi)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(batch, world=None, rank=None, batch_dim_keys=None):
+    """Slice every tensor of `batch` whose leading dimension is the (global) batch size."""
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    sizes = [v.shape[0] for v in batch.values() if torch.is_tensor(v) and v.dim() > 0]
+    if not sizes:
+        return dict(batch)
+    n = max(set(sizes), key=sizes.count)
+    lo, hi = slice_bounds(n, world, rank)
+    out = {}
+    for k, v in batch.items():
+        take = torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n and \
+            (batch_dim_keys is None or k in batch_dim_keys)
+        out[k] = v[lo:hi] if take else v
+    return out
+
+
+def gather_clips(local, n_total, group=None):
+    """All-gather the per-rank results (possibly ragged along dim 0) back into the global batch order."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    counts = [slice_bounds(n_total, world, r)[1] - slice_bounds(n_total, world, r)[0] for r in range(world)]
+    width = max(counts)
+    pad = local
+    if local.shape[0] < width:
+        pad = torch.cat([local, local.new_zeros((width - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad.contiguous(), group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+def sharded_sample(sample_fn, batch, shape, group=None):
+    """Run `sample_fn(local_batch, local_shape) -> x0 [B_local, ...]` on this rank's slice and gather.
+
+    `sample_fn` is the single-GPU call, e.g.
+        lambda b, s: diffusion.eval_losses(model=net, batch=b, shape=s, compute_loss=False, ...)[1]
+    """
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = shape[0]
+    lo, hi = slice_bounds(n, world, rank)
+    local = shard_batch(batch, world, rank)
+    out = sample_fn(local, [hi - lo] + list(shape[1:]))
+    return gather_clips(out, n, group)
