@@ -59,6 +59,21 @@ def synthetic_cond(B, device, seed):
     return cond.permute(0, 2, 1).unsqueeze(2).contiguous().to(device)
 
 
+def pmc_traffic():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json,
+    produced by scripts/gpu_profile.sh + scripts/pmc_summary.py; FETCH_SIZE x2 on gfx950).  PMC collection
+    serialises kernels, so it is a separate run of the same workload, never part of the timed region."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return float(d['gemm_family_bytes_per_launch']), os.path.basename(files[-1])
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -205,7 +220,9 @@ def main():
                 'kernel': 'gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region, '
                           f'sampled every {args.profile_stride}th denoising step)',
                 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': None,
+                'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,
+                'traffic': pmc_traffic()[0], 'traffic_unit': 'bytes per launch (HBM side, PMC)',
+                'traffic_source': pmc_traffic()[1],
                 'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
                 'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,
                 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,

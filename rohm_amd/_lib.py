@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librohm_hip.so')
+LIB_PATH = os.environ.get('ROHM_HIP_LIB') or os.path.join(_HERE, 'librohm_hip.so')
 
 c_float_p = C.POINTER(C.c_float)
 c_int64_p = C.POINTER(C.c_int64)

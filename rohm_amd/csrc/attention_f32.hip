@@ -10,7 +10,8 @@
 //            144 scores of ONE query row, so the softmax row reduction is in-register plus two
 //            cross-lane steps (lanes l, l^16, l^32, l^48 share a query).
 //   phase 2  softmax in fp32 (max-subtracted, normalised before P.V like the reference).
-//   phase 3  O = P . V: the S^T accumulator layout *is* the MFMA A-operand layout of P
+//   phase 3  O^T = V^T . P^T (operands swapped so each lane ends with 4 consecutive output floats = one
+//            16-byte store): the S^T accumulator layout *is* the MFMA operand layout of P
 //            (lane (i = query, g) register j = P[query][16kb + 4g + j]), so P never leaves
 //            registers; V comes from LDS (row stride 132 floats: conflict-free ds_read_b32).
 // Scores never touch LDS or HBM.  LDS: (136 + 132) * 144 * 4 = 154,368 B (of 160 KiB).
@@ -130,12 +131,11 @@ __global__ __launch_bounds__(AT_THREADS) void attention_f32_kernel(const float* 
         for (int kb = 0; kb < AT_NB; ++kb) {
             const float* vp = Vs + (kb * 16 + lg * 4) * AT_VS + db * 16 + li;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[kb][j], vp[j * AT_VS], oacc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j)   // operands swapped (V on the "A" side): the tile comes out as O^T
+                oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[j * AT_VS], sacc[kb][j], oacc, 0, 0, 0);
         }
-        // oacc[r] = O[query = 4*lg + r][d = 16*db + li]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(lg * 4 + r) * D + db * 16 + li] = oacc[r];
+        // oacc[r] = O[query = li][d = 16*db + 4*lg + r]: four consecutive floats -> one 16-byte store
+        *reinterpret_cast<f32x4*>(out + (size_t)li * D + db * 16 + lg * 4) = oacc;
     }
 }
 

@@ -1,70 +1,121 @@
 // fp32 MFMA GEMM for gfx950:  C[M,N] = epi(A[M,K] . W[N,K]^T)
 //
-// Every Linear of the PoseNet path (model/posenet.py:63-69, model/heads.py:154,169) runs on this
-// kernel.  Numerics: v_mfma_f32_16x16x4_f32 is an exact-fp32 fma chain (guide §3), i.e. the same
-// rounding class as the CPU reference's fp32 GEMM; only the summation order differs.
+// Every Linear of the PoseNet path (model/posenet.py:63-69, model/heads.py:154,169) and, with a tap-gathered
+// A operand, every Conv1d / ConvTranspose1d of TrajNet (model/heads.py:72-106) runs on this kernel.
+// Numerics: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 are exact-fp32 fma chains (guide §3), i.e. the
+// same rounding class as the CPU reference's fp32 GEMM; only the summation order differs.
 //
-// Tiling (MI355X-first, not a warp-shaped port):
-//   * workgroup tile 144 x BN (BN = 128 or 64), 4 waves (one per SIMD).  144 = 9 x 16 is exactly one
-//     PoseNet clip (143 frames + timestep token), so M = B*144 tiles with no remainder and, at the
-//     headline batch B = 64, N = 512 gives 64 x 4 = 256 tiles = one per CU.
-//   * wave w owns columns [w*BN/4, (w+1)*BN/4): 9 x (BN/64) accumulator blocks of 16x16.
-//   * K is walked in 32-wide chunks, register-staged global->LDS with two LDS buffers: the loads
-//     for chunk k+1 are in flight while chunk k is multiplied, one barrier per chunk.
-//   * both operands are K-contiguous, so a lane's MFMA fragments for four consecutive k-steps are
-//     one ds_read_b128: lane (i = l&15, g = l>>4) holds X[i][16*ks + 4*g + j], j = 0..3, and MFMA j
-//     contracts k = {4g + j}: a fixed permutation of k inside each 16-chunk, identical for A and W.
-//   * LDS rows are 128 B (32 floats); the 16-byte slot index is XOR-swizzled with (row>>1)&7, which
-//     makes every ds_read_b128 lane group hit 16 distinct 16-byte slots (conflict-free, guide §2).
-//   * blockIdx -> tile mapping is XCD-aware: each XCD gets a contiguous run of tiles that share A
-//     panels, so an A panel is fetched into one L2 instead of eight.
+// Design (MI355X-first, not a warp-shaped port):
+//   * workgroup tile 144 x BN (BN = 64 / 128 / 256 / 384), 4 waves = one per SIMD, ONE workgroup per CU.
+//     144 = one PoseNet clip (143 frames + timestep token), so M = B*144 has no remainder and at the headline
+//     batch B = 64 the widest tile that still gives all 256 CUs a tile is picked per GEMM: N = 512 -> 144x128,
+//     N = 1024 -> 144x256, N = 1536 -> 144x384, each exactly 256 tiles.
+//   * wave w owns columns [w*BN/4, (w+1)*BN/4).  Rows 0..127 of the tile are four 32-row blocks multiplied
+//     with v_mfma_f32_32x32x2_f32 (measured 154.7 TFLOP/s as a bare stream with one wave per SIMD), rows
+//     128..143 one 16-row block on v_mfma_f32_16x16x4_f32 (138.8 TFLOP/s bare; it cannot be issued back to back
+//     at its nominal 32 cycles).  So 8/9 of the flops run on the instruction that reaches peak.  (BN = 64 keeps
+//     the all-16x16 form: a wave's 16 columns are narrower than a 32x32 block.)
+//   * both operands are K-contiguous, so a lane's fragments for several consecutive k-steps are ONE
+//     ds_read_b128: 32x32x2: lane (i = l&31, g = l>>5) holds X[i][8*s + 4g + j], j = 0..3, MFMA j contracts
+//     k = {j, 4 + j}; 16x16x4: lane (i = l&15, g = l>>4) holds X[i][16*s + 4g + j], MFMA j contracts
+//     k = {4g + j}: fixed permutations of k, identical for both operands.
+//   * operands are SWAPPED (weights on the MFMA "A" side) so a lane ends with 4 consecutive output columns of one
+//     row -> 16-byte epilogue stores (the 4-byte form cost 10 us per tile).
+//   * staging: LDS-DMA (global_load_lds_dwordx4), K chunks of 32, two LDS buffers; the XOR swizzle that makes
+//     every ds_read_b128 conflict-free is applied to the per-lane SOURCE address (the DMA writes LDS linearly).
+//     No predicated loads: out-of-range rows are clamped (they only feed rows / columns never stored).
+//   * schedule per chunk: [LDS reads of half 1 | MFMAs of half 0] vmcnt(0)+barrier [DMA of chunk k+2 + LDS reads
+//     of chunk k+1's half 0 | MFMAs of half 1]: HBM/L2 latency has a whole chunk to land, LDS latency hides
+//     behind MFMAs.  The loop body is one basic block (the DMA of the last two iterations is redirected, not
+//     predicated) and sched_group_barrier spreads every non-MFMA instruction between MFMAs: with one wave per
+//     SIMD a clustered non-MFMA issue slot is an MFMA-pipe bubble.
+//   * XCD-aware tile order: each XCD gets a contiguous run of tiles sharing A panels.
 #include <stdlib.h>
 #include "common.h"
 
 namespace rohm {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 constexpr int BM = 144;
 constexpr int BK = 32;
-constexpr int NRB = BM / 16;        // 9 row blocks
+constexpr int NRB = BM / 16;        // 9 row blocks of 16 (BN = 64 path)
 constexpr int A_UNITS = BM * 8;     // 16-byte units per A chunk (1152)
-constexpr int A_ITERS = (A_UNITS + 255) / 256;  // 5 (last one half full)
+constexpr int A_ITERS = (A_UNITS + 255) / 256;  // 5 (the last pass is half populated)
 
 __device__ __forceinline__ int lds_off(int row, int slot) {   // float index inside a [rows][32] tile
     return row * BK + ((slot ^ ((row >> 1) & 7)) << 2);
 }
 
+// Exact-erf GELU (activation="gelu", model/posenet.py:67).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <=
+// 1.5e-7, i.e. at fp32 resolution of the 1 + erf term) -- branch-free, one rcp + one exp, ~3x cheaper than the
+// library erff in a 72-element-per-lane epilogue.
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-z * z);      // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
 }
+
+// compile-time repetition of sched_group_barrier triples (the builtin needs literal arguments)
+template <int I, int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID>
+struct SchedGroups {
+    static __device__ __forceinline__ void run() {
+        constexpr int kMfma = 0x008, kVmem = 0x010, kDsRead = 0x100;
+        __builtin_amdgcn_sched_group_barrier(kMfma, MF, ID);
+        __builtin_amdgcn_sched_group_barrier(kDsRead, DS_TOTAL / N + (I < DS_TOTAL % N ? 1 : 0), ID);
+        __builtin_amdgcn_sched_group_barrier(kVmem, VM_TOTAL / N + (I < VM_TOTAL % N ? 1 : 0), ID);
+        SchedGroups<I + 1, N, MF, DS_TOTAL, VM_TOTAL, ID>::run();
+    }
+};
+template <int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID>
+struct SchedGroups<N, N, MF, DS_TOTAL, VM_TOTAL, ID> {
+    static __device__ __forceinline__ void run() {}
+};
+
+#ifndef ROHM_GEMM_MIXED
+#define ROHM_GEMM_MIXED 1
+#endif
 
 template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
-    constexpr int WN = BN / 4;        // columns per wave
-    constexpr int NCB = WN / 16;      // 16-wide column blocks per wave (2 or 1)
+    constexpr int WN = BN / 4;             // columns per wave
+    constexpr bool M32 = (WN >= 64) && (ROHM_GEMM_MIXED != 0);   // mixed 32x32x2 + 16x16x4 path
+    constexpr int NCB = WN / 16;           // 16-wide column blocks per wave
+    constexpr int NCB32 = WN / 32;         // 32-wide column blocks per wave (M32)
     constexpr int B_UNITS = BN * 8;
-    constexpr int B_ITERS = B_UNITS / 256;   // 4 or 2
+    constexpr int B_ITERS = B_UNITS / 256; // 2, 4, 8 or 12
+    constexpr int PIECES = A_ITERS + B_ITERS;   // LDS-DMA instructions per wave per chunk
+    // Operand order: SWAP puts the weight fragment on the MFMA "A" side, so a lane ends up with four CONSECUTIVE
+    // output columns of one row (one 16-byte store); the transposed output head keeps the natural order because
+    // its stores are contiguous along the token axis instead.
+    constexpr bool SWAP = (EPI != EPI_OUT_T);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][BM*BK]
     float* Bs = smem + 2 * BM * BK;         // [2][BN*BK]
+    float* lds_dummy = smem + 2 * (BM + BN) * BK;     // 2 KiB landing zone (inside the padded LDS request)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
+    const int li = lane & 15, lg = lane >> 4;       // 16x16x4 fragment coordinates
+    const int li32 = lane & 31, lg32 = lane >> 5;   // 32x32x2 fragment coordinates
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave) * 64;   // provably wave-uniform LDS base
 
+    unsigned long long ts_wall[5] = {0, 0, 0, 0, 0}, ts_cyc[2] = {0, 0};   // VAR 7 only (timeline diagnostics)
+    if constexpr (VAR == 7) ts_wall[0] = wall_clock64();
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
 
-    // ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4) ---------------------------
-    // The DMA writes LDS linearly (wave-uniform base + lane*16 B), so the XOR swizzle is applied to
-    // the per-lane SOURCE address instead (guide rule 21): the lane whose LDS unit is (row, pslot)
-    // fetches logical slot pslot ^ ((row>>1)&7) of that row -- still inside the row's one 128-B line.
-    // Rows past M / N are clamped to a valid row: they only feed accumulator rows / columns that the
-    // epilogue never stores, so no zero fill is needed and there is no predicated load.
+    // ---- global -> LDS staging by LDS-DMA ---------------------------------------------------------------------
     const float* a_src[A_ITERS];
     int a_b[A_ITERS], a_tq[A_ITERS], a_slot[A_ITERS];      // conv gather: clip, output frame, 16-B slot
 #pragma unroll
@@ -80,8 +131,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             a_slot[i] = slot;
         }
     }
-    // conv gather: source pointer of unit i for the K chunk starting at k0 (a chunk never straddles taps
-    // because cin_pad is a multiple of 32); taps that fall outside the clip read a page of zeros.
+    // conv gather: source pointer of unit i for the K chunk starting at k0 (a chunk never straddles taps because
+    // cin_pad is a multiple of 32); taps that fall outside the clip read a page of zeros.
     auto conv_src = [&](int i, int k0) -> const float* {
         const int j = k0 / p.conv_cin_pad, ci0 = k0 - j * p.conv_cin_pad;
         const int tin = a_tq[i] * p.conv_stride + p.conv_off[j];
@@ -98,128 +149,195 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const int grow = (n0 + row < p.N) ? n0 + row : p.N - 1;
         b_src[i] = p.W + (size_t)grow * p.ldw + slot * 4;
     }
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave) * 64;   // provably wave-uniform LDS base
-    auto dma = [&](int buf, int k0) {
-        float* as = As + buf * (BM * BK);
-        float* bs = Bs + buf * (BN * BK);
-#pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) {
-            if (i < A_ITERS - 1 || wave_u < A_UNITS - (A_ITERS - 1) * 256)   // last pass: waves 0-1 only
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(CONV ? conv_src(i, k0) : a_src[i] + k0),
-                                                 (__attribute__((address_space(3))) void*)(as + (i * 256 + wave_u) * 4),
-                                                 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i)
+    auto dma_piece = [&](int piece, int buf, int k0) {
+        if (piece < A_ITERS) {
+            // the last A pass is half populated: waves 2-3 fetch a (valid) dummy row into the landing zone instead
+            // of being predicated off -- a branch here would split the block the scheduler interleaves
+            float* dst = As + buf * (BM * BK) + (piece * 256 + wave_u) * 4;
+            if (piece == A_ITERS - 1 && A_UNITS % 256 != 0)
+                dst = (wave_u < A_UNITS - (A_ITERS - 1) * 256) ? dst : lds_dummy + (wave_u & 64) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(CONV ? conv_src(piece, k0) : a_src[piece] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else {
+            const int i = piece - A_ITERS;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(bs + (i * 256 + wave_u) * 4),
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * (BN * BK) + (i * 256 + wave_u) * 4),
                                              16, 0, 0);
+        }
+    };
+    auto dma = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) dma_piece(i, buf, k0);
     };
 
-    f32x4 acc[NRB][NCB];
+    // ---- accumulators and fragments --------------------------------------------------------------------------
+    // M32:  acc32[rb*NCB32 + cb] = 32x32 blocks of rows rb*32.. (rb < 4), acc16[c] = 16x16 blocks of rows 128..143
+    // !M32: acc16[r*NCB + c]     = 16x16 blocks of rows r*16..
+    constexpr int N32 = M32 ? 4 * NCB32 : 1;
+    constexpr int N16 = M32 ? NCB : NRB * NCB;
+    f32x16 acc32[N32];
+    f32x4 acc16[N16];
 #pragma unroll
-    for (int r = 0; r < NRB; ++r)
+    for (int i = 0; i < N32; ++i)
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 16; ++q) acc32[i][q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < N16; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Operand order: SWAP puts the weight fragment on the MFMA "A" side, so a lane ends up with four
-    // CONSECUTIVE output columns of one row (one 16-byte store); the transposed output head keeps the
-    // natural order because its stores are contiguous along the token axis instead.
-    constexpr bool SWAP = (EPI != EPI_OUT_T);
-
-    const int nk = p.K / BK;
-
-    // Fragment registers for the two k16 halves of a chunk.  fa0/fb0 feed half 0, fa1/fb1 half 1.
-    f32x4 fa0[NRB], fb0[NCB], fa1[NRB], fb1[NCB];
-    auto read_frags = [&](f32x4 (&fa)[NRB], f32x4 (&fb)[NCB], int buf, int ks) {
+    // one k16 half of a chunk: M32: a = A32[s8*4 + rb] (8) + A16 (1), b = B32[s8*NCB32 + cb] + B16[c]
+    //                         !M32: a = A16[r] (9), b = B16[c]
+    constexpr int FA = M32 ? 9 : NRB;
+    constexpr int FB = M32 ? 2 * NCB32 + NCB : NCB;
+    constexpr int READS = FA + FB;
+    constexpr int MFMAS = M32 ? 32 * NCB32 + 4 * NCB : 4 * NRB * NCB;
+    struct Frag { f32x4 a[FA]; f32x4 b[FB]; };
+    Frag f0, f1;
+    auto read_frags = [&](Frag& f, int buf, int ks) {
         const float* as = As + buf * (BM * BK);
         const float* bs = Bs + buf * (BN * BK) + wave * WN * BK;
-        const int slot = ks * 4 + lg;
+        if constexpr (M32) {
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) fb[c] = *reinterpret_cast<const f32x4*>(bs + lds_off(c * 16 + li, slot));
+            for (int s8 = 0; s8 < 2; ++s8) {
+                const int slot = ks * 4 + s8 * 2 + lg32;
 #pragma unroll
-        for (int r = 0; r < NRB; ++r) fa[r] = *reinterpret_cast<const f32x4*>(as + lds_off(r * 16 + li, slot));
-    };
-    auto mma_half = [&](const f32x4 (&fa)[NRB], const f32x4 (&fb)[NCB]) {
+                for (int cb = 0; cb < NCB32; ++cb)
+                    f.b[s8 * NCB32 + cb] = *reinterpret_cast<const f32x4*>(bs + lds_off(cb * 32 + li32, slot));
 #pragma unroll
-        for (int r = 0; r < NRB; ++r)
+                for (int rb = 0; rb < 4; ++rb)
+                    f.a[s8 * 4 + rb] = *reinterpret_cast<const f32x4*>(as + lds_off(rb * 32 + li32, slot));
+            }
+            const int slot16 = ks * 4 + lg;
+            f.a[8] = *reinterpret_cast<const f32x4*>(as + lds_off(128 + li, slot16));
 #pragma unroll
             for (int c = 0; c < NCB; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (SWAP)
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[c][j], fa[r][j], acc[r][c], 0, 0, 0);
-                    else
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[r][j], fb[c][j], acc[r][c], 0, 0, 0);
-                }
-    };
-
-    // Schedule (one barrier per 32-wide K chunk, placed BETWEEN the chunk's two MFMA halves):
-    //   top of chunk k : issue LDS reads of half 1 (chunk k is already visible)      } latency hidden
-    //   MFMA half 0    : 72 MFMAs on registers read during the previous chunk         } under MFMAs
-    //   vmcnt(0) + barrier : chunk k+1 (DMA issued one chunk ago) is now visible to everyone, and every
-    //                    wave has finished READING chunk k into registers
-    //   issue DMA of chunk k+2 into chunk k's buffer; issue LDS reads of chunk k+1's half 0
-    //   MFMA half 1    : 72 MFMAs
-    // so neither the HBM/L2 latency nor the LDS latency is ever exposed in steady state.
-    // VAR (diagnostic builds, ROHM_GEMM_VARIANT): 0 = shipped; 5 = MFMA only + no epilogue; 6 = no epilogue.
-    dma(0, 0);
-    if (nk > 1) dma(1, BK);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS + B_ITERS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    read_frags(fa0, fb0, 0, 0);
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if constexpr (VAR != 5) read_frags(fa1, fb1, buf, 1);
-        mma_half(fa0, fb0);
-        if constexpr (VAR != 5) {
-            // MFMAs are register-only, so hipcc would otherwise sink them below the barrier (guide rule 18)
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            if (kc + 2 < nk) dma(buf, (kc + 2) * BK);
-            if (kc + 1 < nk) read_frags(fa0, fb0, buf ^ 1, 0);
-            mma_half(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
+                f.b[2 * NCB32 + c] = *reinterpret_cast<const f32x4*>(bs + lds_off(c * 16 + li, slot16));
         } else {
-            mma_half(fa0, fb0);
-        }
-    }
-    if constexpr (VAR == 5 || VAR == 6) {
-        // diagnostics: skip the epilogue unless an impossible value appears (keeps the MFMAs live)
-        if (acc[0][0][0] != 123456.789f) return;
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------------
-    if constexpr (EPI == EPI_OUT_T) {
-        // natural operand order: acc[r][c][q] = C[m = m0 + r*16 + lg*4 + q][n = n0 + wave*WN + c*16 + li];
-        // rows = output channels, cols = tokens; stored transposed into [B, C_total, 1, T]
+            const int slot = ks * 4 + lg;
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            const int n = n0 + wave * WN + c * 16 + li;
-            if (n >= p.N) continue;
-            const int b = n / p.S, tok = n % p.S;
-            if (tok == 0) continue;
-            float* dst = p.C + ((size_t)b * p.C_total + p.ch_off) * p.T + (tok - 1);
+            for (int c = 0; c < NCB; ++c) f.b[c] = *reinterpret_cast<const f32x4*>(bs + lds_off(c * 16 + li, slot));
+#pragma unroll
+            for (int r = 0; r < NRB; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(as + lds_off(r * 16 + li, slot));
+        }
+    };
+    auto mma_half = [&](const Frag& f) {
+        if constexpr (M32) {
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < NCB32; ++cb) {
+                            const float wv = f.b[s8 * NCB32 + cb][j], av = f.a[s8 * 4 + rb][j];
+                            if constexpr (SWAP)
+                                acc32[rb * NCB32 + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc32[rb * NCB32 + cb], 0, 0, 0);
+                            else
+                                acc32[rb * NCB32 + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc32[rb * NCB32 + cb], 0, 0, 0);
+                        }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    const float wv = f.b[2 * NCB32 + c][j], av = f.a[8][j];
+                    if constexpr (SWAP) acc16[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, av, acc16[c], 0, 0, 0);
+                    else acc16[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, acc16[c], 0, 0, 0);
+                }
+        } else {
 #pragma unroll
             for (int r = 0; r < NRB; ++r)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = m0 + r * 16 + lg * 4 + q;
-                    if (m < p.M) dst[(size_t)m * p.T] = acc[r][c][q] + p.bias[m];
-                }
+                for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (SWAP)
+                            acc16[r * NCB + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[c][j], f.a[r][j], acc16[r * NCB + c], 0, 0, 0);
+                        else
+                            acc16[r * NCB + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r][j], f.b[c][j], acc16[r * NCB + c], 0, 0, 0);
+                    }
+        }
+    };
+
+    // ---- main loop -------------------------------------------------------------------------------------------
+    // VAR (diagnostic builds, ROHM_GEMM_VARIANT): 0 = shipped; 5 = MFMA only + no epilogue; 6 = no epilogue;
+    // 7 = shipped schedule + per-workgroup phase timestamps written to p.R (scripts/gemm_timeline.py).
+    const int nk = p.K / BK;
+    dma(0, 0);
+    if (nk > 1) dma(1, BK);
+    // every wave issues exactly PIECES loads per chunk
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (VAR == 7) { ts_wall[1] = wall_clock64(); ts_cyc[0] = __builtin_readcyclecounter(); }
+    read_frags(f0, 0, 0);
+    constexpr int NG = READS;                       // one LDS read per scheduling group
+    constexpr int MF = (MFMAS + NG - 1) / NG;       // MFMAs per group (the tail groups run dry, harmless)
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if constexpr (VAR != 5) {
+            read_frags(f1, buf, 1);
+            mma_half(f0);
+            SchedGroups<0, NG, MF, READS, 0, 0>::run();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // chunk k+1 landed
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            // the last two iterations re-fetch the last chunk (into buffers nobody reads again) instead of being
+            // predicated: the body stays one basic block
+            const int kn = (kc + 2 < nk) ? (kc + 2) * BK : (nk - 1) * BK;
+            dma(buf, kn);
+            read_frags(f0, buf ^ 1, 0);
+            mma_half(f1);
+            SchedGroups<0, NG, MF, READS, PIECES, 1>::run();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            mma_half(f0);
+            mma_half(f0);
+        }
+    }
+    if constexpr (VAR == 7) { ts_wall[2] = wall_clock64(); ts_cyc[1] = __builtin_readcyclecounter(); }
+    if constexpr (VAR == 5 || VAR == 6) {
+        // diagnostics: skip the epilogue unless an impossible value appears (keeps the MFMAs live)
+        if (acc16[0][0] != 123456.789f) return;
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------------
+    const int nw = n0 + wave * WN;
+    if constexpr (EPI == EPI_OUT_T) {
+        // natural operand order: rows = output channels m, cols = tokens n; stored transposed into [B, C_total, 1, T]
+        auto put = [&](int m, int n, float v) {
+            if (m >= p.M || n >= p.N) return;
+            const int b = n / p.S, tok = n % p.S;
+            if (tok == 0) return;
+            p.C[((size_t)b * p.C_total + p.ch_off + m) * p.T + (tok - 1)] = v + p.bias[m];
+        };
+        if constexpr (M32) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB32; ++cb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        put(m0 + rb * 32 + 8 * (q >> 2) + 4 * lg32 + (q & 3), nw + cb * 32 + li32, acc32[rb * NCB32 + cb][q]);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put(m0 + 128 + lg * 4 + q, nw + c * 16 + li, acc16[c][q]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NRB; ++r)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) put(m0 + r * 16 + lg * 4 + q, nw + c * 16 + li, acc16[r * NCB + c][q]);
         }
     } else {
-        // swapped operand order: acc[r][c][q] = C[m = m0 + r*16 + li][n = nb + q], nb = n0 + wave*WN + c*16 + lg*4
-        // FULL: the launcher proved M % 144 == 0, N % BN == 0 and 16-byte alignment of C / R / bias / tables,
-        // so the hot instantiation carries no edge masks and only 16-byte accesses.
+        // swapped operand order: a lane holds C[m][nb .. nb+3].  FULL: the launcher proved M % 144 == 0,
+        // N % BN == 0 and 16-byte alignment of C / R / bias / tables, so the hot instantiation carries no edge
+        // masks and only 16-byte accesses.
         const bool vec_ok = FULL || ((p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0));
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            const int nb = n0 + wave * WN + c * 16 + lg * 4;
-            if (!FULL && nb >= p.N) continue;
+        auto emit = [&](int m, int nb, f32x4 a) {
+            if (!FULL && (m >= p.M || nb >= p.N)) return;
             f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (FULL) {
                 if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
@@ -227,58 +345,86 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bias4[q] = (nb + q < p.N) ? p.bias[nb + q] : 0.f;
             }
+            f32x4 v;
 #pragma unroll
-            for (int r = 0; r < NRB; ++r) {
-                const int m = m0 + r * 16 + li;
-                if (!FULL && m >= p.M) continue;
-                f32x4 v;
+            for (int q = 0; q < 4; ++q) v[q] = a[q] + bias4[q];
+            if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = acc[r][c][q] + bias4[q];
-                if constexpr (EPI == EPI_BIAS_GELU) {
+                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+            }
+            if constexpr (EPI == EPI_BIAS_RES) {
+                const float* rp = p.R + (size_t)m * p.ldr + nb;
+                if (FULL || (vec_ok && (p.ldr % 4 == 0) && (((uintptr_t)p.R & 15) == 0))) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
-                }
-                if constexpr (EPI == EPI_BIAS_RES) {
-                    const float* rp = p.R + (size_t)m * p.ldr + nb;
-                    if (FULL || (vec_ok && (p.ldr % 4 == 0) && (((uintptr_t)p.R & 15) == 0))) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += rr[q];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (nb + q < p.N) v[q] += rp[q];
-                    }
-                }
-                if constexpr (EPI == EPI_QKV) {
-                    if (nb < p.qcols) {      // qcols is a multiple of 4
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] *= p.qscale;
-                    }
-                }
-                if constexpr (EPI == EPI_EMBED) {
-                    const int bidx = m / p.S, tok = m % p.S;
-                    const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb
-                                                 : p.tab + (size_t)tok * p.ldtab + nb;
-                    if constexpr (FULL) {
-                        const f32x4 tt = *reinterpret_cast<const f32x4*>(tp);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : acc[r][c][q]) + tt[q];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : acc[r][c][q]) + tp[q];
-                    }
-                }
-                const size_t crow = CONV ? (size_t)m * (p.orow_mul_m1 + 1) + p.orow_add : (size_t)m;
-                float* cp = p.C + crow * p.ldc + nb;
-                if (vec_ok) {
-                    *reinterpret_cast<f32x4*>(cp) = v;
+                    for (int q = 0; q < 4; ++q) v[q] += rr[q];
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (nb + q < p.N) cp[q] = v[q];
+                        if (nb + q < p.N) v[q] += rp[q];
                 }
             }
+            if constexpr (EPI == EPI_QKV) {
+                if (nb < p.qcols) {      // qcols is a multiple of 4
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= p.qscale;
+                }
+            }
+            if constexpr (EPI == EPI_EMBED) {
+                const int bidx = m / p.S, tok = m % p.S;
+                const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb
+                                             : p.tab + (size_t)tok * p.ldtab + nb;
+                if constexpr (FULL) {
+                    const f32x4 tt = *reinterpret_cast<const f32x4*>(tp);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tt[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tp[q];
+                }
+            }
+            const size_t crow = CONV ? (size_t)m * (p.orow_mul_m1 + 1) + p.orow_add : (size_t)m;
+            float* cp = p.C + crow * p.ldc + nb;
+            if (vec_ok) {
+                *reinterpret_cast<f32x4*>(cp) = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (nb + q < p.N) cp[q] = v[q];
+            }
+        };
+        if constexpr (M32) {
+            // acc32[rb][cb][4q' + r] = C[m0 + rb*32 + li32][nw + cb*32 + 8q' + 4*lg32 + r]
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB32; ++cb)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x16& a = acc32[rb * NCB32 + cb];
+                        emit(m0 + rb * 32 + li32, nw + cb * 32 + 8 * qq + 4 * lg32,
+                             f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]});
+                    }
+            // acc16[c][r] = C[m0 + 128 + li][nw + c*16 + 4*lg + r]
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) emit(m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < NRB; ++r) emit(m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c]);
+        }
+    }
+    if constexpr (VAR == 7) {
+        ts_wall[3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores acknowledged
+        ts_wall[4] = wall_clock64();
+        if (tid == 0) {
+            unsigned long long* ts = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.R)) + (size_t)blockIdx.x * 8;
+            for (int i = 0; i < 5; ++i) ts[i] = ts_wall[i];
+            ts[5] = ts_cyc[1] - ts_cyc[0];
+            ts[6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
+            ts[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
         }
     }
 }
@@ -298,11 +444,13 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     static int lds_pad = -1;
     if (lds_pad < 0) { const char* e = getenv("ROHM_GEMM_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     // One workgroup per CU on purpose: with two co-resident workgroups the hardware hands BOTH freed slots of
-    // a CU to the next tiles, so a 3-tiles-per-CU GEMM (QKV at B = 64) degenerates to 4 + 2 (measured 158 us vs
-    // 128 us); the schedule above already hides LDS / L2 latency without a partner wave.  Requesting more than
-    // half of the 160 KiB LDS pins the residency to one.
+    // a CU to the next tiles, so a 3-tiles-per-CU GEMM degenerates to 4 + 2 (measured 158 us vs 128 us); the
+    // schedule already hides LDS / L2 latency without a partner wave.  Requesting more than half of the
+    // 160 KiB LDS pins the residency to one.
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + lds_pad;
-    if (lds < 84 * 1024) lds = 84 * 1024;
+    lds += 2048;                           // landing zone of the dummy DMA pieces
+    static const bool occ2 = getenv("ROHM_GEMM_OCC2") != nullptr;      // diagnostics: allow two workgroups per CU
+    if (lds < 84 * 1024 && !occ2) lds = 84 * 1024;
     static bool attr_set[64] = {};
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
@@ -313,17 +461,10 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     }
     static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv", "gemm_embed",
                                          "gemm_out_t"};
-    if (CONV) {
-        prof::Scope ps(BN == 128 ? "conv_gemm" : "conv_gemm/64", 2.0 * p.M * p.N * p.K,
-                       4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
-        hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);
-        ROHM_LAUNCH_CHECK();
-        return ROHM_OK;
-    }
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64",
                                            "gemm_embed/64", "gemm_out_t/64"};
-    prof::Scope ps(BN == 128 ? kNames[EPI] : kNames64[EPI], 2.0 * p.M * p.N * p.K,
-                   4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
+    const char* label = CONV ? (BN == 64 ? "conv_gemm/64" : "conv_gemm") : (BN == 64 ? kNames64[EPI] : kNames[EPI]);
+    prof::Scope ps(label, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
     hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
@@ -337,37 +478,64 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
     if (EPI == EPI_BIAS_RES) full = full && (p.ldr % 4 == 0) && al16(p.R);
     if (EPI == EPI_EMBED) full = full && (p.ldtab % 4 == 0) && (p.ldtab0 % 4 == 0) && al16(p.tab) && al16(p.tab0);
     if (EPI == EPI_QKV) full = full && (p.qcols % 4 == 0);
-    if (EPI == EPI_OUT_T || VAR != 0) full = false;
+    if (EPI == EPI_OUT_T || (VAR != 0 && VAR != 7)) full = false;
     if (p.conv_taps > 0) {
-        if constexpr (EPI == EPI_BIAS && VAR == 0) {
+        if constexpr (EPI == EPI_BIAS && VAR == 0 && BN <= 128) {
             return full ? launch_one<BN, EPI, 0, true, true>(p, s) : launch_one<BN, EPI, 0, false, true>(p, s);
         } else {
-            set_error("gemm: conv gather supports the bias epilogue only");
+            set_error("gemm: conv gather supports the bias epilogue and BN <= 128 only");
             return ROHM_ERR_UNSUPPORTED;
         }
     }
     if (full) {
-        if constexpr (EPI != EPI_OUT_T && VAR == 0) return launch_one<BN, EPI, 0, true>(p, s);
+        if constexpr (EPI != EPI_OUT_T && (VAR == 0 || VAR == 7)) return launch_one<BN, EPI, VAR, true>(p, s);
     }
     return launch_one<BN, EPI, VAR, false>(p, s);
 }
 
+// Workgroups a launch should at least produce before a wider tile is preferred: one per CU of the MI355X, or
+// fewer when the caller runs several independent launches side by side (ROHM_GEMM_TARGET_WGS).
+static int target_wgs() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ROHM_GEMM_TARGET_WGS");
+        v = (e && atoi(e) > 0) ? atoi(e) : 256;
+    }
+    return v;
+}
+
 template <int EPI>
 static int launch_bn(const GemmParams& p, hipStream_t s) {
-    // pick the wider tile only when it still yields at least one tile per CU
-    const int tiles128 = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
+    const int tm = (p.M + BM - 1) / BM;
+    const int tiles128 = tm * ((p.N + 127) / 128);
+    const int want = target_wgs();
     const int var = gemm_variant();
     const int force_bn = var / 10;            // diagnostics: 6x -> BN 64, 12x -> BN 128
     if constexpr (EPI == EPI_BIAS) {
         switch (var % 10) {                   // schedule variants exist for the plain epilogue only
             case 5: return force_bn == 6 ? launch_t<64, EPI, 5>(p, s) : launch_t<128, EPI, 5>(p, s);
             case 6: return force_bn == 6 ? launch_t<64, EPI, 6>(p, s) : launch_t<128, EPI, 6>(p, s);
+            case 7:                           // same tile choice as the shipped path
+                if (!p.R) break;
+                if (force_bn == 12) return launch_t<128, EPI, 7>(p, s);
+                if (p.N % 384 == 0 && tm * (p.N / 384) >= want) return launch_t<384, EPI, 7>(p, s);
+                if (p.N % 256 == 0 && tm * (p.N / 256) >= want) return launch_t<256, EPI, 7>(p, s);
+                return launch_t<128, EPI, 7>(p, s);
             default: break;
         }
     }
     if (force_bn == 6) return launch_t<64, EPI>(p, s);
     if (force_bn == 12) return launch_t<128, EPI>(p, s);
-    if (tiles128 >= 256 && p.N % 128 == 0) return launch_t<128, EPI>(p, s);
+    // Widest tile that still gives every CU a tile: wider tiles move fewer LDS-DMA bytes and fragment reads per
+    // MFMA and amortise the per-chunk barrier over more MFMAs.  At B = 64: N = 1536 -> 144x384, N = 1024 ->
+    // 144x256, N = 512 -> 144x128, each exactly 256 tiles.
+    if constexpr (EPI != EPI_OUT_T) {
+        if (p.conv_taps == 0) {
+            if (p.N % 384 == 0 && tm * (p.N / 384) >= want) return launch_t<384, EPI>(p, s);
+            if (p.N % 256 == 0 && tm * (p.N / 256) >= want) return launch_t<256, EPI>(p, s);
+        }
+    }
+    if (tiles128 >= want && p.N % 128 == 0) return launch_t<128, EPI>(p, s);
     return launch_t<64, EPI>(p, s);
 }
 

@@ -17,6 +17,9 @@
 
 namespace rohm {
 
+constexpr int kPadC = 64;      // row width of <=32-channel activations that are GEMM inputs
+constexpr int kPadCtl = 320;   // 272 control channels padded to the 64-wide K chunk
+
 struct ConvW {          // re-laid-out conv weight: [cout, taps * cin_pad] + bias [cout]
     float* w = nullptr;
     float* b = nullptr;
@@ -287,7 +290,7 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += al(n); return p; };
     const size_t M = (size_t)B * T;
-    w.xin = take(M * 32); w.cin = take(M * 32); w.ctl = take(M * 288);
+    w.xin = take(M * kPadC); w.cin = take(M * kPadC); w.ctl = take(M * kPadCtl);
     for (int i = 0; i < 4; ++i) {
         const size_t Mi = M >> i;
         w.cat[i] = take(Mi * 2 * ch[i]);
@@ -296,14 +299,14 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
         if (i < 3) w.cdn[i] = take((Mi / 2) * ch[i]);
         w.ddn[i] = take((Mi / 2) * 2 * ch[i]);
         w.kdn[i] = take((Mi / 2) * 2 * ch[i]);
-        w.d[i] = take(Mi * (i == 0 ? 32 : ch[i - 1]));
+        w.d[i] = take(Mi * (i == 0 ? kPadC : ch[i - 1]));   // d[0]: 32 channels in a 64-wide zero-padded row
         w.ctrl[i] = take(Mi * (i == 0 ? 32 : ch[i - 1]));
     }
     const size_t M16 = M >> 4;
     w.mid_a = take(M16 * m); w.mid_b = take(M16 * m); w.kmid_a = take(M16 * m); w.kmid_b = take(M16 * m);
     w.ctrl_mid = take(M16 * m);
-    w.cz = take(M * 32);
-    w.fin = take(M * 32);
+    w.cz = take(M * kPadC);
+    w.fin = take(M * kPadC);
     w.tb_all = take((size_t)B * h->tb_total);
     w.sc.ya = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
     w.sc.hb = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
@@ -327,7 +330,7 @@ static int run_cond_encoder(const rohm_trajnet* h, const TWs& w, int B, int T, h
     const int ch[4] = {m / 8, m / 4, m / 2, m};
     int rc;
     const float* x = w.cin;
-    int ldx = 32;
+    int ldx = kPadC;
     for (int i = 0; i < 4; ++i) {
         const int Ti = T >> i;
         float* dst = w.cat[i] + ch[i];
@@ -350,9 +353,9 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
     const float* tb = w.tb_all;
     int rc;
     if (h->control) {   // ControlNet.forward, trajnet.py:43-75
-        if ((rc = conv1(h->c_zero0, w.ctl, 288, B * T, w.cz, 32, s))) return rc;   // cols 13..31 stay zero
+        if ((rc = conv1(h->c_zero0, w.ctl, kPadCtl, B * T, w.cz, kPadC, s))) return rc;   // cols 13..63 stay zero
         const float* x = w.cz;
-        int ldx = 32;
+        int ldx = kPadC;
         for (int i = 0; i < 4; ++i) {
             const int Ti = T >> i;
             if ((rc = res_block(h, h->c_enc[i], x, ldx, B, Ti, tb, ldtb, nullptr, 0, w.ccat[i], 2 * ch[i], nullptr, 0,
@@ -372,7 +375,7 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
     }
     // U-Net encoder
     const float* x = w.xin;
-    int ldx = 32;
+    int ldx = kPadC;
     for (int i = 0; i < 4; ++i) {
         const int Ti = T >> i;
         // output goes to the left half of cat[i] (input of the down conv) and to the right half of dcat[i] (skip)
@@ -394,15 +397,16 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
         const int Ti = T >> i, Tq = Ti / 2;
         if ((rc = upsample(h, h->up[i], x, ldx, B, Tq, w.dcat[i], 2 * ch[i], s))) return rc;
         const int co = (i == 0) ? 32 : ch[i - 1];
+        const int ldd = (i == 0) ? kPadC : co;
         if ((rc = res_block(h, h->dec[i], w.dcat[i], 2 * ch[i], B, Ti, tb, ldtb, h->control ? w.ctrl[i] : nullptr, co,
-                            w.d[i], co, nullptr, 0, w.sc, s)))
+                            w.d[i], ldd, nullptr, 0, w.sc, s)))
             return rc;
-        x = w.d[i]; ldx = co;
+        x = w.d[i]; ldx = ldd;
     }
     // head: Conv1dBlock(32, 32, k5) + Conv1d(32, 13, 1)  (trajnet.py:158-161)
-    if ((rc = conv5(h, h->final_blk.conv, w.d[0], 32, B, T, w.sc.ya, 32, s))) return rc;
-    if ((rc = gn(h->final_blk, w.sc.ya, 32, B, T, nullptr, 0, nullptr, 0, nullptr, 0, w.fin, 32, nullptr, 0, s))) return rc;
-    return conv1(h->final_conv, w.fin, 32, B * T, out, h->ctraj, s);
+    if ((rc = conv5(h, h->final_blk.conv, w.d[0], kPadC, B, T, w.sc.ya, 32, s))) return rc;
+    if ((rc = gn(h->final_blk, w.sc.ya, 32, B, T, nullptr, 0, nullptr, 0, nullptr, 0, w.fin, kPadC, nullptr, 0, s))) return rc;
+    return conv1(h->final_conv, w.fin, kPadC, B * T, out, h->ctraj, s);
 }
 
 static int run_time_path(const rohm_trajnet* h, const TWs& w, const int64_t* t_dev, int64_t t_host, int B,
@@ -412,6 +416,15 @@ static int run_time_path(const rohm_trajnet* h, const TWs& w, const int64_t* t_d
     hipLaunchKernelGGL(time_path_kernel, dim3(rows), dim3(256), 0, s, t_dev, t_host, h->tdim, h->t_w1T, h->t_b1, h->t_w3T,
                        h->t_b3, h->tb_wT, h->tb_b, h->tb_total, w.tb_all);
     ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+// 32-channel activations that feed a GEMM live in 64-wide rows (K chunks are 64 wide); their pad columns are
+// never written by the producers, so they are cleared once per call.
+static int zero_pads(const rohm_trajnet* h, const TWs& w, size_t M, hipStream_t s) {
+    ROHM_HIP_CHECK(hipMemsetAsync(w.d[0], 0, M * kPadC * sizeof(float), s));
+    ROHM_HIP_CHECK(hipMemsetAsync(w.fin, 0, M * kPadC * sizeof(float), s));
+    if (h->control) ROHM_HIP_CHECK(hipMemsetAsync(w.cz, 0, M * kPadC * sizeof(float), s));
     return ROHM_OK;
 }
 
@@ -434,7 +447,7 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
     ROHM_ARG_CHECK(out && wts && wts->tensors, "trajnet_create: null argument");
     ROHM_ARG_CHECK(mid_dim >= 256 && mid_dim % 256 == 0, "trajnet_create: mid_dim must be a multiple of 256");
     ROHM_ARG_CHECK(time_dim == 32, "trajnet_create: time_dim must be 32");
-    ROHM_ARG_CHECK(c_traj > 0 && c_traj <= 32 && c_ctrl > 0 && c_ctrl <= 288, "trajnet_create: bad channel counts");
+    ROHM_ARG_CHECK(c_traj > 0 && c_traj <= 32 && c_ctrl > 0 && c_ctrl <= kPadCtl, "trajnet_create: bad channel counts");
     ROHM_HIP_CHECK(hipSetDevice(device));
     rohm_trajnet* h = new rohm_trajnet();
     h->mid = mid_dim; h->tdim = time_dim; h->ctraj = c_traj; h->cctrl = c_ctrl; h->control = trajcontrol ? 1 : 0;
@@ -469,7 +482,7 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
         if (hipMemcpy(d, src, n * sizeof(float), hipMemcpyDefault) != hipSuccess) { ok = false; err = "hipMemcpy failed"; }
         return d;
     };
-    auto pad32 = [](int c) { return (c + 31) / 32 * 32; };
+    auto pad32 = [](int c) { return (c + 63) / 64 * 64; };   // GEMM K chunks are 64 wide
     // conv: weight [cout, cin, k] (or [cin, cout, k] when transposed) + bias [cout]
     auto load_conv = [&](ConvW& c, int cout, int cin, int k, int tap0, int tap_step, int ntap, bool transposed,
                          const float* wsrc, const float* bsrc) {
@@ -650,11 +663,11 @@ int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float*
         return ROHM_ERR_WORKSPACE;
     }
     const size_t M = (size_t)B * T;
-    if ((rc = pad_rows(x_t, w.xin, M, h->ctraj, 32, s))) return rc;
-    if ((rc = pad_rows(cond, w.cin, M, h->ctraj, 32, s))) return rc;
+    if ((rc = pad_rows(x_t, w.xin, M, h->ctraj, kPadC, s))) return rc;
+    if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;
+    if ((rc = zero_pads(h, w, M, s))) return rc;
     if (h->control) {
-        if ((rc = pad_rows(control_cond, w.ctl, M, h->cctrl, 288, s))) return rc;
-        ROHM_HIP_CHECK(hipMemsetAsync(w.cz, 0, M * 32 * sizeof(float), s));
+        if ((rc = pad_rows(control_cond, w.ctl, M, h->cctrl, kPadCtl, s))) return rc;
     }
     if ((rc = run_time_path(h, w, t, 0, B, s))) return rc;
     if ((rc = run_cond_encoder(h, w, B, T, s))) return rc;
@@ -677,17 +690,17 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
     }
     const size_t M = (size_t)B * T, n = M * h->ctraj;
     // cond / control_cond do not change over the loop: pad them and run the (time-free) cond encoder once
-    if ((rc = pad_rows(cond, w.cin, M, h->ctraj, 32, s))) return rc;
+    if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;
+    if ((rc = zero_pads(h, w, M, s))) return rc;
     if (h->control) {
-        if ((rc = pad_rows(control_cond, w.ctl, M, h->cctrl, 288, s))) return rc;
-        ROHM_HIP_CHECK(hipMemsetAsync(w.cz, 0, M * 32 * sizeof(float), s));
+        if ((rc = pad_rows(control_cond, w.ctl, M, h->cctrl, kPadCtl, s))) return rc;
     }
     if ((rc = run_cond_encoder(h, w, B, T, s))) return rc;
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
         ROHM_ARG_CHECK(sigma == 0.f || noise, "trajnet_sample_loop: noise is required when sigma != 0");
-        if ((rc = pad_rows(x, w.xin, M, h->ctraj, 32, s))) return rc;
+        if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;
         if ((rc = run_time_path(h, w, nullptr, t_model[i], B, s))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
         if ((rc = run_denoiser(h, w, B, T, 0, x0, s))) return rc;

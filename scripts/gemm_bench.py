@@ -22,6 +22,8 @@ def main():
     for name, M, N, K in SHAPES:
         a = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) / K ** 0.5
+        if os.environ.get('GEMM_ZERO'):
+            a.zero_(); w.zero_()      # DVFS probe: same instruction stream, no toggling data
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev)
         for _ in range(5):

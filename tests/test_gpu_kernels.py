@@ -15,7 +15,7 @@ def _dev():
 
 
 @pytest.mark.parametrize('M,N,K', [(144, 512, 512), (288, 1536, 512), (144 * 3, 512, 1024), (100, 70, 64),
-                                   (272, 288, 512), (1, 16, 32), (144 * 64, 512, 512)])
+                                   (272, 288, 512), (1, 16, 64), (144 * 64, 512, 512)])
 @pytest.mark.parametrize('epi', [0, 1, 2])
 def test_gemm(M, N, K, epi):
     from rohm_amd import ops
@@ -35,8 +35,8 @@ def test_gemm(M, N, K, epi):
 def test_gemm_identity_asymmetric():
     from rohm_amd import ops
     d = _dev()
-    a = torch.eye(144, 160)[:, :160].contiguous()
-    w = torch.arange(96 * 160, dtype=torch.float32).reshape(96, 160) / 100.0
+    a = torch.eye(144, 192).contiguous()
+    w = torch.arange(96 * 192, dtype=torch.float32).reshape(96, 192) / 100.0
     out = ops.gemm(a.to(d), w.to(d))
     assert torch.equal(out.cpu(), w[:, :144].T.contiguous())
 
