@@ -64,7 +64,7 @@ int rohm_profile_stop(rohm_profile_row* rows, int max_rows, int* n_rows);
 /* C[M,N] = epi(A[M,K] . W[N,K]^T): the fp32-MFMA GEMM every Linear of the path runs
  * on (nn.Linear in model/heads.py:154,169, nn.TransformerEncoderLayer in
  * model/posenet.py:63-69).  A, W row-major with K contiguous (lda/ldw in floats,
- * multiples of 4, 16-byte aligned); K a multiple of 64; M, N arbitrary.
+ * multiples of 4, 16-byte aligned); K a multiple of 32; M, N arbitrary.
  * epi: 0 = +bias, 1 = +bias, exact-erf GELU, 2 = +bias +R[M,N](ldr).
  * bias may be NULL. */
 int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N,
