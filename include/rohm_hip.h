@@ -222,6 +222,28 @@ int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const floa
                               const float* focal, const float* center, const float* kp2d, int kp_frames, int B,
                               int T, float* grad_out, void* ws, size_t ws_bytes, rohm_stream_t stream);
 
+/* recover_from_repr_smpl (data_loaders/motion_representation.py:332-398) straight from the 294-channel
+ * representation: joints [B,T,22,3].  mode 0 = 'smplx_params' (:373-398, joints[:, 0:22] of the body model incl.
+ * transl; h required), mode 1 = 'joint_abs_traj' (:349-371; h may be NULL).  repr is addressed with strides as in
+ * rohm_traj_rederive; mean294/std294 de-normalise on the fly (both NULL = repr is already de-normalised). */
+int rohm_repr_joints(const rohm_smplx_t* h, const float* repr, long long in_stride_b, long long in_stride_t,
+                     long long in_stride_c, const float* mean294, const float* std294, int B, int T, int mode,
+                     float* joints, rohm_stream_t stream);
+
+/* Between-stage trajectory re-derivation: replaces the drivers' host round trip
+ * test_amass_full.py:262-311 / test_prox_egobody.py:238-287 -- de-normalise TrajNet's representation,
+ * recover_from_repr_smpl('smplx_params') (data_loaders/motion_representation.py:373-398), per-sequence
+ * get_repr_smplx (:187-282), re-normalise, keep the 22 trajectory channels.
+ * repr: element (b, t, c) at repr[b*in_stride_b + t*in_stride_t + c*in_stride_c] (floats), c < 294, t < T, normalised
+ * with (mean_in, std_in); out: element (b, t, c), t < T-1, c < 22, at out[b*out_stride_b + t*out_stride_t +
+ * c*out_stride_c], normalised with (mean_out, std_out) -- so the result can be written straight into channels 0..21
+ * of PoseNet's `cond` in either layout.  2 <= T <= 800.  Degenerate facing directions reproduce the reference's NaN
+ * handling (only the first NaN frame of a clip is patched with its predecessor, :212-215). */
+int rohm_traj_rederive(const rohm_smplx_t* h, const float* repr, long long in_stride_b, long long in_stride_t,
+                       long long in_stride_c, const float* mean_in, const float* std_in, const float* mean_out,
+                       const float* std_out, int B, int T, float* out, long long out_stride_b,
+                       long long out_stride_t, long long out_stride_c, rohm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,50 @@ class _Args:
     sigma_small = True
 
 
+def golden_rederive(ref):
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    # ---- between-stage trajectory re-derivation: the reference's driver lines ----------
+    mr = ref.motion_repr
+    mean_in, std_in = synth.synthetic_stats(0)
+    mean_out, std_out = synth.synthetic_stats(1)
+    rn = synth.plausible_motion(5, 2, 144, mean_in, std_in)[:, :, 0].permute(0, 2, 1).contiguous()   # [2,144,294]
+    den = rn.numpy() * std_in + mean_in
+    dd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in G.split_repr(den).items()}
+    jts, _ = mr.recover_from_repr_smpl(dd, recover_mode='smplx_params', smplx_model=body, return_verts=True)
+    jts = jts.detach().cpu().numpy()
+    full_list = []
+    for i in range(len(jts)):
+        g_aa = ref.konia.rotation_matrix_to_angle_axis(ref.quaternion.rot6d_to_rotmat(dd['smplx_rot_6d'][i]))
+        b_aa = ref.konia.rotation_matrix_to_angle_axis(
+            ref.quaternion.rot6d_to_rotmat(dd['smplx_body_pose_6d'][i].reshape(-1, 6))).reshape(-1, 21, 3)
+        prm = {'transl': dd['smplx_trans'][i].numpy(), 'global_orient': g_aa.numpy(),
+               'body_pose': b_aa.reshape(-1, 63).numpy(), 'betas': dd['smplx_betas'][i].numpy()}
+        rd = mr.get_repr_smplx(positions=jts[i], smplx_params_dict=prm, feet_vel_thre=5e-5)
+        full = np.concatenate([rd[k] for k in ref.other_utils.REPR_LIST], axis=-1)
+        full_list.append((full - mean_out) / std_out)
+    full_ref = np.asarray(full_list)                                   # float64 [2,143,294]
+    # degenerate frames: hips/shoulders stacked along z -> zero forward -> NaN quaternion; the reference patches
+    # only the first such frame (motion_representation.py:213-215)
+    gq = np.random.Generator(np.random.PCG64(77))
+    pos_nan = gq.standard_normal((12, 22, 3)).astype(np.float32)
+    for k in (5, 9):
+        pos_nan[k, [1, 16]] = pos_nan[k, [2, 17]] + np.array([0, 0, 0.3], np.float32)
+    prm_nan = {'transl': gq.standard_normal((12, 3)).astype(np.float32),
+               'global_orient': (gq.standard_normal((12, 3)) * 0.5).astype(np.float32),
+               'body_pose': (gq.standard_normal((12, 63)) * 0.3).astype(np.float32),
+               'betas': gq.standard_normal((12, 10)).astype(np.float32)}
+    rd = mr.get_repr_smplx(positions=pos_nan, smplx_params_dict=prm_nan, feet_vel_thre=5e-5)
+    full_nan = np.concatenate([rd[k] for k in ref.other_utils.REPR_LIST], axis=-1)
+    np.savez_compressed(os.path.join(OUT, 'rederive.npz'), body_seed=0, stats_in_seed=0, stats_out_seed=1, motion_seed=5,
+                        joints=jts, full_ref=full_ref, pos_nan=pos_nan, full_nan=full_nan,
+                        **{'nan_' + k: v for k, v in prm_nan.items()})
+
+
 def main():
+    if sys.argv[1:] == ['rederive']:
+        warnings.filterwarnings('ignore')
+        return golden_rederive(refload.load())
     warnings.filterwarnings('ignore')
     os.makedirs(OUT, exist_ok=True)
     ref = refload.load()
@@ -121,6 +164,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'guidance.npz'), body_seed=0, stats_seed=0, motion_seed=3, cam_seed=0,
                         j_abs=j_abs.numpy(), j_smpl=j_smpl.numpy(), g_skating=g_sk.numpy(), g_2d=g_2d.numpy(),
                         r6_seed=301, rotmat=Rm.numpy(), angle_axis=aa.numpy())
+    golden_rederive(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -93,6 +93,11 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_guidance_proj2d_grad': (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_size_t, C.c_void_p]),
+    'rohm_repr_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'rohm_traj_rederive': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong] +
+                           [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong,
+                                               C.c_void_p]),
 }
 
 
