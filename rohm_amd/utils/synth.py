@@ -244,6 +244,41 @@ def plausible_motion(seed, B, T, mean, std, angle_scale=0.4, trans_z=3.0):
     return torch.from_numpy(x.astype(np.float32)).permute(0, 2, 1).unsqueeze(2).contiguous()
 
 
+def walking_motion(seed, B, T, mean, std, body_tensors, yaw_range=0.6, pose_scale=0.12):
+    """Normalised [B, T, 294] clips of a SMOOTH motion whose facing direction is well conditioned: the global
+    orientation is a slow yaw (|yaw| <= `yaw_range` rad) on top of the rotation that turns the rest body's
+    hip+shoulder axis onto +x (so `get_repr_smplx`'s forward direction stays near +y, away from the -y
+    singularity of its quaternion, motion_representation.py:199-211), joint angles are slow sinusoids of
+    ~`pose_scale` rad, the root drifts ~1 m.  For driver-level (multi-stage) parity tests, where a frame with an
+    ill-conditioned facing direction would dominate the comparison."""
+    g = _rng(seed)
+    jr = body_tensors['J_regressor'].double().numpy() @ body_tensors['v_template'].double().numpy()
+    a = (jr[1] - jr[2]) + (jr[17] - jr[16])
+    a /= np.linalg.norm(a)
+    ax = np.cross(a, [1.0, 0.0, 0.0])
+    sn, cs = np.linalg.norm(ax), float(a[0])
+    R0 = _rodrigues_np((ax / max(sn, 1e-12) * np.arctan2(sn, cs))[None])[0]
+    tt = np.linspace(0.0, 1.0, T)[None, :]
+    full = (g.standard_normal((B, T, 294)) * 0.05).astype(np.float32)
+
+    def slow(shape_tail, amp):
+        # a couple of low-frequency sinusoids with random phase per clip / component
+        f = g.uniform(0.3, 1.5, size=(B, 1) + shape_tail)
+        ph = g.uniform(0, 2 * np.pi, size=(B, 1) + shape_tail)
+        return amp * np.sin(2 * np.pi * f * tt.reshape((1, T) + (1,) * len(shape_tail)) + ph)
+    yaw = slow((), yaw_range)                                               # [B, T]
+    Rz = np.zeros((B, T, 3, 3))
+    Rz[..., 0, 0], Rz[..., 0, 1], Rz[..., 1, 0], Rz[..., 1, 1], Rz[..., 2, 2] = np.cos(yaw), -np.sin(yaw), np.sin(yaw), np.cos(yaw), 1.0
+    Rg = Rz @ R0
+    full[..., 7:13] = Rg[..., :, :2].reshape(B, T, 6).astype(np.float32)
+    Rb = _rodrigues_np(slow((21, 3), pose_scale).reshape(-1, 3))
+    full[..., 154:280] = Rb[:, :, :2].reshape(B, T, 126).astype(np.float32)
+    full[..., 16:19] = np.stack([slow((), 0.5), slow((), 0.5), 0.1 * slow((), 1.0)], -1).astype(np.float32)
+    full[..., 280:290] = (g.standard_normal((B, 1, 10)) * 0.3).astype(np.float32)
+    full[..., 290:294] = (g.uniform(size=(B, T, 4)) > 0.5).astype(np.float32) * 0.9 + 0.05
+    return torch.from_numpy(((full - mean) / std).astype(np.float32))
+
+
 def synthetic_camera_batch(seed, B, frames=145):
     """PROX-like guidance inputs (SURVEY.md §8d cfg 4): Kinect-colour intrinsics
     (utils/get_occlusion_mask.py:64-68), rigid cano->scene transforms, OpenPose-style keypoints."""
