@@ -244,6 +244,21 @@ int rohm_traj_rederive(const rohm_smplx_t* h, const float* repr, long long in_st
                        const float* std_out, int B, int T, float* out, long long out_stride_b,
                        long long out_stride_t, long long out_stride_c, rohm_stream_t stream);
 
+/* AMASS evaluation metrics (eval_amass_full.py:67-147) as per-clip partial sums.  joints_clean / joints_rec
+ * [B,T,22,3]; contact_* point at the 4 contact channels of the de-normalised clean / reconstructed representation
+ * of frame (b, t) = contact[(b*T + t)*stride + k].  A (frame, joint) counts as occluded if bit `joint` of
+ * occ_joint_mask is set (mask_scheme 'lower': joints 1,2,4,5,7,8,10,11, :76) or occ_start <= frame < occ_end
+ * ('full': [65, 65 + int(ratio*145)), :84-87).  out [B,10] doubles:
+ *   0 sum |clean - rec| over T*22        1 the same over occluded entries      2 number of occluded entries
+ *   3 matching contact labels (of T*4)   4 skating frames, clean (of T-1)      5 skating frames, rec
+ *   6 sum |accel_rec - accel_clean| over (T-2)*22    7 toe entries below -0.05 m (of T*2)
+ *   8 sum of negative toe heights        9 min height of the clean clip (the ground reference, :105)
+ * The script's numbers are sums over clips divided by the counts in brackets. */
+int rohm_amass_metrics(const float* joints_clean, const float* joints_rec, const float* contact_clean,
+                       long long contact_clean_stride, const float* contact_rec, long long contact_rec_stride,
+                       unsigned occ_joint_mask, int occ_start, int occ_end, int B, int T, double* out,
+                       rohm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

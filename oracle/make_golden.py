@@ -79,7 +79,34 @@ def golden_rederive(ref):
                         **{'nan_' + k: v for k, v in prm_nan.items()})
 
 
+def golden_metrics():
+    """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
+    results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
+    import textwrap
+    import types
+    from oracle import metrics as M
+    src = open(os.path.join(refload.REF_ROOT, 'eval_amass_full.py')).read().split('\n')
+    block = textwrap.dedent('\n'.join(src[66:148]))
+    out = {}
+    for scheme, ratio in (('lower', 0.0), ('full', 0.1)):
+        clean, rec, r_clean, r_rec = M.synthetic_results(5)
+        ns = {'np': np, 'args': types.SimpleNamespace(mask_scheme=scheme, traj_mask_ratio=ratio),
+              'rec_ric_data_clean_list': clean, 'rec_ric_data_rec_list_from_smpl': rec,
+              'motion_repr_rec_list': r_rec.copy(), 'motion_repr_clean_list': r_clean.copy(), 'print': lambda *a, **k: None}
+        exec(compile(block, 'eval_amass_full.py[67:148]', 'exec'), ns)
+        vals = {'mpjpe_global': np.mean(ns['joints_mpjpe_global']), 'mpjpe_global_vis': np.mean(ns['joints_mpjpe_global_vis']),
+                'mpjpe_global_occ': np.mean(ns['joints_mpjpe_global_invis']), 'contact_lbl_acc': np.mean(ns['contact_lbl_acc']),
+                'skating_gt_ratio': ns['skating_gt_ratio'], 'skating_rec_ratio': ns['skating_rec_ratio'],
+                'accel_error': ns['acc_error'], 'ground_pene_freq': ns['pene_freq'], 'ground_pene_dist': ns['pene_dist']}
+        for k, v in vals.items():
+            out[f'{scheme}_{k}'] = np.float64(v)
+    np.savez_compressed(os.path.join(OUT, 'metrics.npz'), results_seed=5, **out)
+    print({k: float(v) for k, v in out.items()})
+
+
 def main():
+    if sys.argv[1:] == ['metrics']:
+        return golden_metrics()
     if sys.argv[1:] == ['rederive']:
         warnings.filterwarnings('ignore')
         return golden_rederive(refload.load())
@@ -165,6 +192,7 @@ def main():
                         j_abs=j_abs.numpy(), j_smpl=j_smpl.numpy(), g_skating=g_sk.numpy(), g_2d=g_2d.numpy(),
                         r6_seed=301, rotmat=Rm.numpy(), angle_axis=aa.numpy())
     golden_rederive(ref)
+    golden_metrics()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -95,6 +95,8 @@ SIGNATURES = {
                                             C.c_size_t, C.c_void_p]),
     'rohm_repr_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'rohm_amass_metrics': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_uint,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rohm_traj_rederive': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong] +
                            [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong,
                                                C.c_void_p]),

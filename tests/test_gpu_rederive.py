@@ -125,3 +125,18 @@ def test_rederive_rejects_cpu_and_bad_shapes():
         rederive_traj(torch.zeros(1, 144, 100, device=DEV), s, s, _layer())
     with pytest.raises(ValueError):
         rederive_traj(torch.zeros(1, 144, 294, device=DEV), s, s, _layer(), out=torch.zeros(1, 144, 294, device=DEV))
+
+
+@pytest.mark.parametrize('scheme,ratio', [('lower', 0.0), ('full', 0.1)])
+def test_amass_metrics_vs_reference_golden(scheme, ratio):
+    """Device evaluation metrics against what the reference's own statements computed (tests/golden/metrics.npz)."""
+    from oracle import metrics as M
+    from rohm_amd.evaluation import amass_metrics
+    g = golden('metrics.npz')
+    clean, rec, r_clean, r_rec = (torch.from_numpy(a).to(DEV) for a in M.synthetic_results(int(g['results_seed'])))
+    out = amass_metrics(clean, rec, r_clean, r_rec, scheme, ratio)
+    unit = {'mpjpe_global': 1000., 'mpjpe_global_vis': 1000., 'mpjpe_global_occ': 1000., 'ground_pene_freq': 100.,
+            'ground_pene_dist': 1000.}
+    for k, v in out.items():
+        ref = float(g[f'{scheme}_{k}']) * unit.get(k, 1.0)
+        assert abs(v - ref) <= 2e-6 * max(1.0, abs(ref)), (k, v, ref)
