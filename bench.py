@@ -120,6 +120,114 @@ def cpu_baseline(batch=8, budget_s=12.0):
             'torch_threads': torch.get_num_threads()}
 
 
+class _TrajDataset(_Dataset):
+    traj_feat_dim = 13
+
+
+def scheme_bench(args, world, rank, dev, dist):
+    """SURVEY.md §8(d) cfg 3: the drivers' whole inference-iteration loop (rohm_amd.inference), per GPU batch B."""
+    import types
+    from rohm_amd import _lib, sharding
+    from rohm_amd.body_model import SMPLXLayer
+    from rohm_amd.diffusion import gaussian_diffusion_posenet as gdp
+    from rohm_amd.diffusion import gaussian_diffusion_trajnet as gdt
+    from rohm_amd.diffusion.respace import SpacedDiffusionPoseNet, SpacedDiffusionTrajNet
+    from rohm_amd.inference import run_amass_iterations
+    from rohm_amd.model.posenet import PoseNet
+    from rohm_amd.model.trajnet import TrajNet
+    from rohm_amd.utils import synth
+    from rohm_amd.utils.model_util import create_gaussian_diffusion
+    B, S = args.batch, args.ddpm_steps
+    body_t = synth.synthetic_smplx_tensors(0)
+    layer = SMPLXLayer.from_tensors(body_t).to(dev)
+    s_traj, s_pose = synth.synthetic_stats(0), synth.synthetic_stats(1)
+    tds, pds = _TrajDataset(), _Dataset()
+    tds.Mean, tds.Std = s_traj
+    pds.Mean, pds.Std = s_pose
+    pnet = PoseNet(pds, 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                   body_model_path=layer, device=dev)
+    pnet.load_state_dict(synth.posenet_state_dict(0), strict=False)
+    pnet = pnet.to(dev).eval()
+    nets = {'posenet': pnet}
+    for name, ctrl in (('trajnet', False), ('trajnet_control', True)):
+        n = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=ctrl, device=dev)
+        n.load_state_dict(synth.trajnet_state_dict(1 + ctrl, trajcontrol=ctrl), strict=True)
+        nets[name] = n.to(dev).eval()
+    diffs = {'posenet': create_gaussian_diffusion(_Args, gdp, SpacedDiffusionPoseNet, S, '', device=dev),
+             'trajnet': create_gaussian_diffusion(_Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev),
+             'trajnet_control': create_gaussian_diffusion(_Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev)}
+    sargs = types.SimpleNamespace(sample_iter=2, repr_abs_only=True, infill_traj=False, traj_mask_ratio=0.1,
+                                  mask_scheme='lower', input_noise=True, iter2_cond_noisy_traj=True,
+                                  iter2_cond_noisy_pose=True, early_stop=False, cond_fn_with_grad=True,
+                                  timestep_respacing_eval='')
+    abs_ch = [0, 2, 3, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18]
+    clean_t = synth.walking_motion(1000 + rank, B, 144, *s_traj, body_t).to(dev)
+    clean_p = synth.walking_motion(1000 + rank, B, 144, *s_pose, body_t).to(dev)
+    torch.manual_seed(rank)
+    noisy_t, noisy_p = clean_t + 0.05 * torch.randn_like(clean_t), clean_p + 0.05 * torch.randn_like(clean_p)
+
+    def batches():
+        bt = {'cond': noisy_t[:, :, abs_ch].contiguous(), 'motion_repr_clean': clean_t.clone(),
+              'motion_repr_noisy': noisy_t.clone()}
+        bp = {'motion_repr_clean': clean_p.clone(), 'motion_repr_noisy': noisy_p.clone()}
+        return bt, bp
+
+    def one_pass():
+        bt, bp = batches()
+        pose, _, _ = run_amass_iterations(sargs, nets, diffs, bt, bp, tds, pds, layer)
+        if world > 1:
+            sharding.gather_clips(pose, world * B)
+        return pose
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        one_pass()
+    sync()
+    _lib.profile_start(args.profile_stride)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(out).all())
+    if rank == 0:
+        clips = world * B * args.steps
+        all_ms = sum(v['total_ms'] for v in prof.values())
+        gemm = {k: v for k, v in prof.items() if k.startswith('gemm_') or k.startswith('conv_gemm')}
+        g_ms, g_fl = sum(v['total_ms'] for v in gemm.values()), sum(v['flops'] for v in gemm.values())
+        g_n = sum(v['launches'] for v in gemm.values())
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else None
+        kernels = {k: {'launches': v['launches'], 'avg_us': round(v['total_ms'] / v['launches'] * 1e3, 2),
+                       'time_share': round(v['total_ms'] / all_ms, 4)}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
+        rec = {'metric': f'denoised 145-frame clips/sec, full 2-iteration RoHM scheme (TrajNet 100 + PoseNet {S} '
+                         f'+ TrajControl 100 + PoseNet {S} steps, skating guidance on t<=50)',
+               'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'full scheme [BASELINE.json configs[2] / SURVEY cfg 3], batch={B} clips per GPU, '
+                                      f'sample_iter=2, mask_scheme=lower, guidance weights as the reference (3e6)',
+                          'clips_per_gpu': B, 'ddpm_steps': S, 'finite_output': finite,
+                          'sharding': f'{world} x {B} independent clips' if world > 1 else 'single GPU'},
+               'roofline': {'kernel': 'gemm_f32_kernel (all fp32-MFMA GEMM / conv-GEMM launches, sampled)', 'bound': 'mfma',
+                            'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': None,
+                            'launches_timed': g_n, 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
+                            'kernels': kernels}}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -128,6 +236,10 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--ddpm-steps', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['posenet', 'scheme'], default='posenet',
+                    help="'posenet' = BASELINE.json configs[1] (the headline metric); 'scheme' = configs[2]: the full "
+                         "two-iteration RoHM scheme per clip (TrajNet 100 -> PoseNet 1000 + skating guidance -> "
+                         "TrajControl 100 -> PoseNet 1000 + skating guidance), extra measurement, not the headline")
     ap.add_argument('--profile-stride', type=int, default=16)
     args = ap.parse_args()
 
@@ -152,6 +264,8 @@ def main():
     from rohm_amd.utils.model_util import create_gaussian_diffusion
 
     B, S = args.batch, args.ddpm_steps
+    if args.workload == 'scheme':
+        return scheme_bench(args, world, rank, dev, dist)
     net = PoseNet(_Dataset(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
                   body_model_path=torch.nn.Identity(), device=dev)
     net.load_state_dict(synth.posenet_state_dict(0), strict=True)

@@ -97,6 +97,10 @@ struct GemmParams {
     int conv_off[5];
     const float* zero_page;      // >= 128 B of zeros (source of padded taps)
     int orow_mul_m1, orow_add;
+    // ---- split-K (few-tile, long-K problems: TrajNet's deep levels): workgroup (tile, split) accumulates the K
+    // chunks of its split and stores the raw partial tile to partial[split][m][n] (row stride ld_partial); a second
+    // kernel sums the splits in a fixed order, adds the bias and writes C.  ksplit <= 1: off.  EPI_BIAS only.
+    int ksplit; float* partial; int ld_partial;
 };
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);

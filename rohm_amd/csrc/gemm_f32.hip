@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     if constexpr (VAR == 7) ts_wall[0] = wall_clock64();
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
+    const int split = (ksplit > 1) ? (int)(blockIdx.x % ksplit) : 0;
+    const int tile = xcd_remap(ksplit > 1 ? blockIdx.x / ksplit : blockIdx.x, tiles_m * tiles_n);
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
 
@@ -261,9 +263,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // ---- main loop -------------------------------------------------------------------------------------------
     // VAR (diagnostic builds, ROHM_GEMM_VARIANT): 0 = shipped; 5 = MFMA only + no epilogue; 6 = no epilogue;
     // 7 = shipped schedule + per-workgroup phase timestamps written to p.R (scripts/gemm_timeline.py).
-    const int nk = p.K / BK;
-    dma(0, 0);
-    if (nk > 1) dma(1, BK);
+    // split-K: this workgroup owns chunks [kc0, kc0 + nk) of the K / BK chunks (the first K/BK % ksplit splits
+    // take one more)
+    const int nk_all = p.K / BK;
+    const int nk = nk_all / ksplit + (split < nk_all % ksplit ? 1 : 0);
+    const int kc0 = split * (nk_all / ksplit) + (split < nk_all % ksplit ? split : nk_all % ksplit);
+    const int kbase = kc0 * BK;
+    dma(0, kbase);
+    if (nk > 1) dma(1, kbase + BK);
     // every wave issues exactly PIECES loads per chunk
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
             // the last two iterations re-fetch the last chunk (into buffers nobody reads again) instead of being
             // predicated: the body stays one basic block
-            const int kn = (kc + 2 < nk) ? (kc + 2) * BK : (nk - 1) * BK;
+            const int kn = kbase + ((kc + 2 < nk) ? (kc + 2) * BK : (nk - 1) * BK);
             dma(buf, kn);
             read_frags(f0, buf ^ 1, 0);
             mma_half(f1);
@@ -338,6 +345,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const bool vec_ok = FULL || ((p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0));
         auto emit = [&](int m, int nb, f32x4 a) {
             if (!FULL && (m >= p.M || nb >= p.N)) return;
+            if constexpr (EPI == EPI_BIAS) {
+                if (ksplit > 1) {      // raw partial tile; ld_partial is a multiple of 4 and covers N rounded up
+                    *reinterpret_cast<f32x4*>(p.partial + ((size_t)split * p.M + m) * p.ld_partial + nb) = a;
+                    return;
+                }
+            }
             f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (FULL) {
                 if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
@@ -429,6 +442,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
+// Second pass of a split-K GEMM: C[crow(m)][n] = bias[n] + sum_s partial[s][m][n], splits added in index order
+// (deterministic).  One thread per 4 columns.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                            int ldp, const float* __restrict__ bias, float* __restrict__ C,
+                                                            int ldc, int orow_mul_m1, int orow_add) {
+    const int n4 = (N + 3) / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * n4) return;
+    const int m = (int)(idx / n4), nb = (int)(idx % n4) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(partial + (size_t)m * ldp + nb);
+    for (int s = 1; s < S; ++s) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + ((size_t)s * M + m) * ldp + nb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += v[q];
+    }
+    float* cp = C + ((size_t)m * (orow_mul_m1 + 1) + orow_add) * ldc + nb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (nb + q < N) cp[q] = acc[q] + (bias ? bias[nb + q] : 0.f);
+}
+
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -440,7 +474,8 @@ static int gemm_variant() {
 
 template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 static int launch_one(const GemmParams& p, hipStream_t s) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * ksplit;
     static int lds_pad = -1;
     if (lds_pad < 0) { const char* e = getenv("ROHM_GEMM_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     // One workgroup per CU on purpose: with two co-resident workgroups the hardware hands BOTH freed slots of
@@ -464,9 +499,18 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64",
                                            "gemm_embed/64", "gemm_out_t/64"};
     const char* label = CONV ? (BN == 64 ? "conv_gemm/64" : "conv_gemm") : (BN == 64 ? kNames64[EPI] : kNames[EPI]);
+    {
     prof::Scope ps(label, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
     hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);
     ROHM_LAUNCH_CHECK();
+    }
+    if (ksplit > 1) {
+        prof::Scope pr("splitk_reduce", 0.0, 4.0 * ((double)ksplit + 1.0) * p.M * p.N, s);
+        const long n = (long)p.M * ((p.N + 3) / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.partial, ksplit, p.M,
+                           p.N, p.ld_partial, p.bias, p.C, p.ldc, CONV ? p.orow_mul_m1 : 0, CONV ? p.orow_add : 0);
+        ROHM_LAUNCH_CHECK();
+    }
     return ROHM_OK;
 }
 
@@ -526,16 +570,31 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
     }
     if (force_bn == 6) return launch_t<64, EPI>(p, s);
     if (force_bn == 12) return launch_t<128, EPI>(p, s);
-    // Widest tile that still gives every CU a tile: wider tiles move fewer LDS-DMA bytes and fragment reads per
-    // MFMA and amortise the per-chunk barrier over more MFMAs.  At B = 64: N = 1536 -> 144x384, N = 1024 ->
-    // 144x256, N = 512 -> 144x128, each exactly 256 tiles.
+    // Tile width: minimise  rounds x (BN + per-tile overhead),  rounds = ceil(tiles / workgroup slots).  Wider
+    // tiles move fewer LDS-DMA bytes and fragment reads per MFMA and amortise the per-chunk barrier, but only while
+    // every CU still gets a tile.  B = 64: N = 1536 -> 144x384, 1024 -> x256, 512 -> x128 (256 tiles each);
+    // B = 32 (the per-GPU batch of the full-scheme configs): 1536 -> x192, 1024 -> x128, 512 -> x64.
+    int best = 64;
+    if (p.conv_taps == 0 && EPI != EPI_OUT_T) {
+        long best_cost = -1;
+        const int cand[5] = {384, 256, 192, 128, 64};
+        for (int bn : cand) {
+            if (bn > 64 && p.N % bn != 0) continue;
+            const long tiles = (long)tm * ((p.N + bn - 1) / bn);
+            const long cost = ((tiles + want - 1) / want) * (bn + 24);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bn; }
+        }
+    } else if (tiles128 >= want && p.N % 128 == 0) {
+        best = 128;
+    }
     if constexpr (EPI != EPI_OUT_T) {
         if (p.conv_taps == 0) {
-            if (p.N % 384 == 0 && tm * (p.N / 384) >= want) return launch_t<384, EPI>(p, s);
-            if (p.N % 256 == 0 && tm * (p.N / 256) >= want) return launch_t<256, EPI>(p, s);
+            if (best == 384) return launch_t<384, EPI>(p, s);
+            if (best == 256) return launch_t<256, EPI>(p, s);
+            if (best == 192) return launch_t<192, EPI>(p, s);
         }
     }
-    if (tiles128 >= want && p.N % 128 == 0) return launch_t<128, EPI>(p, s);
+    if (best == 128) return launch_t<128, EPI>(p, s);
     return launch_t<64, EPI>(p, s);
 }
 
@@ -544,6 +603,12 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     ROHM_ARG_CHECK(p.lda % 4 == 0 && p.ldw % 4 == 0, "gemm: lda/ldw must be multiples of 4 floats");
     ROHM_ARG_CHECK(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "gemm: A/W must be 16-byte aligned");
     ROHM_ARG_CHECK(p.M > 0 && p.N > 0, "gemm: empty problem");
+    if (p.ksplit > 1) {
+        ROHM_ARG_CHECK(epi == EPI_BIAS, "gemm: split-K supports the plain bias epilogue only");
+        ROHM_ARG_CHECK(p.partial && p.ld_partial % 4 == 0 && p.ld_partial >= ((p.N + 3) / 4) * 4 &&
+                           (((uintptr_t)p.partial) & 15) == 0 && p.ksplit <= p.K / BK,
+                       "gemm: bad split-K workspace (ksplit=%d, K chunks=%d)", p.ksplit, p.K / BK);
+    }
     if (p.conv_taps > 0) {
         ROHM_ARG_CHECK(p.conv_taps <= 5 && p.conv_cin_pad % BK == 0 && p.K == p.conv_taps * p.conv_cin_pad,
                        "gemm: conv gather needs cin_pad %% 32 == 0 and K == taps * cin_pad");

@@ -10,6 +10,7 @@
 // residual) are one fused kernel per conv block.  Everything that depends on the timestep only -- the
 // sinusoid -> MLP embedding and the per-block time biases -- is one small launch per step.
 #include <math.h>
+#include <algorithm>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -204,6 +205,24 @@ __global__ void transpose2_kernel(const float* __restrict__ src, float* __restri
 // ---- launch helpers --------------------------------------------------------------------------------------
 static inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
 
+// Split-K plan for the few-tile, long-K convolutions of the deep levels (T <= 36: 16-32 output tiles on 256 CUs):
+// enough splits to give every CU a workgroup, at least 4 K chunks per split.  The partial-tile buffer is part of the
+// caller's workspace; forward() publishes it here for the launch helpers of this host thread.
+constexpr size_t kSplitKFloats = (size_t)256 * 144 * 128;
+static thread_local float* tl_splitk = nullptr;
+
+static void plan_split(GemmParams& g) {
+    if (!tl_splitk) return;
+    const int tm = (g.M + 143) / 144;
+    const int bn = (tm * ((g.N + 127) / 128) >= 256 && g.N % 128 == 0) ? 128 : 64;
+    const int tiles = tm * ((g.N + bn - 1) / bn);
+    const int nk = g.K / 32;
+    const int S = std::min(256 / tiles, nk / 4);
+    const int ldp = (g.N + 3) / 4 * 4;
+    if (tiles > 128 || S < 2 || (size_t)S * g.M * ldp > kSplitKFloats) return;
+    g.ksplit = S; g.partial = tl_splitk; g.ld_partial = ldp;
+}
+
 static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int tin, int tq,
                      int stride, const int* offs, float* out, int ldo, int orow_mul, int orow_add, hipStream_t s) {
     GemmParams g{};
@@ -212,6 +231,7 @@ static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int 
     g.conv_taps = w.taps; g.conv_cin_pad = w.cin_pad; g.conv_tin = tin; g.conv_tq = tq; g.conv_stride = stride;
     for (int j = 0; j < w.taps; ++j) g.conv_off[j] = offs[j];
     g.zero_page = h->zero_page; g.orow_mul_m1 = orow_mul - 1; g.orow_add = orow_add;
+    plan_split(g);
     return launch_gemm(g, EPI_BIAS, s);
 }
 static int conv5(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
@@ -223,6 +243,7 @@ static int conv1(const ConvW& w, const float* x, int ldx, int M, float* out, int
     GemmParams g{};
     g.A = x; g.lda = ldx; g.W = w.w; g.ldw = w.cin_pad; g.C = out; g.ldc = ldo; g.M = M; g.N = w.cout;
     g.K = w.cin_pad; g.bias = w.b;
+    plan_split(g);
     return launch_gemm(g, EPI_BIAS, s);
 }
 static int down(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
@@ -280,6 +301,7 @@ struct TWs {
     float *tb_all;                          // [B or 1][tb_total]
     Scratch sc;
     float *x0, *cond_keep;                  // loop: network output [B,T,13]
+    float *splitk;                          // split-K partial tiles (plan_split)
     size_t floats;
 };
 
@@ -313,6 +335,7 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     w.sc.rc = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
     w.x0 = take(M * h->ctraj);
     w.cond_keep = take(16);
+    w.splitk = take(kSplitKFloats);
     w.floats = off;
     return w;
 }
@@ -662,6 +685,7 @@ int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float*
         set_error("trajnet_forward: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
         return ROHM_ERR_WORKSPACE;
     }
+    tl_splitk = w.splitk;
     const size_t M = (size_t)B * T;
     if ((rc = pad_rows(x_t, w.xin, M, h->ctraj, kPadC, s))) return rc;
     if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;
@@ -688,6 +712,7 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         set_error("trajnet_sample_loop: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
         return ROHM_ERR_WORKSPACE;
     }
+    tl_splitk = w.splitk;
     const size_t M = (size_t)B * T, n = M * h->ctraj;
     // cond / control_cond do not change over the loop: pad them and run the (time-free) cond encoder once
     if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;

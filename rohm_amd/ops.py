@@ -16,7 +16,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES = 0, 1, 2
 
 
 def gemm(a, w, bias=None, residual=None, epi=EPI_BIAS, out=None):
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T); K must be a multiple of 64."""
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T); K must be a multiple of 32."""
     _lib.require_hip(a, w)
     M, K = a.shape
     N = w.shape[0]

@@ -15,7 +15,8 @@ def _dev():
 
 
 @pytest.mark.parametrize('M,N,K', [(144, 512, 512), (288, 1536, 512), (144 * 3, 512, 1024), (100, 70, 64),
-                                   (272, 288, 512), (1, 16, 64), (144 * 64, 512, 512)])
+                                   (272, 288, 512), (1, 16, 64), (144 * 64, 512, 512),
+                                   (144 * 32, 1536, 512), (144 * 64, 1536, 512), (144 * 64, 1024, 512)])   # 144x192 / x384 / x256 tiles
 @pytest.mark.parametrize('epi', [0, 1, 2])
 def test_gemm(M, N, K, epi):
     from rohm_amd import ops
