@@ -222,6 +222,21 @@ int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const floa
                               const float* focal, const float* center, const float* kp2d, int kp_frames, int B,
                               int T, float* grad_out, void* ws, size_t ws_bytes, rohm_stream_t stream);
 
+/* Full linear blend skinning (smplx==0.1.28 `lbs`, as called with return_verts=True from
+ * data_loaders/motion_representation.py:389-396; the post-loop meshes of test_amass_full.py:405-425).  Optional:
+ * rohm_smplx_set_skinning uploads what the joints-only path does not need -- posedirs [(J-1)*9, V*3] (pose_feature
+ * @ posedirs layout of smplx), lbs_weights [V, J] (+ v_template, shapedirs again) -- after which
+ * rohm_smplx_forward produces joints [N, n_joints_out, 3] (may be NULL) and verts [N, V, 3] (may be NULL: joints only)
+ * from poses pose [N, n_pose, 3] (pose_kind 0: axis-angle) or [N, n_pose, 6] (pose_kind 1: the interleaved 6-D vectors
+ * of the motion representation, quaternion.py:482-501); global orient first; joints >= n_pose unrotated; expression = 0;
+ * betas [N,10], transl [N,3].  ws: rohm_smplx_lbs_workspace_bytes(h, N), 256-byte aligned.  N <= 65535 per call. */
+int rohm_smplx_set_skinning(rohm_smplx_t* h, const float* v_template, const float* shapedirs, int n_shape_total,
+                            const float* posedirs, int n_pose_feat, const float* lbs_weights);
+size_t rohm_smplx_lbs_workspace_bytes(const rohm_smplx_t* h, int N);
+int rohm_smplx_forward(const rohm_smplx_t* h, const float* pose, int n_pose, int pose_kind, const float* betas, const float* transl,
+                       int N, float* joints, int n_joints_out, float* verts, void* ws, size_t ws_bytes,
+                       rohm_stream_t stream);
+
 /* recover_from_repr_smpl (data_loaders/motion_representation.py:332-398) straight from the 294-channel
  * representation: joints [B,T,22,3].  mode 0 = 'smplx_params' (:373-398, joints[:, 0:22] of the body model incl.
  * transl; h required), mode 1 = 'joint_abs_traj' (:349-371; h may be NULL).  repr is addressed with strides as in

@@ -93,6 +93,10 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_guidance_proj2d_grad': (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_size_t, C.c_void_p]),
+    'rohm_smplx_set_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'rohm_smplx_lbs_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'rohm_smplx_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_repr_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rohm_amass_metrics': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_uint,

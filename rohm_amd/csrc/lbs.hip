@@ -1,0 +1,266 @@
+// Full SMPL-X linear blend skinning: vertices [N, V, 3] (+ all J joints) of smplx.SMPLX.forward.
+//
+// Reference: third-party smplx==0.1.28 `lbs` (blend_shapes, vertices2joints, batch_rodrigues,
+// batch_rigid_transform, skinning) as called from data_loaders/motion_representation.py:379-396 with
+// `return_verts=True` (test_amass_full.py:283,405,415,425: the post-loop meshes).
+// The denoising loops and the guidance never need vertices (smplx.hip); this is the mesh path.
+//
+//   lbs_pose_kernel   one thread per frame: Rodrigues, rest joints from the folded regressor, the 55-joint chain,
+//                     relative transforms A[m][j] = [G_j | P_j - G_j J_j] and the pose feature (R_j - I, j >= 1).
+//   gemm_f32_kernel   pose blendshapes as a fp32-MFMA GEMM: off[N, V*3] = pose_feature[N, 486] . posedirs
+//                     (30.5 MFLOP per frame -- the one dense contraction of the body model).
+//   lbs_skin_kernel   one thread per (frame, vertex): v_template + shapedirs.beta + off, blended transform
+//                     sum_j w[v][j] A[m][j] from LDS, + transl.  HBM-bound: 12 B read (off) + 12 B written per vertex;
+//                     weights / bases are L2-resident and read coalesced (weights stored [J, V]).
+// Expression coefficients are taken as zero (every reference call site passes zeros, :383-388).
+#include "common.h"
+#include "smplx_fk.h"
+
+namespace rohm {
+
+constexpr int kMaxJ = 64;
+
+__global__ __launch_bounds__(64) void lbs_pose_kernel(const float* __restrict__ pose, int n_pose, int pose_kind,
+                                                      const float* __restrict__ betas, const float* __restrict__ Jt,
+                                                      const float* __restrict__ Js, const int* __restrict__ parents,
+                                                      int J, float* __restrict__ A, float* __restrict__ feat, int KP,
+                                                      int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float beta[NBETA];
+#pragma unroll
+    for (int k = 0; k < NBETA; ++k) beta[k] = betas[(size_t)n * NBETA + k];
+    float* An = A + (size_t)n * J * 12;          // pass 1: (G_j [9], P_j [3]); pass 2: P_j -> P_j - G_j J_j
+    float* fn = feat + (size_t)n * KP;
+    for (int k = (J - 1) * 9; k < KP; ++k) fn[k] = 0.f;
+    auto rest = [&](int j, float* o) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = Jt[j * 3 + c];
+#pragma unroll
+            for (int k = 0; k < NBETA; ++k) v = fmaf(Js[(j * 3 + c) * NBETA + k], beta[k], v);
+            o[c] = v;
+        }
+    };
+    for (int j = 0; j < J; ++j) {
+        float R[9];
+        if (j < n_pose && pose_kind == 1) {          // interleaved 6-D (quaternion.py:482-501), as the representation stores it
+            float x6[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) x6[k] = pose[((size_t)n * n_pose + j) * 6 + k];
+            rot6d_fwd(x6, R);
+        } else if (j < n_pose) {
+            const float r[3] = {pose[((size_t)n * n_pose + j) * 3], pose[((size_t)n * n_pose + j) * 3 + 1],
+                                pose[((size_t)n * n_pose + j) * 3 + 2]};
+            rodrigues(r, R);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.f : 0.f;
+        }
+        if (j >= 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fn[(j - 1) * 9 + i] = R[i] - ((i % 4 == 0) ? 1.f : 0.f);
+        }
+        float Jj[3];
+        rest(j, Jj);
+        float* o = An + j * 12;
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) o[i] = R[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[9 + c] = Jj[c];
+        } else {
+            const int p = parents[j];
+            const float* gp = An + p * 12;
+            float Gp[9], Pp[3], Jp[3], G[9], w[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Gp[i] = gp[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Pp[c] = gp[9 + c];
+            rest(p, Jp);
+            mat_mul(Gp, R, G);
+            const float off[3] = {Jj[0] - Jp[0], Jj[1] - Jp[1], Jj[2] - Jp[2]};
+            mat_vec(Gp, off, w);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) o[i] = G[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[9 + c] = Pp[c] + w[c];
+        }
+    }
+}
+
+// joints out (posed + transl) and P_j -> t_j = P_j - G_j J_j; separate pass so children above read the parents' P_j
+__global__ __launch_bounds__(64) void lbs_finish_pose_kernel(const float* __restrict__ betas, const float* __restrict__ transl,
+                                                             const float* __restrict__ Jt, const float* __restrict__ Js,
+                                                             int J, float* __restrict__ A, float* __restrict__ joints,
+                                                             int n_joints_out, int N) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * J) return;
+    const int n = idx / J, j = idx % J;
+    float* o = A + (size_t)idx * 12;
+    float Jj[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = Jt[j * 3 + c];
+#pragma unroll
+        for (int k = 0; k < NBETA; ++k) v = fmaf(Js[(j * 3 + c) * NBETA + k], betas[(size_t)n * NBETA + k], v);
+        Jj[c] = v;
+    }
+    if (joints && j < n_joints_out)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) joints[((size_t)n * n_joints_out + j) * 3 + c] = o[9 + c] + transl[(size_t)n * 3 + c];
+    float w[3];
+    mat_vec(o, Jj, w);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[9 + c] -= w[c];
+}
+
+__global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ vt, const float* __restrict__ sd,
+                                                       const float* __restrict__ wT, const float* __restrict__ off, int ldo,
+                                                       const float* __restrict__ A, const float* __restrict__ betas,
+                                                       const float* __restrict__ transl, int J, int V,
+                                                       float* __restrict__ verts) {
+    __shared__ float sA[kMaxJ * 12];
+    __shared__ float sb[NBETA + 3];
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < J * 12; i += blockDim.x) sA[i] = A[(size_t)n * J * 12 + i];
+    if (threadIdx.x < NBETA) sb[threadIdx.x] = betas[(size_t)n * NBETA + threadIdx.x];
+    if (threadIdx.x >= 32 && threadIdx.x < 35) sb[NBETA + threadIdx.x - 32] = transl[(size_t)n * 3 + threadIdx.x - 32];
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float x = vt[v * 3 + c];
+#pragma unroll
+        for (int k = 0; k < NBETA; ++k) x = fmaf(sd[((size_t)v * 3 + c) * NBETA + k], sb[k], x);
+        p[c] = x + off[(size_t)n * ldo + v * 3 + c];
+    }
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+    for (int j = 0; j < J; ++j) {
+        const float w = wT[(size_t)j * V + v];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = fmaf(w, sA[j * 12 + i], T[i]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        verts[((size_t)n * V + v) * 3 + c] = T[c * 3] * p[0] + T[c * 3 + 1] * p[1] + T[c * 3 + 2] * p[2] + T[9 + c] + sb[NBETA + c];
+}
+
+// dst[c][r] = src[r][c] for r < R, c < Cc; dst rows padded to ldd (pre-zeroed)
+__global__ void lbs_transpose_kernel(const float* __restrict__ src, int R, int Cc, float* __restrict__ dst, int ldd) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * Cc) return;
+    const int r = (int)(i / Cc), c = (int)(i % Cc);
+    dst[(size_t)c * ldd + r] = src[i];
+}
+__global__ void lbs_copy_shape_kernel(const float* __restrict__ src, int n_total, float* __restrict__ dst, long rows) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * NBETA) return;
+    dst[i] = src[(i / NBETA) * n_total + (i % NBETA)];
+}
+
+static inline size_t al64(size_t n) { return (n + 63) / 64 * 64; }
+
+}  // namespace rohm
+
+using namespace rohm;
+
+extern "C" {
+
+int rohm_smplx_set_skinning(rohm_smplx_t* h, const float* v_template, const float* shapedirs, int n_shape_total,
+                            const float* posedirs, int n_pose_feat, const float* lbs_weights) {
+    ROHM_ARG_CHECK(h && v_template && shapedirs && posedirs && lbs_weights, "smplx_set_skinning: null argument");
+    ROHM_ARG_CHECK(n_pose_feat == (h->J - 1) * 9, "smplx_set_skinning: posedirs must have (J-1)*9 = %d rows (got %d)",
+                   (h->J - 1) * 9, n_pose_feat);
+    ROHM_ARG_CHECK(h->J <= kMaxJ && n_shape_total >= NBETA, "smplx_set_skinning: bad sizes");
+    ROHM_HIP_CHECK(hipSetDevice(h->device));
+    const int V = h->V, J = h->J;
+    h->P = n_pose_feat;
+    h->KP = (n_pose_feat + 31) / 32 * 32;
+    h->NP = (V * 3 + 383) / 384 * 384;
+    float *d_pd = nullptr, *d_w = nullptr, *d_sdin = nullptr;
+    hipError_t e = hipSuccess;
+    auto bad = [&](hipError_t err) {
+        if (d_pd) (void)hipFree(d_pd);
+        if (d_w) (void)hipFree(d_w);
+        if (d_sdin) (void)hipFree(d_sdin);
+        set_error("smplx_set_skinning: %s", hipGetErrorString(err));
+        return ROHM_ERR_HIP;
+    };
+#define TRY(x) if ((e = (x)) != hipSuccess) return bad(e)
+    if (!h->d_vt) TRY(hipMalloc(&h->d_vt, (size_t)V * 3 * sizeof(float)));
+    if (!h->d_sd) TRY(hipMalloc(&h->d_sd, (size_t)V * 3 * NBETA * sizeof(float)));
+    if (!h->d_pdT) TRY(hipMalloc(&h->d_pdT, (size_t)h->NP * h->KP * sizeof(float)));
+    if (!h->d_wT) TRY(hipMalloc(&h->d_wT, (size_t)J * V * sizeof(float)));
+    TRY(hipMalloc(&d_pd, (size_t)n_pose_feat * V * 3 * sizeof(float)));
+    TRY(hipMalloc(&d_w, (size_t)V * J * sizeof(float)));
+    TRY(hipMalloc(&d_sdin, (size_t)V * 3 * n_shape_total * sizeof(float)));
+    TRY(hipMemcpy(h->d_vt, v_template, (size_t)V * 3 * sizeof(float), hipMemcpyDefault));
+    TRY(hipMemcpy(d_sdin, shapedirs, (size_t)V * 3 * n_shape_total * sizeof(float), hipMemcpyDefault));
+    TRY(hipMemcpy(d_pd, posedirs, (size_t)n_pose_feat * V * 3 * sizeof(float), hipMemcpyDefault));
+    TRY(hipMemcpy(d_w, lbs_weights, (size_t)V * J * sizeof(float), hipMemcpyDefault));
+    TRY(hipMemset(h->d_pdT, 0, (size_t)h->NP * h->KP * sizeof(float)));
+    {
+        const long n = (long)V * 3 * NBETA;
+        hipLaunchKernelGGL(lbs_copy_shape_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_sdin, n_shape_total,
+                           h->d_sd, (long)V * 3);
+        const long n2 = (long)n_pose_feat * V * 3;     // posedirs [P, V*3] -> [V*3 (pad NP), KP]
+        hipLaunchKernelGGL(lbs_transpose_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, 0, d_pd, n_pose_feat,
+                           V * 3, h->d_pdT, h->KP);
+        const long n3 = (long)V * J;                   // weights [V, J] -> [J, V]
+        hipLaunchKernelGGL(lbs_transpose_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, 0, d_w, V, J, h->d_wT, V);
+    }
+    TRY(hipDeviceSynchronize());
+#undef TRY
+    (void)hipFree(d_pd); (void)hipFree(d_w); (void)hipFree(d_sdin);
+    return ROHM_OK;
+}
+
+size_t rohm_smplx_lbs_workspace_bytes(const rohm_smplx_t* h, int N) {
+    if (!h || N <= 0 || !h->d_pdT) return 0;
+    return (al64((size_t)N * h->KP) + al64((size_t)N * h->J * 12) + al64((size_t)N * h->NP)) * sizeof(float);
+}
+
+int rohm_smplx_forward(const rohm_smplx_t* h, const float* pose, int n_pose, int pose_kind, const float* betas, const float* transl,
+                       int N, float* joints, int n_joints_out, float* verts, void* ws, size_t ws_bytes,
+                       rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && pose && betas && transl && ws, "smplx_forward: null argument");
+    ROHM_ARG_CHECK(h->d_pdT, "smplx_forward: call rohm_smplx_set_skinning first (posedirs / lbs_weights)");
+    ROHM_ARG_CHECK(n_pose >= 1 && n_pose <= h->J, "smplx_forward: n_pose must be in [1, %d]", h->J);
+    ROHM_ARG_CHECK(pose_kind == 0 || pose_kind == 1, "smplx_forward: pose_kind must be 0 (axis-angle) or 1 (6-D)");
+    ROHM_ARG_CHECK(!joints || (n_joints_out >= 1 && n_joints_out <= h->J), "smplx_forward: n_joints_out must be in [1, %d]", h->J);
+    ROHM_ARG_CHECK(((uintptr_t)ws % 256) == 0, "smplx_forward: workspace must be 256-byte aligned");
+    if (N <= 0) return ROHM_OK;
+    ROHM_ARG_CHECK(N <= 65535, "smplx_forward: at most 65535 frames per call (got %d)", N);
+    ROHM_ARG_CHECK(ws_bytes >= rohm_smplx_lbs_workspace_bytes(h, N), "smplx_forward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* feat = (float*)ws;
+    float* A = feat + al64((size_t)N * h->KP);
+    float* off = A + al64((size_t)N * h->J * 12);
+    {
+        prof::Scope ps("lbs_pose", 0.0, 4.0 * N * (n_pose * 3 + 10 + h->J * 12 + h->KP), s);
+        hipLaunchKernelGGL(lbs_pose_kernel, dim3((N + 63) / 64), dim3(64), 0, s, pose, n_pose, pose_kind, betas, h->d_Jt, h->d_Js,
+                           h->d_parents, h->J, A, feat, h->KP, N);
+        const int nj = N * h->J;
+        hipLaunchKernelGGL(lbs_finish_pose_kernel, dim3((nj + 63) / 64), dim3(64), 0, s, betas, transl, h->d_Jt, h->d_Js,
+                           h->J, A, joints, n_joints_out, N);
+        ROHM_LAUNCH_CHECK();
+    }
+    if (!verts) return ROHM_OK;
+    GemmParams g{};
+    g.A = feat; g.lda = h->KP; g.W = h->d_pdT; g.ldw = h->KP; g.C = off; g.ldc = h->NP;
+    g.M = N; g.N = h->NP; g.K = h->KP; g.bias = nullptr;
+    int rc = launch_gemm(g, EPI_BIAS, s);
+    if (rc) return rc;
+    prof::Scope ps("lbs_skin", 2.0 * N * h->V * (h->J * 12 + 30 + 12), 24.0 * N * h->V, s);
+    hipLaunchKernelGGL(lbs_skin_kernel, dim3((h->V + 255) / 256, N), dim3(256), 0, s, h->d_vt, h->d_sd, h->d_wT, off, h->NP, A,
+                       betas, transl, h->J, h->V, verts);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+}  // extern "C"

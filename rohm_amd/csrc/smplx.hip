@@ -354,6 +354,10 @@ int rohm_smplx_create(rohm_smplx_t** out, const float* v_template, const float* 
 void rohm_smplx_destroy(rohm_smplx_t* h) {
     if (!h) return;
     (void)hipFree(h->d_Jt); (void)hipFree(h->d_Js); (void)hipFree(h->d_parents);
+    if (h->d_vt) (void)hipFree(h->d_vt);
+    if (h->d_sd) (void)hipFree(h->d_sd);
+    if (h->d_pdT) (void)hipFree(h->d_pdT);
+    if (h->d_wT) (void)hipFree(h->d_wT);
     delete h;
 }
 

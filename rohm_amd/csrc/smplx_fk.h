@@ -20,6 +20,12 @@ struct rohm_smplx {
     float* d_Js;       // [J, 3, 10]    J_regressor . shapedirs[:, :, :10]
     int* d_parents;    // [J]
     int parents[64];
+    // ---- full linear blend skinning (lbs.hip; optional, set by rohm_smplx_set_skinning) ----
+    int P, KP, NP;     // pose-blendshape rows (J-1)*9, padded to a multiple of 32; V*3 padded to a multiple of 384
+    float* d_vt;       // [V, 3]          v_template
+    float* d_sd;       // [V, 3, 10]      shapedirs[:, :, :10]
+    float* d_pdT;      // [NP, KP]        posedirs transposed (GEMM weight layout), zero padded
+    float* d_wT;       // [J, V]          lbs_weights transposed (coalesced per-vertex reads)
 };
 
 namespace rohm {

@@ -87,12 +87,27 @@ def joints_from_repr(repr_full, recover_mode='smplx_params', smplx_model=None, s
 def recover_from_repr_smpl(data_dict, recover_mode='joint_abs_traj', smplx_model=None, return_verts=False,
                            return_full_joints=False):
     """Drop-in for motion_representation.py:332-398 with the reference's dict-of-slices argument
-    ([bs, T, dim] tensors, de-normalised).  Vertices / the 127-joint set are outside the hot path."""
-    if return_verts or return_full_joints:
-        raise NotImplementedError('vertices / 127 joints are not produced by the joints-only FK kernels')
+    ([bs, T, dim] tensors, de-normalised).  `return_verts` / `return_full_joints` run the full-LBS path
+    (rohm_smplx_forward; the 72 landmark joints beyond the 55 kinematic ones stay zero)."""
     if recover_mode not in _MODES:
         print('[ERROR] recover_mode incorrect! in func recover_from_repr_smpl()')   # as the reference (:347-348)
         raise ValueError(recover_mode)
+    if (return_verts or return_full_joints) and recover_mode == 'smplx_params':      # :389-396, full LBS
+        from ..body_model import lbs_forward
+        r6, b6 = data_dict['smplx_rot_6d'], data_dict['smplx_body_pose_6d']
+        _lib.require_hip(r6)
+        bs = len(r6)
+        pose = torch.cat([r6.reshape(-1, 1, 6), b6.reshape(-1, 21, 6)], dim=1).float().contiguous()
+        nat = native_for(smplx_model, r6.device)
+        jall, verts = lbs_forward(nat, pose, 1, data_dict['smplx_betas'].reshape(-1, 10).float().contiguous(),
+                                  data_dict['smplx_trans'].reshape(-1, 3).float().contiguous(), want_verts=return_verts)
+        if return_full_joints:
+            joints = torch.zeros(pose.shape[0], 127, 3, device=pose.device)
+            joints[:, :jall.shape[1]] = jall
+            joints = joints.reshape(bs, -1, 127, 3)
+        else:
+            joints = jall[:, 0:22].reshape(bs, -1, 22, 3)
+        return (joints, verts.reshape(bs, -1, verts.shape[1], 3)) if return_verts else joints
     need = (['root_rot_angle', 'root_l_pos', 'root_height', 'local_positions'] if recover_mode == 'joint_abs_traj'
             else ['smplx_rot_6d', 'smplx_trans', 'smplx_body_pose_6d', 'smplx_betas'])
     ref = data_dict[need[0]]

@@ -111,8 +111,12 @@ def test_joints_from_repr_vs_golden_and_oracle():
     d = G.split_repr(full)
     assert max_abs(recover_from_repr_smpl(d, 'smplx_params', layer), j_s) < 1e-6
     assert max_abs(recover_from_repr_smpl(d, 'joint_abs_traj'), j_a) < 1e-6
-    with pytest.raises(NotImplementedError):
-        recover_from_repr_smpl(d, 'smplx_params', layer, return_verts=True)
+    # full LBS (return_verts=True, motion_representation.py:389-396) against the oracle body model
+    jv, verts = recover_from_repr_smpl(d, 'smplx_params', layer, return_verts=True)
+    dc = {k: v.cpu() for k, v in d.items()}
+    jr, vr = G.joints_from_smplx(dc, G.BodyModel(synth.synthetic_smplx_tensors(0)), return_verts=True)
+    assert verts.shape == (2, 143, 10475, 3)
+    assert max_abs(jv.cpu(), jr) < 1e-5 and max_abs(verts.cpu(), vr) < 2e-5
 
 
 def test_rederive_rejects_cpu_and_bad_shapes():
@@ -140,3 +144,27 @@ def test_amass_metrics_vs_reference_golden(scheme, ratio):
     for k, v in out.items():
         ref = float(g[f'{scheme}_{k}']) * unit.get(k, 1.0)
         assert abs(v - ref) <= 2e-6 * max(1.0, abs(ref)), (k, v, ref)
+
+
+def test_lbs_vertices_vs_oracle_with_face_and_hands():
+    """Body-model layer called like smplx (axis-angle, all 55 joints posed): `.vertices`, `.joints[:, :55]`."""
+    t = synth.synthetic_smplx_tensors(0)
+    layer, body = _layer(t), G.BodyModel(t)
+    N = 37
+    betas, go, bp, tr = seeded(1, N, 10), seeded(2, N, 3) * 0.8, seeded(3, N, 63) * 0.5, seeded(4, N, 3)
+    jaw, le, re_ = seeded(5, N, 3) * 0.2, seeded(6, N, 3) * 0.1, seeded(7, N, 3) * 0.1
+    lh, rh = seeded(8, N, 45) * 0.3, seeded(9, N, 45) * 0.3
+    bp[:3] = 0.0
+    ref = body(betas=betas, global_orient=go, body_pose=bp, transl=tr, jaw_pose=jaw, leye_pose=le, reye_pose=re_,
+               left_hand_pose=lh, right_hand_pose=rh, return_verts=True)
+    g = lambda a: a.to(DEV)
+    out = layer(betas=g(betas), global_orient=g(go), body_pose=g(bp), transl=g(tr), jaw_pose=g(jaw), leye_pose=g(le),
+                reye_pose=g(re_), left_hand_pose=g(lh), right_hand_pose=g(rh), expression=torch.zeros(N, 10, device=DEV),
+                return_verts=True)
+    assert out.vertices.shape == (N, 10475, 3) and out.joints.shape == (N, 127, 3)
+    assert max_abs(out.vertices.cpu(), ref.vertices) < 2e-5
+    assert max_abs(out.joints[:, :55].cpu(), ref.joints[:, :55]) < 1e-5
+    # body-only call (the reference's call sites pass zeros for face and hands)
+    ref2 = body(betas=betas, global_orient=go, body_pose=bp, transl=tr, return_verts=True)
+    out2 = layer(betas=g(betas), global_orient=g(go), body_pose=g(bp), transl=g(tr), return_verts=True)
+    assert max_abs(out2.vertices.cpu(), ref2.vertices) < 2e-5
