@@ -215,6 +215,16 @@ int rohm_guidance_skating_grad(const rohm_smplx_t* h, const float* x0, const flo
                                int B, int T, float* grad_out, float* counts2, void* ws, size_t ws_bytes,
                                rohm_stream_t stream);
 
+/* The two halves of rohm_guidance_skating_grad, for clip sharding with GLOBAL-batch semantics:
+ * the loss normalises by mask counts over the whole batch (model/posenet.py:231,243), so each rank runs `prepare`
+ * (local counts -> counts2), the host all-reduces the 2 floats (RCCL), and `apply` uses the summed counts.  `apply`
+ * must follow `prepare` on the same x0 / workspace. */
+int rohm_guidance_skating_prepare(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                                  int B, int T, float* counts2, void* ws, size_t ws_bytes, rohm_stream_t stream);
+int rohm_guidance_skating_apply(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                                int B, int T, const float* counts2, float* grad_out, void* ws, size_t ws_bytes,
+                                rohm_stream_t stream);
+
 /* guide_2d_projection_with_smpl (model/posenet.py:260-317): transf_matrix [B,4,4] (affine, inverted on the
  * device), cam_R [3,3], cam_t [3], focal / center [B,2], kp2d [B, kp_frames, 22, 3] (u, v, confidence). */
 int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,

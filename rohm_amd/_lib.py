@@ -91,6 +91,10 @@ SIGNATURES = {
     'rohm_guidance_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'rohm_guidance_skating_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'rohm_guidance_skating_prepare': (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.c_void_p]),
+    'rohm_guidance_skating_apply': (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_size_t, C.c_void_p]),
     'rohm_guidance_proj2d_grad': (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_size_t, C.c_void_p]),
     'rohm_smplx_set_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

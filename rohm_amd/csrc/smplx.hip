@@ -378,15 +378,17 @@ size_t rohm_guidance_workspace_bytes(int B, int T) {
     return ((size_t)B * T * 24 + (size_t)B * 21 + 64) * sizeof(float);
 }
 
-int rohm_guidance_skating_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
-                               int B, int T, float* grad_out, float* counts2, void* ws, size_t ws_bytes,
-                               rohm_stream_t stream) {
-    ROHM_ARG_CHECK(h && x0 && mean294 && std294 && grad_out && counts2 && ws, "guidance_skating: null argument");
+// The skating loss normalises by mask counts taken over the whole batch (model/posenet.py:231,243), so under clip
+// sharding the reference-at-full-batch result needs the two counts summed over the ranks between the two halves:
+//   prepare: foot joints of both recoveries + the local counts;   apply: gradient with the counts it is GIVEN.
+int rohm_guidance_skating_prepare(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                                  int B, int T, float* counts2, void* ws, size_t ws_bytes, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && x0 && mean294 && std294 && counts2 && ws, "guidance_skating: null argument");
     ROHM_ARG_CHECK(B > 0 && T > 1, "guidance_skating: need B > 0 and T > 1");
     ROHM_ARG_CHECK(ws_bytes >= rohm_guidance_workspace_bytes(B, T), "guidance_skating: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float* feet = (float*)ws;
-    prof::Scope ps("guidance_skating", 0.0, 8.0 * B * T * C_TOTAL, s);
+    prof::Scope ps("guidance_skating_fwd", 0.0, 4.0 * B * T * (C_TOTAL + 24), s);
     ROHM_HIP_CHECK(hipMemsetAsync(counts2, 0, 2 * sizeof(float), s));
     const int nf = B * T;
     hipLaunchKernelGGL(skating_fwd_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
@@ -394,10 +396,32 @@ int rohm_guidance_skating_grad(const rohm_smplx_t* h, const float* x0, const flo
     const int np = B * (T - 1) * 4;
     hipLaunchKernelGGL(skating_count_kernel, dim3((np + 255) / 256), dim3(256), 0, s, x0, mean294, std294, feet,
                        counts2, B, T);
-    hipLaunchKernelGGL(skating_bwd_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
-                       h->d_parents, feet, counts2, grad_out, B, T);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
+}
+
+int rohm_guidance_skating_apply(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                                int B, int T, const float* counts2, float* grad_out, void* ws, size_t ws_bytes,
+                                rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && x0 && mean294 && std294 && grad_out && counts2 && ws, "guidance_skating: null argument");
+    ROHM_ARG_CHECK(B > 0 && T > 1, "guidance_skating: need B > 0 and T > 1");
+    ROHM_ARG_CHECK(ws_bytes >= rohm_guidance_workspace_bytes(B, T), "guidance_skating: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    prof::Scope ps("guidance_skating_bwd", 0.0, 4.0 * B * T * (2 * C_TOTAL + 24), s);
+    const int nf = B * T;
+    hipLaunchKernelGGL(skating_bwd_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
+                       h->d_parents, (const float*)ws, counts2, grad_out, B, T);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+int rohm_guidance_skating_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,
+                               int B, int T, float* grad_out, float* counts2, void* ws, size_t ws_bytes,
+                               rohm_stream_t stream) {
+    ROHM_ARG_CHECK(grad_out, "guidance_skating: null argument");
+    int rc = rohm_guidance_skating_prepare(h, x0, mean294, std294, B, T, counts2, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return rohm_guidance_skating_apply(h, x0, mean294, std294, B, T, counts2, grad_out, ws, ws_bytes, stream);
 }
 
 int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const float* mean294, const float* std294,

@@ -5,6 +5,11 @@ gradient tensor [B, 294, 1, T] (d(-loss)/dx0, channels [0,22) and [290,294) zero
 returns a 0-d zero (no active skating constraint anywhere in the batch) the kernels return an all-zero
 tensor: numerically identical in `mean + w * variance * grad`, and it avoids the reference's three host
 syncs per step.
+
+Clip sharding: by default every rank behaves like the reference run at its LOCAL batch size.  Setting
+`model.guidance_group` (see `rohm_amd.sharding.use_global_batch_guidance`) switches to GLOBAL-batch semantics: the
+skating mask counts are all-reduced and the 2-D term is scaled by B_local / B_global, so the sharded job reproduces
+the reference at the full batch size.
 """
 from __future__ import annotations
 
@@ -14,6 +19,22 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 from .body_model import native_for
+
+
+def _allreduce_sum(t, group):
+    """SUM all-reduce over `group` (a torch.distributed ProcessGroup, or True for the default group).  A callable is
+    accepted too (tests emulate the ranks of a job inside one process)."""
+    if callable(group):
+        return group(t)
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=None if group is True else group)
+    return t
+
+
+def global_batch(B, group, device):
+    """Total number of clips over the ranks of `group` (shards may be ragged)."""
+    n = torch.tensor([float(B)], device=device)
+    return float(_allreduce_sum(n, group).item())
 
 
 def _stats(model, device):
@@ -51,8 +72,18 @@ def guide_skating(model, batch, out, denoise_t, compute_grad='x_t', return_count
     grad = torch.empty_like(x)
     counts = torch.empty(2, device=x.device, dtype=torch.float32)
     ws = nat.workspace(B, T)
-    check(lib().rohm_guidance_skating_grad(nat.handle, ptr(x), ptr(mean), ptr(std), B, T, ptr(grad), ptr(counts),
-                                           ptr(ws), ws.numel(), stream_ptr(x.device)), 'rohm_guidance_skating_grad')
+    group = getattr(model, 'guidance_group', None)
+    if group is None:
+        check(lib().rohm_guidance_skating_grad(nat.handle, ptr(x), ptr(mean), ptr(std), B, T, ptr(grad), ptr(counts),
+                                               ptr(ws), ws.numel(), stream_ptr(x.device)), 'rohm_guidance_skating_grad')
+    else:
+        # global-batch semantics under clip sharding: the two mask counts are summed over the ranks (one 8-byte
+        # RCCL all-reduce per guided step) between the forward/count half and the gradient half
+        check(lib().rohm_guidance_skating_prepare(nat.handle, ptr(x), ptr(mean), ptr(std), B, T, ptr(counts), ptr(ws),
+                                                  ws.numel(), stream_ptr(x.device)), 'rohm_guidance_skating_prepare')
+        _allreduce_sum(counts, group)
+        check(lib().rohm_guidance_skating_apply(nat.handle, ptr(x), ptr(mean), ptr(std), B, T, ptr(counts), ptr(grad),
+                                                ptr(ws), ws.numel(), stream_ptr(x.device)), 'rohm_guidance_skating_apply')
     return (grad, counts) if return_counts else grad
 
 
@@ -74,4 +105,8 @@ def guide_2d_projection(model, batch, out, denoise_t, compute_grad='x_t'):
     check(lib().rohm_guidance_proj2d_grad(nat.handle, ptr(x), ptr(mean), ptr(std), ptr(tm), ptr(cam_R), ptr(cam_t),
                                           ptr(focal), ptr(center), ptr(kp), kp.shape[1], B, T, ptr(grad), ptr(ws),
                                           ws.numel(), stream_ptr(dev)), 'rohm_guidance_proj2d_grad')
+    group = getattr(model, 'guidance_group', None)
+    if group is not None:
+        # loss_joints_2d.mean() runs over the whole batch (model/posenet.py:309): d/dx of a local clip scales as 1 / B_global
+        grad.mul_(B / float(global_batch(B, group, dev)))
     return grad

@@ -69,3 +69,13 @@ def sharded_sample(sample_fn, batch, shape, group=None):
     local = shard_batch(batch, world, rank)
     out = sample_fn(local, [hi - lo] + list(shape[1:]))
     return gather_clips(out, n, group)
+
+
+def use_global_batch_guidance(model, group=True):
+    """Make the test-time guidance of `model` (a PoseNet) reproduce the reference at the GLOBAL batch size when the
+    clips are sharded over the ranks of `group` (default process group if True; None switches back to per-rank
+    semantics).  Costs one 8-byte all-reduce per guided step (the two skating mask counts, model/posenet.py:231,243)
+    and one per 2-D guided step for the batch size."""
+    raw = getattr(model, 'model', model)
+    raw.guidance_group = group
+    return model

@@ -163,3 +163,44 @@ def test_guided_loop_matches_oracle_free_running(monkeypatch):
                             grad_type='amass')
     ref = odiff.p_sample_loop(fn, x_T, noises, tab, idx, guidance=guid, grad_type='amass')
     assert max_abs(y.cpu(), ref) < 1e-3
+
+
+def test_global_batch_guidance_equals_full_batch():
+    """Clip sharding with GLOBAL-batch semantics (SURVEY §8(e) ii): two 'ranks' holding 3 + 1 of 4 clips, their mask
+    counts / batch sizes summed as an all-reduce would, must reproduce the single-process gradients of the full batch
+    (= the reference at B = 4, pinned by the golden tests above) -- for both guidance terms."""
+    from rohm_amd.guidance import guide_2d_projection, guide_skating
+    from rohm_amd.sharding import use_global_batch_guidance
+    mean, std = synth.synthetic_stats(0)
+    net = _posenet(mean, std)
+    B = 4
+    x0 = synth.plausible_motion(41, B, 143, mean, std).to(DEV)
+    cam = {k: v.to(DEV) for k, v in synth.synthetic_camera_batch(0, B).items()}
+    full_s, full_counts = guide_skating(net, {}, {'pred_xstart': x0}, None, 'x_0', return_counts=True)
+    full_p = guide_2d_projection(net, dict(cam), {'pred_xstart': x0}, None, 'x_0')
+    shards = [slice(0, 3), slice(3, 4)]
+    # pass 1: what every rank would contribute to the all-reduce
+    contrib = []
+    for sl in shards:
+        use_global_batch_guidance(net, group=lambda t: t)                      # identity: record the local value
+        _, c = guide_skating(net, {}, {'pred_xstart': x0[sl].contiguous()}, None, 'x_0', return_counts=True)
+        contrib.append(c.clone())
+    total = contrib[0] + contrib[1]
+    assert torch.equal(total, full_counts)
+
+    def fake_allreduce(t):                                                     # counts (2 floats) or batch size (1)
+        t.copy_(total if t.numel() == 2 else torch.tensor([float(B)], device=t.device))
+        return t
+    use_global_batch_guidance(net, group=fake_allreduce)
+    gs, gp = [], []
+    for sl in shards:
+        gs.append(guide_skating(net, {}, {'pred_xstart': x0[sl].contiguous()}, None, 'x_0'))
+        gp.append(guide_2d_projection(net, {k: v[sl].contiguous() for k, v in cam.items()},
+                                      {'pred_xstart': x0[sl].contiguous()}, None, 'x_0'))
+    use_global_batch_guidance(net, group=None)
+    gs, gp = torch.cat(gs), torch.cat(gp)
+    assert max_abs(gs.cpu(), full_s.cpu()) <= 1e-6 * float(full_s.abs().max())
+    assert max_abs(gp.cpu(), full_p.cpu()) <= 1e-6 * float(full_p.abs().max())
+    # and per-rank (replica) semantics really is different: the local run normalises by the local counts
+    local = guide_skating(net, {}, {'pred_xstart': x0[0:3].contiguous()}, None, 'x_0')
+    assert max_abs(local.cpu(), full_s[0:3].cpu()) > 1e-3 * float(full_s.abs().max())

@@ -69,3 +69,38 @@ def test_slice_bounds_cover_everything():
             spans = [sharding.slice_bounds(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_guidance(rank, world, port, q):
+    """The host side of global-batch guidance: the all-reduce helpers of rohm_amd.guidance over a real process
+    group (gloo stands in for RCCL): mask counts are summed, the global batch size of ragged shards is recovered."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from rohm_amd import guidance
+        counts = torch.tensor([3.0 + rank, 10.0 * (rank + 1)])
+        guidance._allreduce_sum(counts, True)
+        b_local = 3 if rank == 0 else 2
+        total = guidance.global_batch(b_local, dist.group.WORLD, 'cpu')
+
+        class M:
+            pass
+        m = sharding.use_global_batch_guidance(M())
+        q.put((rank, counts.tolist(), total, m.guidance_group is True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_batch_guidance_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_guidance, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, counts, total, flag in res:
+        assert counts == [7.0, 30.0] and total == 5.0 and flag
