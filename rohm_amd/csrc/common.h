@@ -101,6 +101,17 @@ struct GemmParams {
     // chunks of its split and stores the raw partial tile to partial[split][m][n] (row stride ld_partial); a second
     // kernel sums the splits in a fixed order, adds the bias and writes C.  ksplit <= 1: off.  EPI_BIAS only.
     int ksplit; float* partial; int ld_partial;
+    // ---- LayerNorm folded into the GEMMs around it (posenet.hip).  A producer (bias+residual epilogue) writes
+    // per-row partial sums of its OUTPUT, one (sum, sum of squares) pair per column tile: out_stats[m][tile_n][2].
+    // A consumer whose normalised operand is LN(x) = (x - mu) rstd gamma + beta runs on the RAW x with
+    // gamma-scaled weights and finishes in the epilogue:  (acc - mu_m c_n) rstd_m + d_n,  c_n = sum_k gamma_k W_nk,
+    // d_n = bias_n + sum_k beta_k W_nk  (passed as `ln_c` and `bias`).  For EPI_OUT_T the normalised operand is the
+    // column side (tokens): (acc - mu_n c_m) rstd_n + d_m.  A residual that is itself LN(raw) is normalised on the
+    // fly from `r_stats` / `r_gamma` / `r_beta`.  Stats cover ln_dim columns; parts = number of partial pairs.
+    const float* ln_stats; int ln_parts; const float* ln_c;
+    const float* r_stats; int r_parts; const float* r_gamma; const float* r_beta;
+    float* out_stats; int out_parts;
+    int ln_dim; float ln_eps;
 };
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);

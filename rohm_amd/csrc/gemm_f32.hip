@@ -77,6 +77,24 @@ struct SchedGroups<N, N, MF, DS_TOTAL, VM_TOTAL, ID> {
     static __device__ __forceinline__ void run() {}
 };
 
+// (mu, rstd) of one row from its partial (sum, sum of squares) pairs -- biased variance, eps inside the root, like
+// nn.LayerNorm.  The pairs of a row are contiguous (parts x 2 floats, parts a multiple of 2): independent 16-byte
+// loads, summed in index order.
+__device__ __forceinline__ void row_mu_rstd(const float* __restrict__ stats, int parts, int row, int dim, float eps,
+                                            float& mu, float& rstd) {
+    const f32x4* sp = reinterpret_cast<const f32x4*>(stats + (size_t)row * parts * 2);
+    f32x4 v[4];                      // parts <= 8 (launch_gemm checks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (2 * i < parts) ? sp[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s += v[i][0]; q += v[i][1]; s += v[i][2]; q += v[i][3]; }
+    const float inv = 1.0f / (float)dim;
+    mu = s * inv;
+    const float var = fmaxf(q * inv - mu * mu, 0.f);
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
 #ifndef ROHM_GEMM_MIXED
 #define ROHM_GEMM_MIXED 1
 #endif
@@ -271,7 +289,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int kbase = kc0 * BK;
     dma(0, kbase);
     if (nk > 1) dma(1, kbase + BK);
-    // every wave issues exactly PIECES loads per chunk
+    // ---- LayerNorm folding (common.h): row statistics, fetched under the prologue's DMA latency ----------------------
+    // per-lane row slots -- !M32: slot r = row m0 + 16 r + li; M32: slots 0..3 = rows m0 + 32 rb + li32, slot 4 = row
+    // m0 + 128 + li.
+    constexpr int NSLOT = M32 ? 5 : NRB;
+    constexpr bool LN_CONSUMER = (EPI == EPI_QKV || EPI == EPI_BIAS_GELU);
+    constexpr bool LN_PRODUCER = (EPI == EPI_BIAS_RES) && !M32;
+    float amu[NSLOT], ars[NSLOT], rmu[NSLOT], rrs[NSLOT], osum[NSLOT], osq[NSLOT];
+    auto slot_row = [&](int sl) {
+        int m;
+        if constexpr (M32) m = (sl < 4) ? m0 + sl * 32 + li32 : m0 + 128 + li;
+        else m = m0 + sl * 16 + li;
+        return m < p.M ? m : p.M - 1;
+    };
+    if constexpr (LN_CONSUMER) {
+        if (p.ln_stats) {
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl)
+                row_mu_rstd(p.ln_stats, p.ln_parts, slot_row(sl), p.ln_dim, p.ln_eps, amu[sl], ars[sl]);
+        }
+    }
+    if constexpr (EPI == EPI_BIAS_RES) {
+        if (p.r_stats) {
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl)
+                row_mu_rstd(p.r_stats, p.r_parts, slot_row(sl), p.ln_dim, p.ln_eps, rmu[sl], rrs[sl]);
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) { osum[sl] = 0.f; osq[sl] = 0.f; }
+    }
+    // every wave issues exactly PIECES loads per chunk (the statistics loads above are younger: waiting for
+    // vmcnt <= PIECES still means chunk 0 has landed)
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -312,10 +360,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int nw = n0 + wave * WN;
     if constexpr (EPI == EPI_OUT_T) {
         // natural operand order: rows = output channels m, cols = tokens n; stored transposed into [B, C_total, 1, T]
-        auto put = [&](int m, int n, float v) {
+        // LN fold: the normalised operand is the token (column) side; a lane's columns are fixed per column block
+        constexpr int NCOL = M32 ? NCB32 + NCB : NCB;
+        float cmu[NCOL], crs[NCOL];
+        if (p.ln_stats) {
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                int n;
+                if constexpr (M32) n = (c < NCB32) ? nw + c * 32 + li32 : nw + (c - NCB32) * 16 + li;
+                else n = nw + c * 16 + li;
+                n = n < p.N ? n : p.N - 1;
+                row_mu_rstd(p.ln_stats, p.ln_parts, n, p.ln_dim, p.ln_eps, cmu[c], crs[c]);
+            }
+        }
+        auto put = [&](int m, int n, float v, int cslot) {
             if (m >= p.M || n >= p.N) return;
             const int b = n / p.S, tok = n % p.S;
             if (tok == 0) return;
+            if (p.ln_stats) v = (v - cmu[cslot] * p.ln_c[m]) * crs[cslot];
             p.C[((size_t)b * p.C_total + p.ch_off + m) * p.T + (tok - 1)] = v + p.bias[m];
         };
         if constexpr (M32) {
@@ -325,25 +387,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 for (int cb = 0; cb < NCB32; ++cb)
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        put(m0 + rb * 32 + 8 * (q >> 2) + 4 * lg32 + (q & 3), nw + cb * 32 + li32, acc32[rb * NCB32 + cb][q]);
+                        put(m0 + rb * 32 + 8 * (q >> 2) + 4 * lg32 + (q & 3), nw + cb * 32 + li32, acc32[rb * NCB32 + cb][q], cb);
 #pragma unroll
             for (int c = 0; c < NCB; ++c)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) put(m0 + 128 + lg * 4 + q, nw + c * 16 + li, acc16[c][q]);
+                for (int q = 0; q < 4; ++q) put(m0 + 128 + lg * 4 + q, nw + c * 16 + li, acc16[c][q], NCB32 + c);
         } else {
 #pragma unroll
             for (int r = 0; r < NRB; ++r)
 #pragma unroll
                 for (int c = 0; c < NCB; ++c)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) put(m0 + r * 16 + lg * 4 + q, nw + c * 16 + li, acc16[r * NCB + c][q]);
+                    for (int q = 0; q < 4; ++q) put(m0 + r * 16 + lg * 4 + q, nw + c * 16 + li, acc16[r * NCB + c][q], c);
         }
     } else {
         // swapped operand order: a lane holds C[m][nb .. nb+3].  FULL: the launcher proved M % 144 == 0,
         // N % BN == 0 and 16-byte alignment of C / R / bias / tables, so the hot instantiation carries no edge
         // masks and only 16-byte accesses.
         const bool vec_ok = FULL || ((p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0));
-        auto emit = [&](int m, int nb, f32x4 a) {
+        auto emit = [&](int m, int nb, f32x4 a, int sl) {
             if (!FULL && (m >= p.M || nb >= p.N)) return;
             if constexpr (EPI == EPI_BIAS) {
                 if (ksplit > 1) {      // raw partial tile; ld_partial is a multiple of 4 and covers N rounded up
@@ -359,22 +421,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 for (int q = 0; q < 4; ++q) bias4[q] = (nb + q < p.N) ? p.bias[nb + q] : 0.f;
             }
             f32x4 v;
+            bool folded = false;
+            if constexpr (LN_CONSUMER) {
+                if (p.ln_stats) {       // (acc - mu c_n) rstd + d_n ; d_n arrives as the bias
+                    folded = true;
+                    f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FULL) {
+                        c4 = *reinterpret_cast<const f32x4*>(p.ln_c + nb);
+                    } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = a[q] + bias4[q];
+                        for (int q = 0; q < 4; ++q) c4[q] = (nb + q < p.N) ? p.ln_c[nb + q] : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (a[q] - amu[sl] * c4[q]) * ars[sl] + bias4[q];
+                }
+            }
+            if (!folded) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = a[q] + bias4[q];
+            }
             if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
             }
             if constexpr (EPI == EPI_BIAS_RES) {
                 const float* rp = p.R + (size_t)m * p.ldr + nb;
+                f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (FULL || (vec_ok && (p.ldr % 4 == 0) && (((uintptr_t)p.R & 15) == 0))) {
-                    const f32x4 rr = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += rr[q];
+                    rr = *reinterpret_cast<const f32x4*>(rp);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (nb + q < p.N) v[q] += rp[q];
+                        if (nb + q < p.N) rr[q] = rp[q];
+                }
+                if (p.r_stats) {        // the residual is LN(raw): normalise it on the fly
+                    f32x4 g4 = f32x4{0.f, 0.f, 0.f, 0.f}, b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FULL) {
+                        g4 = *reinterpret_cast<const f32x4*>(p.r_gamma + nb);
+                        b4 = *reinterpret_cast<const f32x4*>(p.r_beta + nb);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (nb + q < p.N) { g4[q] = p.r_gamma[nb + q]; b4[q] = p.r_beta[nb + q]; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr[q] = (rr[q] - rmu[sl]) * rrs[sl] * g4[q] + b4[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += rr[q];
+                if constexpr (LN_PRODUCER) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (FULL || nb + q < p.N) { osum[sl] += v[q]; osq[sl] += v[q] * v[q]; }
                 }
             }
             if constexpr (EPI == EPI_QKV) {
@@ -416,16 +514,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     for (int qq = 0; qq < 4; ++qq) {
                         const f32x16& a = acc32[rb * NCB32 + cb];
                         emit(m0 + rb * 32 + li32, nw + cb * 32 + 8 * qq + 4 * lg32,
-                             f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]});
+                             f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]}, rb);
                     }
             // acc16[c][r] = C[m0 + 128 + li][nw + c*16 + 4*lg + r]
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) emit(m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c]);
+            for (int c = 0; c < NCB; ++c) emit(m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c], 4);
         } else {
 #pragma unroll
             for (int c = 0; c < NCB; ++c)
 #pragma unroll
-                for (int r = 0; r < NRB; ++r) emit(m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c]);
+                for (int r = 0; r < NRB; ++r) emit(m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c], r);
+        }
+        if constexpr (LN_PRODUCER) {
+            if (p.out_stats) {
+                // a row's columns of this tile live in the 4 lanes (li, lg = 0..3) of each of the 4 waves: two shuffles,
+                // then the waves meet in LDS (a zone past the staging buffers and the DMA landing zone)
+                float* part = lds_dummy + 512;                  // [4 waves][BM][2]
+#pragma unroll
+                for (int sl = 0; sl < NSLOT; ++sl) {
+                    float a = osum[sl], b = osq[sl];
+                    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                    if (lg == 0) { part[(wave * BM + sl * 16 + li) * 2] = a; part[(wave * BM + sl * 16 + li) * 2 + 1] = b; }
+                }
+                __syncthreads();
+                if (tid < BM && m0 + tid < p.M) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { a += part[(w * BM + tid) * 2]; b += part[(w * BM + tid) * 2 + 1]; }
+                    // one slot per 64 columns whatever BN the launcher picked: this tile fills its first slot and
+                    // zeroes the others it covers
+                    float* o = p.out_stats + ((size_t)(m0 + tid) * p.out_parts + (n0 / 64)) * 2;
+                    o[0] = a; o[1] = b;
+#pragma unroll
+                    for (int k = 1; k < BN / 64; ++k)
+                        if (n0 / 64 + k < p.out_parts) { o[2 * k] = 0.f; o[2 * k + 1] = 0.f; }
+                }
+            }
         }
     }
     if constexpr (VAR == 7) {
@@ -484,6 +609,7 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     // 160 KiB LDS pins the residency to one.
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + lds_pad;
     lds += 2048;                           // landing zone of the dummy DMA pieces
+    lds += 4 * BM * 2 * sizeof(float);     // row-stat exchange of the LayerNorm-producing epilogue
     static const bool occ2 = getenv("ROHM_GEMM_OCC2") != nullptr;      // diagnostics: allow two workgroups per CU
     if (lds < 84 * 1024 && !occ2) lds = 84 * 1024;
     static bool attr_set[64] = {};
@@ -522,6 +648,7 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
     if (EPI == EPI_BIAS_RES) full = full && (p.ldr % 4 == 0) && al16(p.R);
     if (EPI == EPI_EMBED) full = full && (p.ldtab % 4 == 0) && (p.ldtab0 % 4 == 0) && al16(p.tab) && al16(p.tab0);
     if (EPI == EPI_QKV) full = full && (p.qcols % 4 == 0);
+    full = full && al16(p.ln_c) && al16(p.r_gamma) && al16(p.r_beta);      // 16-byte loads of the LayerNorm vectors
     if (EPI == EPI_OUT_T || (VAR != 0 && VAR != 7)) full = false;
     if (p.conv_taps > 0) {
         if constexpr (EPI == EPI_BIAS && VAR == 0 && BN <= 128) {
@@ -580,6 +707,7 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
         const int cand[5] = {384, 256, 192, 128, 64};
         for (int bn : cand) {
             if (bn > 64 && p.N % bn != 0) continue;
+            if (p.out_stats && bn > 128) continue;      // the row-stat epilogue exists for the 16x16 layouts only
             const long tiles = (long)tm * ((p.N + bn - 1) / bn);
             const long cost = ((tiles + want - 1) / want) * (bn + 24);
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bn; }
@@ -603,6 +731,13 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     ROHM_ARG_CHECK(p.lda % 4 == 0 && p.ldw % 4 == 0, "gemm: lda/ldw must be multiples of 4 floats");
     ROHM_ARG_CHECK(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "gemm: A/W must be 16-byte aligned");
     ROHM_ARG_CHECK(p.M > 0 && p.N > 0, "gemm: empty problem");
+    if (p.out_stats) ROHM_ARG_CHECK(epi == EPI_BIAS_RES && p.out_parts == (p.N + 63) / 64 && p.out_parts <= 8 &&
+                                        p.out_parts % 2 == 0, "gemm: bad row-stat request");
+    ROHM_ARG_CHECK((!p.ln_stats || (p.ln_parts <= 8 && p.ln_parts % 2 == 0)) && (!p.r_stats || (p.r_parts <= 8 && p.r_parts % 2 == 0)),
+                   "gemm: LayerNorm folding supports 2..8 statistic slots (64 columns each)");
+    if (p.ln_stats) ROHM_ARG_CHECK((epi == EPI_QKV || epi == EPI_BIAS_GELU || epi == EPI_OUT_T) && p.ln_c && p.ln_dim > 0,
+                                   "gemm: LayerNorm folding needs ln_c / ln_dim and a supporting epilogue");
+    if (p.r_stats) ROHM_ARG_CHECK(epi == EPI_BIAS_RES && p.r_gamma && p.r_beta && p.ln_dim > 0, "gemm: bad residual LN");
     if (p.ksplit > 1) {
         ROHM_ARG_CHECK(epi == EPI_BIAS, "gemm: split-K supports the plain bias epilogue only");
         ROHM_ARG_CHECK(p.partial && p.ld_partial % 4 == 0 && p.ld_partial >= ((p.N + 3) / 4) * 4 &&

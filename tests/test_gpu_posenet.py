@@ -36,7 +36,11 @@ def make_diffusion(steps):
     return create_gaussian_diffusion(Args, gdp, SpacedDiffusionPoseNet, steps, '', device=DEV)
 
 
-def test_forward_vs_reference_golden():
+@pytest.mark.parametrize('ln_fold', ['0', '1'])
+def test_forward_vs_reference_golden(ln_fold, monkeypatch):
+    """ln_fold = '1': the opt-in path with LayerNorm folded into the surrounding GEMMs (csrc/posenet.hip) must meet
+    the same bar as the default path with the separate LayerNorm kernel."""
+    monkeypatch.setenv('ROHM_POSENET_LNFOLD', ln_fold)
     g = golden('posenet_forward.npz')
     net, _ = make_posenet(int(g['weight_seed']))
     x, c = seeded(int(g['x_seed']), 2, 294, 1, 143), seeded(int(g['cond_seed']), 2, 294, 1, 143)
