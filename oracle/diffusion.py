@@ -40,6 +40,7 @@ def tables(betas, spaced=True):
     ac_prev = np.append(1.0, ac[:-1])
     var = betas * (1.0 - ac_prev) / (1.0 - ac)
     return {
+        'alphas_cumprod': ac, 'alphas_cumprod_prev': ac_prev,
         'variance': var,
         'log_variance': np.log(np.append(var[1], var[1:])),
         'coef1': betas * np.sqrt(ac_prev) / (1.0 - ac),
@@ -81,3 +82,26 @@ def p_sample_loop(model_fn, x_T, step_noise, tab, indices, guidance=None, grad_t
     if return_all:
         return trace
     return x0 if early_stop else x
+
+
+def ddim_step(x, pred_xstart, noise, tab, i, eta=0.0, dtype=torch.float32):
+    """The body of `ddim_sample` (gaussian_diffusion_posenet.py:693-712): eps re-derived from the x0 prediction
+    (:299-303), DDIM eq. 12, float32 arithmetic on table entries cast with .float() like `_extract_into_tensor`."""
+    ab, ab_prev = _f(tab['alphas_cumprod'], i, dtype), _f(tab['alphas_cumprod_prev'], i, dtype)
+    r = _f(np.sqrt(1.0 / tab['alphas_cumprod']), i, dtype)
+    m = _f(np.sqrt(1.0 / tab['alphas_cumprod'] - 1), i, dtype)
+    eps = (r * x - pred_xstart) / m
+    sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab)) * torch.sqrt(1 - ab / ab_prev)
+    mean_pred = pred_xstart * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
+    nonzero = 0.0 if i == 0 else 1.0
+    return mean_pred + nonzero * sigma * noise
+
+
+def ddim_sample_loop(model_fn, x_T, step_noise, tab, indices, eta=0.0, dtype=torch.float32):
+    """`ddim_sample_loop` (:775-822) with injected noise (step_noise may be None when eta == 0)."""
+    x = x_T.to(dtype)
+    for step, i in enumerate(indices):
+        x0 = model_fn(x, i)
+        nz = step_noise[step].to(dtype) if step_noise is not None else torch.zeros_like(x)
+        x = ddim_step(x, x0, nz, tab, i, eta, dtype)
+    return x

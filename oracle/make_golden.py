@@ -79,6 +79,26 @@ def golden_rederive(ref):
                         **{'nan_' + k: v for k, v in prm_nan.items()})
 
 
+def golden_ddim(ref):
+    """The reference's `ddim_sample` cannot be called as written (it omits `batch` when it calls p_mean_variance,
+    gaussian_diffusion_posenet.py:681-688, and no driver reaches it).  Its BODY -- the DDIM update -- runs fine once
+    p_mean_variance is stubbed to return a given pred_xstart: that pins the update formula."""
+    betas = ref.gd_posenet.get_named_beta_schedule('cosine', 1000)
+    gd = ref.gd_posenet.GaussianDiffusionPoseNet(betas=betas, model_mean_type=ref.gd_posenet.ModelMeanType.START_X,
+                                                 model_var_type=ref.gd_posenet.ModelVarType.FIXED_SMALL,
+                                                 loss_type=ref.gd_posenet.LossType.MSE, device='cpu')
+    x, x0 = seeded(501, 2, 16, 1, 9), seeded(502, 2, 16, 1, 9)      # elementwise formula: a small tensor pins it
+    gd.p_mean_variance = lambda model, x_, t_, **kw: {'pred_xstart': x0}
+    out = {}
+    for k, (i, eta) in enumerate([(999, 0.0), (500, 0.0), (37, 0.7), (1, 1.0), (0, 1.0)]):
+        torch.manual_seed(600 + k)
+        r = gd.ddim_sample(None, x, torch.tensor([i, i]), eta=eta)
+        out[f'case{k}'] = r['sample'].numpy()
+        out[f'case{k}_i'], out[f'case{k}_eta'], out[f'case{k}_seed'] = i, eta, 600 + k
+    np.savez_compressed(os.path.join(OUT, 'ddim.npz'), x_seed=501, x0_seed=502, n_cases=5, **out)
+    print('ddim.npz', os.path.getsize(os.path.join(OUT, 'ddim.npz')))
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -107,6 +127,9 @@ def golden_metrics():
 def main():
     if sys.argv[1:] == ['metrics']:
         return golden_metrics()
+    if sys.argv[1:] == ['ddim']:
+        warnings.filterwarnings('ignore')
+        return golden_ddim(refload.load())
     if sys.argv[1:] == ['rederive']:
         warnings.filterwarnings('ignore')
         return golden_rederive(refload.load())
@@ -193,6 +216,7 @@ def main():
                         r6_seed=301, rotmat=Rm.numpy(), angle_axis=aa.numpy())
     golden_rederive(ref)
     golden_metrics()
+    golden_ddim(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

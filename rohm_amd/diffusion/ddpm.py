@@ -283,15 +283,90 @@ class DDPMSampler:
         batch['x_t'] = x
         return x0_last if early_stop else x
 
+    # ------------------------------------------------------------------ DDIM
+    def ddim_coefficients(self, i, eta=0.0):
+        """DDIM eq. 12 with the x0 parameterisation (gaussian_diffusion_posenet.py:693-712): with
+        eps = (sqrt(1/ab) x_t - x0) / sqrt(1/ab - 1) the update x_{t-1} = sqrt(ab_prev) x0 + sqrt(1 - ab_prev - s^2) eps
+        + s z  is affine in (x0, x_t):  returns (c1, c2, s) with x_{t-1} = c1 x0 + c2 x_t + s z  (s = 0 at i = 0)."""
+        # The reference evaluates sigma and sqrt(1 - ab_prev - sigma^2) in float32 on table entries cast with .float()
+        # (`_extract_into_tensor`); near t = 0 the subtraction cancels and float32 rounding moves the result by ~1e-3, so
+        # the same float32 steps are taken here (bit-level agreement with the reference body, tests/golden/ddim.npz).
+        f = np.float32
+        ab, ab_prev = f(self.alphas_cumprod[i]), f(self.alphas_cumprod_prev[i])
+        r, m = f(np.sqrt(1.0 / self.alphas_cumprod[i])), f(np.sqrt(1.0 / self.alphas_cumprod[i] - 1))
+        one = f(1.0)
+        sigma = f(eta) * np.sqrt((one - ab_prev) / (one - ab)) * np.sqrt(one - ab / ab_prev)
+        c = np.sqrt(np.maximum(one - ab_prev - sigma * sigma, f(0.0)))
+        c1 = float(np.sqrt(ab_prev)) - float(c) / float(m)
+        c2 = float(c) * float(r) / float(m)
+        return f(c1), f(c2), f(sigma if i != 0 else 0.0)
+
+    def ddim_sample(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                    eta=0.0):
+        """One DDIM step.  (The reference's `ddim_sample` cannot run -- it calls p_mean_variance without `batch`,
+        gaussian_diffusion_posenet.py:681-688 -- and no driver reaches it; the update formula is pinned to the body
+        of that function, tests/golden/ddim.npz.)"""
+        if cond_fn is not None:
+            raise NotImplementedError('cond_fn is unused by RoHM')
+        raw = getattr(model, 'model', model)
+        t_int = int(t[0])
+        if not bool((t == t_int).all()):
+            raise NotImplementedError('ddim_sample expects one timestep for the whole batch, as the loops produce')
+        with torch.no_grad():
+            batch['x_t'] = x
+            x0 = raw(batch, self._mapped(t))
+            noise = self._noise(None, x)
+            c1, c2, sg = self.ddim_coefficients(t_int, eta)
+            sample = ops.ddpm_step(x.contiguous(), x0, noise, float(c1), float(c2), float(sg))
+        return {'sample': sample, 'pred_xstart': x0}
+
+    def ddim_sample_loop(self, model, batch, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
+                         randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False):
+        """DDIM sampling run (gaussian_diffusion_posenet.py:775-822), device-resident: the affine DDIM update has the
+        shape of the DDPM one, so the fused `rohm_*_sample_loop` kernels run it with `ddim_coefficients`.  No
+        guidance (the reference's DDIM path never had any that worked)."""
+        if cond_fn_with_grad or cond_fn is not None or skip_timesteps or init_image is not None or dump_steps:
+            raise NotImplementedError('guidance / skip_timesteps / init_image / dump_steps are not supported with DDIM')
+        raw = getattr(model, 'model', model)
+        if device is None:
+            device = next(raw.parameters()).device
+        x = (noise if noise is not None else self._x_T(shape, device)).to(torch.float32).contiguous().clone()
+        cond = batch['cond'].detach().to(torch.float32).contiguous()
+        indices = self._indices(0, False)
+        with torch.no_grad():
+            pos = 0
+            while pos < len(indices):
+                n = min(self.fused_chunk, len(indices) - pos)
+                ts = indices[pos:pos + n]
+                coef = np.asarray([self.ddim_coefficients(i, eta) for i in ts], dtype=np.float32)
+                if eta == 0.0:
+                    nz = None
+                elif self.noise_source is not None:
+                    nz = torch.stack([self._noise(pos + k, x) for k in range(n)])
+                else:
+                    nz = torch.randn((n,) + tuple(x.shape), device=x.device, dtype=torch.float32)
+                raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz, want_x0_last=False,
+                                       batch=batch)
+                pos += n
+        batch['x_t'] = x
+        return x
+
     # ------------------------------------------------------------------ entry point
     def _eval(self, model, batch, shape, progress, clip_denoised, cond_fn_with_grad, grad_type, early_stop,
               timestep_respacing, compute_loss):
         if compute_loss:
             raise NotImplementedError('compute_loss=True needs the training losses, which are outside the '
                                       'inference hot path; the RoHM test drivers pass compute_loss=False')
+        if timestep_respacing[0:4] == 'ddim':
+            # the branch the reference left commented out (gaussian_diffusion_posenet.py:949-952): eta = 0 DDIM over
+            # the (already respaced) schedule of this object
+            if cond_fn_with_grad and grad_type is not None and self.supports_guidance:
+                raise NotImplementedError('test-time guidance is not defined for DDIM sampling in RoHM')
+            return None, self.ddim_sample_loop(model=getattr(model, 'model', model), batch=batch, shape=shape,
+                                               progress=progress, clip_denoised=clip_denoised, eta=0.0)
         if timestep_respacing != '':
-            raise NotImplementedError("only timestep_respacing='' reaches a sampler in RoHM "
-                                      '(gaussian_diffusion_posenet.py:943-955)')
+            raise NotImplementedError("timestep_respacing must be '' (ancestral sampling) or 'ddimN'")
         out = self.p_sample_loop(model=getattr(model, 'model', model), batch=batch, shape=shape, progress=progress,
                                  clip_denoised=clip_denoised, cond_fn_with_grad=cond_fn_with_grad,
                                  grad_type=grad_type, early_stop=early_stop)

@@ -98,3 +98,29 @@ def test_loop_early_stop_returns_pred_xstart():
     fn = lambda x, i: nets.posenet_forward(sd, x, cond, torch.full((1,), i, dtype=torch.int64))
     ref = odiff.p_sample_loop(fn, x_T, noises, tab, [999, 998, 997, 996, 995, 994], early_stop=True)
     assert max_abs(y.cpu(), ref) < 1e-3
+
+
+@pytest.mark.parametrize('eta', [0.0, 0.5])
+def test_ddim_loop_vs_oracle(eta):
+    """DDIM sampling on a 'ddim10' respaced schedule: fused HIP loop with the DDIM coefficients
+    against the oracle loop built on the reference's update body (tests/test_ddim_oracle.py pins it)."""
+    from rohm_amd.diffusion import gaussian_diffusion_posenet as gdp
+    from rohm_amd.diffusion.respace import SpacedDiffusionPoseNet, space_timesteps
+    from rohm_amd.utils.model_util import create_gaussian_diffusion
+    net, sd = make_posenet(21)
+    B, n = 2, 10
+    diff = create_gaussian_diffusion(Args, gdp, SpacedDiffusionPoseNet, 1000, f'ddim{n}', device=DEV)
+    assert diff.num_timesteps == n
+    cond = seeded(5, B, 294, 1, 143)
+    x_T, noises = cpu_noise_sequence(77, (B, 294, 1, 143), n)
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    _, y = diff.eval_losses(model=net, batch={'cond': cond.to(DEV)}, shape=[B, 294, 1, 143], progress=False,
+                            clip_denoised=False, timestep_respacing=f'ddim{n}', cond_fn_with_grad=False,
+                            compute_loss=False)
+    if eta != 0.0:
+        y = diff.ddim_sample_loop(net, {'cond': cond.to(DEV)}, [B, 294, 1, 143], eta=eta)
+    keep = sorted(space_timesteps(1000, f'ddim{n}'))
+    tab = odiff.tables(odiff.respaced_betas(odiff.cosine_betas(1000), keep), spaced=False)
+    fn = lambda x, i: nets.posenet_forward(sd, x, cond, torch.full((B,), keep[i], dtype=torch.int64))
+    ref = odiff.ddim_sample_loop(fn, x_T, noises, tab, list(range(n))[::-1], eta=eta)
+    assert max_abs(y.cpu(), ref) < 1e-3
