@@ -236,10 +236,12 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--ddpm-steps', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['posenet', 'scheme'], default='posenet',
+    ap.add_argument('--workload', choices=['posenet', 'scheme', 'prox'], default='posenet',
                     help="'posenet' = BASELINE.json configs[1] (the headline metric); 'scheme' = configs[2]: the full "
                          "two-iteration RoHM scheme per clip (TrajNet 100 -> PoseNet 1000 + skating guidance -> "
-                         "TrajControl 100 -> PoseNet 1000 + skating guidance), extra measurement, not the headline")
+                         "TrajControl 100 -> PoseNet 1000 + skating guidance); 'prox' = configs[3]: PoseNet with the PROX "
+                         "test-time guidance (2-D re-projection + skating on t <= 100, early stop at 980 steps); both are "
+                         "extra measurements, not the headline")
     ap.add_argument('--profile-stride', type=int, default=16)
     args = ap.parse_args()
 
@@ -266,20 +268,37 @@ def main():
     B, S = args.batch, args.ddpm_steps
     if args.workload == 'scheme':
         return scheme_bench(args, world, rank, dev, dist)
-    net = PoseNet(_Dataset(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
-                  body_model_path=torch.nn.Identity(), device=dev)
-    net.load_state_dict(synth.posenet_state_dict(0), strict=True)
+    prox = args.workload == 'prox'
+    ds = _Dataset()
+    body = torch.nn.Identity()
+    if prox:       # SURVEY.md §8(d) cfg 4: guidance needs a body model, dataset statistics and the camera
+        from rohm_amd.body_model import SMPLXLayer
+        body = SMPLXLayer.from_tensors(synth.synthetic_smplx_tensors(0)).to(dev)
+        ds.Mean, ds.Std = synth.synthetic_stats(1)
+        ds.cam_R, ds.cam_t = torch.tensor(synth.SYNTH_CAM_R), torch.tensor(synth.SYNTH_CAM_T)
+    net = PoseNet(ds, 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                  body_model_path=body, device=dev)
+    net.load_state_dict(synth.posenet_state_dict(0), strict=not prox)
     net = net.to(dev).eval()
     diffusion = create_gaussian_diffusion(_Args, gdp, SpacedDiffusionPoseNet, S, '', device=dev)
     cond = synthetic_cond(B, dev, seed=1000 + rank)
+    extra = {}
+    if prox:
+        cond = synth.plausible_motion(1000 + rank, B, 143, ds.Mean, ds.Std).to(dev)
+        extra = {k: v.to(dev) for k, v in synth.synthetic_camera_batch(rank, B).items()}
     torch.manual_seed(rank)
     from rohm_amd import sharding
 
     def one_pass():
-        batch = {'cond': cond}
-        _, x0 = diffusion.eval_losses(model=net, batch=batch, shape=[B, 294, 1, 143], progress=False,
-                                      clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
-                                      compute_loss=False)
+        batch = {'cond': cond, **extra}
+        if prox:
+            _, x0 = diffusion.eval_losses(model=net, batch=batch, shape=[B, 294, 1, 143], progress=False,
+                                          clip_denoised=False, timestep_respacing='', cond_fn_with_grad=True,
+                                          grad_type='prox', early_stop=True, compute_loss=False)
+        else:
+            _, x0 = diffusion.eval_losses(model=net, batch=batch, shape=[B, 294, 1, 143], progress=False,
+                                          clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
+                                          compute_loss=False)
         if world > 1:
             sharding.gather_clips(x0, world * B)      # the path's only exchange: finished clips, RCCL all-gather
         return x0
@@ -303,7 +322,8 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert torch.isfinite(out).all(), 'non-finite samples'
+    finite = bool(torch.isfinite(out).all())
+    assert finite or prox, 'non-finite samples'
 
     if rank == 0:
         clips = world * B * args.steps
@@ -319,14 +339,18 @@ def main():
                        'time_share': round(v['total_ms'] / all_ms, 4)}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
         rec = {
-            'metric': 'denoised 145-frame clips/sec @1000 DDPM steps' if S == 1000 else
-                      f'denoised 145-frame clips/sec @{S} DDPM steps',
+            'metric': ('denoised 145-frame clips/sec, PROX guidance (2-D re-projection + skating on t <= 100), 980 of '
+                       f'{S} DDPM steps (early stop)') if prox else
+                      ('denoised 145-frame clips/sec @1000 DDPM steps' if S == 1000 else
+                       f'denoised 145-frame clips/sec @{S} DDPM steps'),
             'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'PoseNet {S}-step DDPM (x0-pred, fixed-small var), batch={B} synthetic '
                                    f'145-frame clips per GPU (T=143 -> 144 tokens, d=512, 8 layers), no guidance '
                                    f'[BASELINE.json configs[1]]',
+                       'guidance': 'prox [BASELINE.json configs[3]]: synthetic camera + OpenPose-style keypoints, weights as '
+                                   f'the reference (3e5 / 1e5); finite_output={finite}' if prox else 'none',
                        'clips_per_gpu': B, 'ddpm_steps': S, 'sharding': f'{world} x {B} independent clips, '
                        'all-gather of results only' if world > 1 else 'single GPU', 'weights': 'random (seed 0)'},
             'model_tflops': clips * S * POSENET_GFLOP_PER_CLIP_STEP * 1e-3 / elapsed,
@@ -343,7 +367,7 @@ def main():
                 'kernels': kernels,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not prox:
             rec['cpu_baseline'] = cpu_baseline()
         print(json.dumps(rec), flush=True)
     if world > 1:

@@ -141,3 +141,47 @@ def amass_iterations(traj_stage, pose_stage, batch_traj, batch_pose, stats_traj,
             batch_pose['motion_repr_clean'] = batch_pose['motion_repr_clean'].permute(0, 2, 1).unsqueeze(-2)
         val_pose = pose_stage(it, batch_pose)                                               # :377-386
     return val_pose, val_traj, recs
+
+
+def prox_iterations(traj_stage, pose_stage, batch_traj, batch_pose, stats_traj, stats_pose, body, args):
+    """The loop of test_prox_egobody.py:213-313: the noisy representation is the carrier, the visibility mask
+    (`mask_vec_vis` [B, T+2, 294], :291-294) replaces the mask schemes.  Same stage callables as `amass_iterations`."""
+    tfd = 13 if args.repr_abs_only else 22
+    B, T = batch_traj['cond'].shape[:2]
+    val_pose = val_traj = None
+    recs = []
+    for it in range(args.sample_iter):
+        if it > 0:                                                                          # :230-234
+            cc = torch.zeros(B, T, 272)
+            cc[:, 0:-1] = val_pose[:, :, 0].permute(0, 2, 1)[:, :, -272:]
+            cc[:, -1] = cc[:, -2].clone()
+            batch_traj['control_cond'] = cc
+        val_traj = traj_stage(it, batch_traj)
+        rec = merge_traj(batch_traj['motion_repr_noisy'], val_traj, args.repr_abs_only, tfd)   # :245-254
+        if it == 0:
+            batch_traj['motion_repr_noisy'] = rec
+        if it < args.sample_iter - 1 and not args.iter2_cond_noisy_traj:
+            batch_traj['cond'] = val_traj
+        traj_rec_full = torch.from_numpy(RD.rederive_traj(rec, *stats_traj, *stats_pose, body))   # :258-287
+        recs.append(traj_rec_full)
+        if it == 0:                                                                         # :290-291
+            batch_pose['motion_repr_noisy'] = batch_pose['motion_repr_noisy'][:, 0:-1]
+        if args.iter2_cond_noisy_pose:                                                      # :292-300
+            cond = batch_pose['motion_repr_noisy'].clone()
+            if it > 0:
+                cond = cond[:, :, 0].permute(0, 2, 1)
+        elif it == 0:
+            cond = batch_pose['motion_repr_noisy'].clone()
+        else:
+            cond = val_pose[:, :, 0].permute(0, 2, 1)
+        cond = cond.contiguous()
+        cond[:, :, 0:22] = traj_rec_full                                                    # :302
+        mask_iter_num = args.sample_iter if args.iter2_cond_noisy_pose else 1
+        if it < mask_iter_num:                                                              # :305-309
+            cond = cond * batch_pose['mask_vec_vis'][:, 0:-2, :]
+            cond[:, :, -4:] = 0.
+        if it == 0:
+            batch_pose['motion_repr_noisy'] = batch_pose['motion_repr_noisy'].permute(0, 2, 1).unsqueeze(-2)
+        batch_pose['cond'] = cond.permute(0, 2, 1).unsqueeze(-2)
+        val_pose = pose_stage(it, batch_pose)
+    return val_pose, val_traj, recs

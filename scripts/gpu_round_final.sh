@@ -10,6 +10,7 @@ python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $OUT/pytest_gpu.txt
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -2 $OUT/bench.err; cat $OUT/bench.json
 python bench.py --workload scheme --batch 32 --steps 1 --warmup 1 > $OUT/bench_scheme_b32.json 2>> $OUT/bench.err
 python bench.py --batch 32 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_b32.json 2>> $OUT/bench.err
+python bench.py --workload prox --batch 32 --steps 1 --warmup 1 > $OUT/bench_prox_b32.json 2>> $OUT/bench.err
 python scripts/bench_stages.py > $OUT/stages.json 2>> $OUT/bench.err
 export TMPDIR=/tmp
 cd /tmp

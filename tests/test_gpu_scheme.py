@@ -122,6 +122,50 @@ def test_glue_with_stub_stages(kw):
     assert gbp['motion_repr_clean'].shape == (B, 294, 1, 143) and gbt['motion_repr_noisy'].shape == (B, 144, 294)
 
 
+@pytest.mark.parametrize('kw', [dict(sample_iter=3), dict(sample_iter=2, iter2_cond_noisy_pose=False, iter2_cond_noisy_traj=False)])
+def test_prox_glue_with_stub_stages(kw):
+    """The PROX / EgoBody loop (test_prox_egobody.py:213-313; cfg 5 uses sample_iter = 3) with stub stages."""
+    from rohm_amd import inference as INF
+    from rohm_amd.body_model import SMPLXLayer
+    args = _args(**kw)
+    B = 2
+    body_t = synth.synthetic_smplx_tensors(0)
+    s_traj, s_pose = synth.synthetic_stats(0), synth.synthetic_stats(1)
+    bt, bp = _batches(B, body_t, s_traj, s_pose, 150)
+    g = np.random.Generator(np.random.PCG64(9))
+    bp['mask_vec_vis'] = torch.from_numpy((g.uniform(size=(B, 145, 294)) < 0.8).astype(np.float32))
+    n_it = args.sample_iter
+    traj_out = [synth.walking_motion(160 + i, B, 144, *s_traj, body_t)[:, :, ABS].contiguous() for i in range(n_it)]
+    pose_out = [synth.walking_motion(170 + i, B, 143, *s_pose, body_t).permute(0, 2, 1).unsqueeze(2).contiguous()
+                for i in range(n_it)]
+    olog = []
+
+    def o_traj(it, batch):
+        olog.append(('traj', {k: batch[k].clone() for k in ('cond', 'control_cond') if k in batch}))
+        return traj_out[it]
+
+    def o_pose(it, batch):
+        olog.append(('pose', {'cond': batch['cond'].clone()}))
+        return pose_out[it]
+    ref_pose, ref_traj, ref_recs = OS.prox_iterations(o_traj, o_pose, _clone(bt), _clone(bp), s_traj, s_pose,
+                                                      G.BodyModel(body_t), args)
+    glog = []
+    diffs = {'trajnet': StubDiffusion([traj_out[0].to(DEV)], glog, 'traj'),
+             'trajnet_control': StubDiffusion([t.to(DEV) for t in traj_out[1:]], glog, 'traj'),
+             'posenet': StubDiffusion([p.to(DEV) for p in pose_out], glog, 'pose')}
+    pose, traj, recs = INF.run_prox_iterations(args, {'trajnet': None, 'trajnet_control': None, 'posenet': None}, diffs,
+                                               _clone(bt, DEV), _clone(bp, DEV), TrajDataset(*s_traj),
+                                               PoseDataset(*s_pose), SMPLXLayer.from_tensors(body_t).to(DEV))
+    assert [n for n, _ in glog] == [n for n, _ in olog]
+    for (n, a), (_, b) in zip(glog, olog):
+        assert a.keys() == b.keys(), n
+        for k in a:
+            assert a[k].shape == b[k].shape and max_abs(a[k], b[k].float()) < 2e-5, (n, k)
+    for a, b in zip(recs, ref_recs):
+        assert max_abs(a.cpu(), b.float()) < 2e-5
+    assert torch.equal(pose.cpu(), ref_pose) and torch.equal(traj.cpu(), ref_traj)
+
+
 class NoiseFeed:
     def __init__(self, runs):
         self.runs, self.k = runs, -1
