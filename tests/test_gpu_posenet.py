@@ -124,3 +124,32 @@ def test_ddim_loop_vs_oracle(eta):
     fn = lambda x, i: nets.posenet_forward(sd, x, cond, torch.full((B,), keep[i], dtype=torch.int64))
     ref = odiff.ddim_sample_loop(fn, x_T, noises, tab, list(range(n))[::-1], eta=eta)
     assert max_abs(y.cpu(), ref) < 1e-3
+
+
+def test_full_1000_step_loop_vs_oracle():
+    """The headline configuration end to end on one clip: 1000 ancestral steps through `eval_losses` (fused HIP loop)
+    against the CPU oracle with the same injected noise -- the bar of BASELINE.json's north_star (1e-3 on the output
+    representation, sub-millimetre MPJPE on the joints recovered from it)."""
+    from rohm_amd.body_model import SMPLXLayer
+    from rohm_amd.data_loaders.motion_representation import joints_from_repr
+    net, sd = make_posenet(31)
+    B, S = 1, 1000
+    diff = make_diffusion(S)
+    mean, std = synth.synthetic_stats(1)
+    cond = synth.plausible_motion(7, B, 143, mean, std)
+    x_T, noises = cpu_noise_sequence(99, (B, 294, 1, 143), S)
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    _, y = diff.eval_losses(model=net, batch={'cond': cond.to(DEV)}, shape=[B, 294, 1, 143], progress=False,
+                            clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+    torch.set_num_threads(16)
+    fn = lambda x, i: nets.posenet_forward(sd, x, cond, torch.full((B,), i, dtype=torch.int64))
+    with torch.no_grad():
+        ref = odiff.p_sample_loop(fn, x_T, noises, odiff.tables(odiff.cosine_betas(S)), list(range(S))[::-1])
+    err = max_abs(y.cpu(), ref)
+    layer = SMPLXLayer.from_tensors(synth.synthetic_smplx_tensors(0)).to(DEV)
+    j_hip = joints_from_repr(y, 'smplx_params', layer, stats=(mean, std), layout='bc1t')
+    j_ref = joints_from_repr(ref.to(DEV), 'smplx_params', layer, stats=(mean, std), layout='bc1t')
+    mpjpe_mm = float((j_hip - j_ref).norm(dim=-1).mean()) * 1000.0
+    print(f'1000-step loop: max|HIP - oracle| = {err:.3e}, MPJPE = {mpjpe_mm:.4f} mm')
+    assert err < 1e-3, err
+    assert mpjpe_mm < 1.0, mpjpe_mm
