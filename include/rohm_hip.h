@@ -249,7 +249,8 @@ int rohm_smplx_forward(const rohm_smplx_t* h, const float* pose, int n_pose, int
 
 /* recover_from_repr_smpl (data_loaders/motion_representation.py:332-398) straight from the 294-channel
  * representation: joints [B,T,22,3].  mode 0 = 'smplx_params' (:373-398, joints[:, 0:22] of the body model incl.
- * transl; h required), mode 1 = 'joint_abs_traj' (:349-371; h may be NULL).  repr is addressed with strides as in
+ * transl; h required), mode 1 = 'joint_abs_traj' (:349-371; h may be NULL), mode 2 = 'joint_rel_traj' (:312-329: root
+ * angle / position as running sums of the per-frame velocities; h may be NULL).  repr is addressed with strides as in
  * rohm_traj_rederive; mean294/std294 de-normalise on the fly (both NULL = repr is already de-normalised). */
 int rohm_repr_joints(const rohm_smplx_t* h, const float* repr, long long in_stride_b, long long in_stride_t,
                      long long in_stride_c, const float* mean294, const float* std294, int B, int T, int mode,

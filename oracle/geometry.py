@@ -222,6 +222,37 @@ def joints_from_abs_traj(d):
     return torch.cat([r_pos.unsqueeze(-2), positions], dim=-2)
 
 
+def recover_root_rot_pos_rel(data):
+    """'rel' branch with up_axis='z' (motion_representation.py:312-329): the root angle is the running sum of the
+    rotation velocities of the EARLIER frames, the root position the running sum of the earlier frames' velocities
+    rotated back by qinv(q_t); height is absolute."""
+    rot_vel = data[..., 0]
+    ang = torch.zeros_like(rot_vel)
+    ang[..., 1:] = rot_vel[..., :-1]
+    ang = torch.cumsum(ang, dim=-1)
+    q = torch.zeros(data.shape[:-1] + (4,), dtype=data.dtype)
+    q[..., 0] = torch.cos(ang)
+    q[..., 3] = torch.sin(ang)
+    pos = torch.zeros(data.shape[:-1] + (3,), dtype=data.dtype)
+    pos[..., 1:, [0, 1]] = data[..., :-1, 1:3]
+    pos = qrot(qinv(q), pos)
+    pos = torch.cumsum(pos, dim=-2)
+    pos[..., 2] = data[..., 3]
+    return q, pos
+
+
+def joints_from_rel_traj(d):
+    """recover_mode='joint_rel_traj' (motion_representation.py:349-371) -> [B, T, 22, 3]."""
+    q, r_pos = recover_root_rot_pos_rel(torch.cat([d['root_rot_angle_vel'], d['root_l_vel'], d['root_height']], -1))
+    positions = d['local_positions'][..., 3:]
+    positions = positions.reshape(positions.shape[:-1] + (-1, 3))
+    positions = qrot(qinv(q[..., None, :]).expand(positions.shape[:-1] + (4,)), positions)
+    positions = positions.clone()
+    positions[..., 0] += r_pos[..., 0:1]
+    positions[..., 1] += r_pos[..., 1:2]
+    return torch.cat([r_pos.unsqueeze(-2), positions], dim=-2)
+
+
 def joints_from_smplx(d, body_model, return_verts=False, through_axis_angle=True):
     """recover_mode='smplx_params' (motion_representation.py:373-398) -> [B, T, 22, 3] (+ verts).
     `through_axis_angle=False` skips the R -> quaternion -> axis-angle -> Rodrigues round trip (what the HIP

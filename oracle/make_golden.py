@@ -99,6 +99,17 @@ def golden_ddim(ref):
     print('ddim.npz', os.path.getsize(os.path.join(OUT, 'ddim.npz')))
 
 
+def golden_rel(ref):
+    """recover_from_repr_smpl(recover_mode='joint_rel_traj') (used by test_trajnet.py:204 and the training losses)."""
+    from oracle import geometry as G
+    mean, std = synth.synthetic_stats(0)
+    x0 = synth.plausible_motion(3, 2, 143, mean, std)
+    full = x0[:, :, 0].permute(0, 2, 1) * torch.from_numpy(std) + torch.from_numpy(mean)
+    j_rel = ref.motion_repr.recover_from_repr_smpl(G.split_repr(full), recover_mode='joint_rel_traj', smplx_model=None)
+    np.savez_compressed(os.path.join(OUT, 'recover_rel.npz'), stats_seed=0, motion_seed=3, j_rel=j_rel.numpy())
+    print('recover_rel.npz', os.path.getsize(os.path.join(OUT, 'recover_rel.npz')))
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -127,6 +138,9 @@ def golden_metrics():
 def main():
     if sys.argv[1:] == ['metrics']:
         return golden_metrics()
+    if sys.argv[1:] == ['rel']:
+        warnings.filterwarnings('ignore')
+        return golden_rel(refload.load())
     if sys.argv[1:] == ['ddim']:
         warnings.filterwarnings('ignore')
         return golden_ddim(refload.load())
@@ -217,6 +231,7 @@ def main():
     golden_rederive(ref)
     golden_metrics()
     golden_ddim(ref)
+    golden_rel(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

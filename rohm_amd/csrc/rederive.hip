@@ -209,6 +209,53 @@ __global__ __launch_bounds__(64) void repr_joints_kernel(const float* __restrict
     }
 }
 
+// mode 2 = 'joint_rel_traj' (motion_representation.py:312-329,349-371): the root angle / position are RUNNING SUMS over
+// the earlier frames (torch.cumsum, float32, sequential) -- one workgroup per clip: thread 0 scans the T frames into
+// LDS in the reference's order, then one thread per frame places the local joints.
+constexpr int CH_ROOT_ANG_VEL = 1, CH_ROOT_VEL = 4;
+__global__ __launch_bounds__(256) void repr_joints_rel_kernel(const float* __restrict__ repr, long long isb, long long ist,
+                                                              long long isc, const float* __restrict__ mean,
+                                                              const float* __restrict__ stdv, float* __restrict__ out,
+                                                              int T) {
+    extern __shared__ __attribute__((aligned(16))) float sroot[];     // [T][4] = angle, x, y, (unused)
+    const int b = blockIdx.x;
+    const float* xb = repr + (size_t)b * isb;
+    auto ldc = [&](int t, int c) {
+        const float v = xb[(size_t)t * ist + (size_t)c * isc];
+        return mean ? add(mul(v, stdv[c]), mean[c]) : v;
+    };
+    if (threadIdx.x == 0) {
+        float ang = 0.f, px = 0.f, py = 0.f;
+        for (int t = 0; t < T; ++t) {
+            float vx = 0.f, vy = 0.f;
+            if (t > 0) {
+                ang = add(ang, ldc(t - 1, CH_ROOT_ANG_VEL));
+                vx = ldc(t - 1, CH_ROOT_VEL);
+                vy = ldc(t - 1, CH_ROOT_VEL + 1);
+            }
+            // r_pos increment = qrot(qinv(q_t), (vx, vy, 0)), q_t = (cos ang, 0, 0, sin ang); then cumsum
+            const float q[4] = {cosf(ang), 0.f, 0.f, -sinf(ang)};
+            const float v[3] = {vx, vy, 0.f};
+            float r[3];
+            qrot_rn(q, v, r);
+            px = add(px, r[0]);
+            py = add(py, r[1]);
+            sroot[t * 4] = ang; sroot[t * 4 + 1] = px; sroot[t * 4 + 2] = py;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float ang = sroot[t * 4];
+        const float pos[3] = {sroot[t * 4 + 1], sroot[t * 4 + 2], ldc(t, CH_ROOT_H)};
+        float* o = out + ((size_t)b * T + t) * NJ * 3;
+        o[0] = pos[0]; o[1] = pos[1]; o[2] = pos[2];
+        for (int j = 1; j < NJ; ++j) {
+            const float v[3] = {ldc(t, CH_LOCAL + 3 * j), ldc(t, CH_LOCAL + 3 * j + 1), ldc(t, CH_LOCAL + 3 * j + 2)};
+            abs_joint(ang, pos, v, o + j * 3);
+        }
+    }
+}
+
 }  // namespace rohm
 
 using namespace rohm;
@@ -217,12 +264,19 @@ extern "C" int rohm_repr_joints(const rohm_smplx_t* h, const float* repr, long l
                                 long long in_stride_c, const float* mean294, const float* std294, int B, int T, int mode,
                                 float* joints, rohm_stream_t stream) {
     ROHM_ARG_CHECK(repr && joints, "repr_joints: null argument");
-    ROHM_ARG_CHECK(mode == 1 || h, "repr_joints: mode 0 ('smplx_params') needs a body-model handle");
-    ROHM_ARG_CHECK(mode == 0 || mode == 1, "repr_joints: mode must be 0 (smplx_params) or 1 (joint_abs_traj)");
+    ROHM_ARG_CHECK(mode != 0 || h, "repr_joints: mode 0 ('smplx_params') needs a body-model handle");
+    ROHM_ARG_CHECK(mode >= 0 && mode <= 2, "repr_joints: mode must be 0 (smplx_params), 1 (joint_abs_traj) or 2 (joint_rel_traj)");
     ROHM_ARG_CHECK((mean294 == nullptr) == (std294 == nullptr), "repr_joints: pass both mean and std or neither");
     if (B <= 0 || T <= 0) return ROHM_OK;
     const int n = B * T;
     prof::Scope ps("repr_joints", 0.0, 4.0 * n * (155 + 66), (hipStream_t)stream);
+    if (mode == 2) {
+        ROHM_ARG_CHECK(T <= 2048, "repr_joints: 'joint_rel_traj' supports T <= 2048");
+        hipLaunchKernelGGL(repr_joints_rel_kernel, dim3(B), dim3(256), (size_t)T * 4 * sizeof(float), (hipStream_t)stream, repr,
+                           in_stride_b, in_stride_t, in_stride_c, mean294, std294, joints, T);
+        ROHM_LAUNCH_CHECK();
+        return ROHM_OK;
+    }
     hipLaunchKernelGGL(repr_joints_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, repr, in_stride_b,
                        in_stride_t, in_stride_c, mean294, std294, h ? h->d_Jt : nullptr, h ? h->d_Js : nullptr,
                        h ? h->d_parents : nullptr, joints, mode, B, T);

@@ -23,7 +23,7 @@ REPR_DIM_DICT = {'root_rot_angle': 1, 'root_rot_angle_vel': 1, 'root_l_pos': 2, 
                  'smplx_rot_6d': 6, 'smplx_rot_vel': 3, 'smplx_trans': 3, 'smplx_trans_vel': 3,
                  'local_positions': 66, 'local_vel': 66, 'smplx_body_pose_6d': 126, 'smplx_betas': 10,
                  'foot_contact': 4}          # utils/other_utils.py:17-37
-_MODES = {'smplx_params': 0, 'joint_abs_traj': 1}
+_MODES = {'smplx_params': 0, 'joint_abs_traj': 1, 'joint_rel_traj': 2}
 
 
 def _stats(ds, device):
@@ -62,7 +62,7 @@ def joints_from_repr(repr_full, recover_mode='smplx_params', smplx_model=None, s
     """[B,T,22,3] joints from the full 294-channel representation (any strides, no copy).  `stats` = dataset or
     (mean, std) to de-normalise on the fly, None if `repr_full` is already de-normalised."""
     if recover_mode not in _MODES:
-        raise ValueError(f'recover_mode {recover_mode!r} is not supported (joint_abs_traj | smplx_params)')
+        raise ValueError(f'recover_mode {recover_mode!r} is not supported (joint_abs_traj | joint_rel_traj | smplx_params)')
     _lib.require_hip(repr_full)
     x = repr_full.detach()
     if x.dtype != torch.float32:
@@ -108,8 +108,9 @@ def recover_from_repr_smpl(data_dict, recover_mode='joint_abs_traj', smplx_model
         else:
             joints = jall[:, 0:22].reshape(bs, -1, 22, 3)
         return (joints, verts.reshape(bs, -1, verts.shape[1], 3)) if return_verts else joints
-    need = (['root_rot_angle', 'root_l_pos', 'root_height', 'local_positions'] if recover_mode == 'joint_abs_traj'
-            else ['smplx_rot_6d', 'smplx_trans', 'smplx_body_pose_6d', 'smplx_betas'])
+    need = {'joint_abs_traj': ['root_rot_angle', 'root_l_pos', 'root_height', 'local_positions'],
+            'joint_rel_traj': ['root_rot_angle_vel', 'root_l_vel', 'root_height', 'local_positions'],
+            'smplx_params': ['smplx_rot_6d', 'smplx_trans', 'smplx_body_pose_6d', 'smplx_betas']}[recover_mode]
     ref = data_dict[need[0]]
     lead = ref.shape[:-1]
     full = torch.zeros(lead + (294,), device=ref.device, dtype=torch.float32)

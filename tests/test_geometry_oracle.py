@@ -98,3 +98,14 @@ def test_smplx_restatement_self_consistency():
     R = G.batch_rodrigues(aa)
     exp = (R @ (J - J[:, :1]).transpose(1, 2)).transpose(1, 2) + J[:, :1]
     assert max_abs(out2.joints[:, :55], exp) < 1e-5
+
+
+def test_recover_rel_traj_matches_reference():
+    """recover_mode='joint_rel_traj' (running sums of the root velocities) vs the reference's output."""
+    import numpy as np
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'recover_rel.npz'))
+    mean, std = synth.synthetic_stats(int(g['stats_seed']))
+    x0 = synth.plausible_motion(int(g['motion_seed']), 2, 143, mean, std)
+    d = G.split_repr(x0[:, :, 0].permute(0, 2, 1) * torch.from_numpy(std) + torch.from_numpy(mean))
+    assert float((G.joints_from_rel_traj(d) - torch.from_numpy(g['j_rel'])).abs().max()) == 0.0

@@ -106,11 +106,14 @@ def test_joints_from_repr_vs_golden_and_oracle():
     j_a = joints_from_repr(x0, 'joint_abs_traj', stats=(mean, std), layout='bc1t')
     assert max_abs(j_s.cpu(), torch.from_numpy(g['j_smpl'])) < 1e-5
     assert max_abs(j_a.cpu(), torch.from_numpy(g['j_abs'])) < 1e-5
+    j_r = joints_from_repr(x0, 'joint_rel_traj', stats=(mean, std), layout='bc1t')
+    assert max_abs(j_r.cpu(), torch.from_numpy(golden('recover_rel.npz')['j_rel'])) < 2e-5      # 143-term running sums
     # the reference's dict-of-slices signature on de-normalised data
     full = x0[:, :, 0].permute(0, 2, 1) * torch.from_numpy(std).to(DEV) + torch.from_numpy(mean).to(DEV)
     d = G.split_repr(full)
     assert max_abs(recover_from_repr_smpl(d, 'smplx_params', layer), j_s) < 1e-6
     assert max_abs(recover_from_repr_smpl(d, 'joint_abs_traj'), j_a) < 1e-6
+    assert max_abs(recover_from_repr_smpl(d, 'joint_rel_traj'), j_r) < 2e-5     # running sums amplify the 1-ulp de-normalisation difference
     # full LBS (return_verts=True, motion_representation.py:389-396) against the oracle body model
     jv, verts = recover_from_repr_smpl(d, 'smplx_params', layer, return_verts=True)
     dc = {k: v.cpu() for k, v in d.items()}
