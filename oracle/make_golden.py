@@ -110,6 +110,46 @@ def golden_rel(ref):
     print('recover_rel.npz', os.path.getsize(os.path.join(OUT, 'recover_rel.npz')))
 
 
+def golden_eval_losses(ref):
+    """The reference's own `compute_losses_with_smpl` of PoseNet and TrajNet (the eval report of test_posenet.py /
+    test_trajnet.py) on synthetic clips, with the oracle body model standing in for smplx."""
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    mean, std = synth.synthetic_stats(0)
+
+    class DS:
+        pose_feat_dim, traj_feat_dim, joints_num = 272, 22, 22
+        Mean, Std = mean, std
+    out = {}
+    pw = dict(weight_loss_rec_repr_full_body=1.0, weight_loss_repr_foot_contact_mse=0.5, weight_loss_joint_pos_global=2.0,
+              weight_loss_joint_vel_global=3.0, weight_loss_joint_smooth=0.7, weight_loss_foot_skating=0.3,
+              start_skating_loss_epoch=0)
+    pnet = ref.posenet.PoseNet(DS(), 294, latent_dim=64, ff_size=64, num_layers=1, num_heads=1, traj_feat_dim=22,
+                               device='cpu', **pw).eval()
+    clean = synth.plausible_motion(11, 3, 143, mean, std)
+    rec = clean + 0.05 * seeded(12, 3, 294, 1, 143)
+    with torch.no_grad():
+        d = pnet.compute_losses_with_smpl({'motion_repr_clean': clean}, rec, smplx_model=body, epoch=0)
+    for k, v in d.items():
+        out['posenet_' + k] = np.float64(v)
+    tw = dict(weight_loss_root_rec_repr=1.0, weight_loss_root_pos_global=2.0, weight_loss_root_vel_global=3.0,
+              weight_loss_root_rot_vel_from_abs_traj=0.4, weight_loss_root_smplx_transl_vel=0.6,
+              weight_loss_root_smplx_rot_vel=0.8, weight_loss_root_smooth=0.9,
+              weight_loss_root_rot_cos_smooth_from_abs_traj=1.1)
+    clean_t = clean[:, :, 0].permute(0, 2, 1).contiguous()[:, :128]          # [3, 128, 294]
+    for abs_only, dim in ((True, 13), (False, 22)):
+        DS.traj_feat_dim = dim
+        tnet = ref.trajnet.TrajNet(time_dim=32, cond_dim=dim, mid_dim=64, traj_feat_dim=dim, device='cpu', dataset=DS(),
+                                   repr_abs_only=abs_only, trajcontrol=False, **tw).eval()
+        mo = seeded(13 + dim, 3, 128, dim) * 0.3
+        with torch.no_grad():
+            d = tnet.compute_losses_with_smpl({'motion_repr_clean': clean_t}, mo, smplx_model=body)
+        for k, v in d.items():
+            out[f'trajnet{dim}_' + k] = np.float64(v)
+    np.savez_compressed(os.path.join(OUT, 'eval_losses.npz'), **out)
+    print('eval_losses.npz', len(out), 'entries')
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -138,6 +178,9 @@ def golden_metrics():
 def main():
     if sys.argv[1:] == ['metrics']:
         return golden_metrics()
+    if sys.argv[1:] == ['eval_losses']:
+        warnings.filterwarnings('ignore')
+        return golden_eval_losses(refload.load())
     if sys.argv[1:] == ['rel']:
         warnings.filterwarnings('ignore')
         return golden_rel(refload.load())
@@ -232,6 +275,7 @@ def main():
     golden_metrics()
     golden_ddim(ref)
     golden_rel(ref)
+    golden_eval_losses(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

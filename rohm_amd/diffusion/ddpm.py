@@ -354,10 +354,18 @@ class DDPMSampler:
 
     # ------------------------------------------------------------------ entry point
     def _eval(self, model, batch, shape, progress, clip_denoised, cond_fn_with_grad, grad_type, early_stop,
-              timestep_respacing, compute_loss):
-        if compute_loss:
-            raise NotImplementedError('compute_loss=True needs the training losses, which are outside the '
-                                      'inference hot path; the RoHM test drivers pass compute_loss=False')
+              timestep_respacing, compute_loss, smplx_model=None, epoch=0):
+        loss_dict, out = None, self._sample(model, batch, shape, progress, clip_denoised, cond_fn_with_grad, grad_type,
+                                            early_stop, timestep_respacing)[1]
+        if compute_loss:       # the evaluation report of test_posenet.py / test_trajnet.py (…posenet.py:957-958)
+            raw = getattr(model, 'model', model)
+            with torch.no_grad():
+                loss_dict = (raw.compute_losses_with_smpl(batch, out, smplx_model, epoch) if self.supports_guidance
+                             else raw.compute_losses_with_smpl(batch, out, smplx_model))
+        return loss_dict, out
+
+    def _sample(self, model, batch, shape, progress, clip_denoised, cond_fn_with_grad, grad_type, early_stop,
+                timestep_respacing):
         if timestep_respacing[0:4] == 'ddim':
             # the branch the reference left commented out (gaussian_diffusion_posenet.py:949-952): eta = 0 DDIM over
             # the (already respaced) schedule of this object

@@ -19,6 +19,6 @@ class GaussianDiffusionPoseNet(DDPMSampler):
                     dump_steps=None, const_noise=False, cur_epoch=0, timestep_respacing='', compute_loss=True,
                     smplx_model=None, epoch=0):
         """Entry point used by the drivers (gaussian_diffusion_posenet.py:913-962) ->
-        (None, x0 [B, 294, 1, T])."""
+        (loss report or None, x0 [B, 294, 1, T])."""
         return self._eval(model, batch, shape, progress, clip_denoised, cond_fn_with_grad, grad_type, early_stop,
-                          timestep_respacing, compute_loss)
+                          timestep_respacing, compute_loss, smplx_model, epoch)

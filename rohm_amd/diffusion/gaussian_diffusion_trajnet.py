@@ -13,6 +13,6 @@ class GaussianDiffusionTrajNet(DDPMSampler):
                     device=None, progress=False, skip_timesteps=0, init_data=None, randomize_class=False,
                     cond_fn_with_grad=False, cond_grad_weight=1.0, dump_steps=None, const_noise=False,
                     cur_epoch=0, timestep_respacing='', compute_loss=True, smplx_model=None):
-        """Entry point used by the drivers (gaussian_diffusion_trajnet.py:878-915) -> (None, x0 [B, T, 13])."""
+        """Entry point used by the drivers (gaussian_diffusion_trajnet.py:878-915) -> (loss report or None, x0 [B, T, 13])."""
         return self._eval(model, batch, shape, progress, clip_denoised, cond_fn_with_grad, None, False,
-                          timestep_respacing, compute_loss)
+                          timestep_respacing, compute_loss, smplx_model)

@@ -229,5 +229,7 @@ class PoseNet(nn.Module):
         from ..guidance import guide_2d_projection
         return guide_2d_projection(self, batch, out, denoise_t, compute_grad)
 
-    def compute_losses_with_smpl(self, *a, **k):
-        raise NotImplementedError('training losses are outside the inference hot path (SURVEY.md §8)')
+    def compute_losses_with_smpl(self, batch, model_output, smplx_model=None, epoch=0):
+        """Evaluation loss report (model/posenet.py:98-194), forward only."""
+        from .eval_losses import posenet_losses
+        return posenet_losses(self, batch, model_output, smplx_model, epoch)

@@ -230,5 +230,7 @@ class TrajNet(nn.Module):
                                              ptr(ws), ws.numel(), stream_ptr(x.device)), 'rohm_trajnet_sample_loop')
         return x0_last
 
-    def compute_losses_with_smpl(self, *a, **k):
-        raise NotImplementedError('training losses are outside the inference hot path (SURVEY.md §8)')
+    def compute_losses_with_smpl(self, batch, model_output, smplx_model=None):
+        """Evaluation loss report (model/trajnet.py:277-400), forward only."""
+        from .eval_losses import trajnet_losses
+        return trajnet_losses(self, batch, model_output, smplx_model)
