@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""TrajNet / TrajControl 100-step sampling loop: wall time per run against the sum of kernel times (in-library HIP-event
+profiler), to see whether the loop is launch-bound.  usage (GPU box): python scripts/bench_trajnet.py"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rohm_amd import _lib  # noqa: E402
+from rohm_amd.diffusion import gaussian_diffusion_trajnet as gdt  # noqa: E402
+from rohm_amd.diffusion.respace import SpacedDiffusionTrajNet  # noqa: E402
+from rohm_amd.model.trajnet import TrajNet  # noqa: E402
+from rohm_amd.utils import synth  # noqa: E402
+from rohm_amd.utils.model_util import create_gaussian_diffusion  # noqa: E402
+
+
+class Args:
+    noise_schedule, sigma_small = 'cosine', True
+
+
+def main():
+    dev = torch.device('cuda', 0)
+    res = {}
+    for ctrl in (False, True):
+        net = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=ctrl, device=dev)
+        net.load_state_dict(synth.trajnet_state_dict(1, trajcontrol=ctrl), strict=True)
+        net = net.to(dev).eval()
+        diff = create_gaussian_diffusion(Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev)
+        for B in (1, 32, 256):
+            batch = {'cond': torch.randn(B, 144, 13, device=dev), 'control_cond': torch.randn(B, 144, 272, device=dev)}
+            run = lambda: diff.eval_losses(model=net, batch=batch, shape=[B, 144, 13], progress=False, clip_denoised=False,
+                                           timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / 3
+            _lib.profile_start(1)
+            run()
+            torch.cuda.synchronize()
+            prof = _lib.profile_stop()
+            ksum = sum(v['total_ms'] for v in prof.values())
+            n = sum(v['launches'] for v in prof.values())
+            res[f'{"control" if ctrl else "vanilla"}_B{B}'] = {'wall_ms': round(wall * 1e3, 2), 'kernel_event_ms': round(ksum, 2),
+                                                                'launches': n, 'clips_per_s': round(B / wall, 1)}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main()
