@@ -42,6 +42,7 @@ Scope::~Scope() {
     if (idx >= 0) (void)hipEventRecord(g_recs[idx].b, stream);
 }
 void set_step(int step) { g_active = g_enabled && (step % g_stride == 0); }
+bool enabled() { return g_enabled; }
 }  // namespace prof
 }  // namespace rohm
 

@@ -50,6 +50,7 @@ struct Scope {
     hipStream_t stream;
 };
 void set_step(int step);       // sample loops call this; activates every `stride`-th step
+bool enabled();                // between rohm_profile_start and rohm_profile_stop
 }  // namespace prof
 
 constexpr int kNumXCD = 8;
@@ -119,6 +120,10 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 // ---- other kernels -----------------------------------------------------------------------
 int launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
 int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, hipStream_t s);
+// Graph-replayable variants: per-step values come from device tables indexed by a device-side step counter.
+int launch_ddpm_step_indexed(const float* x_t, const float* x0, const float* noise_base, const float* coef_tab,
+                             const int* step_ctr, float* out, size_t n, hipStream_t s);
+int launch_advance_counter(int* step_ctr, hipStream_t s);
 int launch_ddpm_step(const float* x_t, const float* x0, const float* noise, const float* grad, float c1,
                      float c2, float sigma, float gscale, float* out, size_t n, hipStream_t s);
 

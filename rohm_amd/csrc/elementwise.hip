@@ -89,6 +89,40 @@ int launch_ddpm_step(const float* x_t, const float* x0, const float* noise, cons
 }
 
 
+// The same update with its per-step values read on the device: coef_tab[step] = (c1, c2, sigma), noise of step k at
+// noise_base + k n, step = *step_ctr.  Lets one captured hipGraph of a denoising step be replayed for every step.
+__global__ __launch_bounds__(256) void ddpm_step_indexed_kernel(const float* x_t, const float* __restrict__ x0,
+                                                                const float* __restrict__ noise_base,
+                                                                const float* __restrict__ coef_tab,
+                                                                const int* __restrict__ step_ctr, float* out, size_t n) {
+    const int k = *step_ctr;
+    const float c1 = coef_tab[3 * k], c2 = coef_tab[3 * k + 1], sigma = coef_tab[3 * k + 2];
+    const float* noise = (sigma != 0.f && noise_base) ? noise_base + (size_t)k * n : nullptr;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = c1 * x0[i] + c2 * x_t[i];
+        if (noise) v += sigma * noise[i];
+        out[i] = v;
+    }
+}
+__global__ void advance_counter_kernel(int* ctr) { *ctr += 1; }
+
+int launch_ddpm_step_indexed(const float* x_t, const float* x0, const float* noise_base, const float* coef_tab,
+                             const int* step_ctr, float* out, size_t n, hipStream_t s) {
+    if (n == 0) return ROHM_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ddpm_step_indexed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x_t, x0, noise_base, coef_tab,
+                       step_ctr, out, n);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+int launch_advance_counter(int* step_ctr, hipStream_t s) {
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, s, step_ctr);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
 // Per-sample timesteps, schedule tables on the device (p_sample_with_grad without a host sync).
 __global__ __launch_bounds__(256) void ddpm_step_table_kernel(const float* x_t, const float* __restrict__ x0,
                                                               const float* __restrict__ noise,

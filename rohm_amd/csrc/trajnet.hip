@@ -79,14 +79,18 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
 // Timestep path of one step: SinusoidalPosEmb(32) -> Linear(32,128) -> Mish -> Linear(128,32)
 // (trajnet.py:120-125, heads.py:57-69), then every block's `Mish -> Linear(32, C_out)` (heads.py:34-38)
 // stacked into one [tb_total] vector.  One block per row (sample, or 1 when the batch shares t).
-__global__ __launch_bounds__(256) void time_path_kernel(const int64_t* __restrict__ t_dev, int64_t t_host, int tdim,
+__global__ __launch_bounds__(256) void time_path_kernel(const int64_t* __restrict__ t_dev, int64_t t_host,
+                                                        const int64_t* __restrict__ t_tab, const int* __restrict__ step_ctr,
+                                                        int tdim,
                                                         const float* __restrict__ w1T, const float* __restrict__ b1,
                                                         const float* __restrict__ w3T, const float* __restrict__ b3,
                                                         const float* __restrict__ tbwT, const float* __restrict__ tbb,
                                                         int tb_total, float* __restrict__ tb_all) {
     __shared__ float e[64], h[256], te[64];
     const int tid = threadIdx.x;
-    const float tval = (float)(t_dev ? t_dev[blockIdx.x] : t_host);
+    // t: per sample (t_dev), shared by the batch (t_host), or the entry of a device table selected by the step counter
+    // of a replayed hipGraph
+    const float tval = (float)(t_tab ? t_tab[*step_ctr] : (t_dev ? t_dev[blockIdx.x] : t_host));
     const int half = tdim / 2;
     if (tid < tdim) {
         const int k = tid % half;
@@ -209,6 +213,7 @@ static inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
 // enough splits to give every CU a workgroup, at least 4 K chunks per split.  The partial-tile buffer is part of the
 // caller's workspace; forward() publishes it here for the launch helpers of this host thread.
 constexpr size_t kSplitKFloats = (size_t)256 * 144 * 128;
+constexpr int kGraphMaxSteps = 1024;       // steps per sample-loop call that the captured-graph path accepts
 static thread_local float* tl_splitk = nullptr;
 
 static void plan_split(GemmParams& g) {
@@ -302,6 +307,9 @@ struct TWs {
     Scratch sc;
     float *x0, *cond_keep;                  // loop: network output [B,T,13]
     float *splitk;                          // split-K partial tiles (plan_split)
+    float *step_coef;                       // graph replay: (c1, c2, sigma) per step, timesteps, step counter
+    int64_t* step_t;
+    int* step_ctr;
     size_t floats;
 };
 
@@ -336,6 +344,9 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     w.x0 = take(M * h->ctraj);
     w.cond_keep = take(16);
     w.splitk = take(kSplitKFloats);
+    w.step_coef = take(3 * (size_t)kGraphMaxSteps);
+    w.step_t = reinterpret_cast<int64_t*>(take(2 * (size_t)kGraphMaxSteps));
+    w.step_ctr = reinterpret_cast<int*>(take(16));
     w.floats = off;
     return w;
 }
@@ -433,10 +444,10 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
 }
 
 static int run_time_path(const rohm_trajnet* h, const TWs& w, const int64_t* t_dev, int64_t t_host, int B,
-                         hipStream_t s) {
+                         hipStream_t s, const int64_t* t_tab = nullptr, const int* step_ctr = nullptr) {
     const int rows = t_dev ? B : 1;
     prof::Scope ps("time_path", 0.0, 4.0 * h->tb_total * h->tdim, s);
-    hipLaunchKernelGGL(time_path_kernel, dim3(rows), dim3(256), 0, s, t_dev, t_host, h->tdim, h->t_w1T, h->t_b1, h->t_w3T,
+    hipLaunchKernelGGL(time_path_kernel, dim3(rows), dim3(256), 0, s, t_dev, t_host, t_tab, step_ctr, h->tdim, h->t_w1T, h->t_b1, h->t_w3T,
                        h->t_b3, h->tb_wT, h->tb_b, h->tb_total, w.tb_all);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
@@ -456,6 +467,71 @@ static int pad_rows(const float* src, float* dst, size_t rows, int cin, int cpad
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, cin, cpad);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
+}
+
+// Opt-in (ROHM_TRAJNET_GRAPH=1): measured on ROCm 7.2 / MI355X the replayed graph is SLOWER than plain stream launches
+// (100-step loop, B = 1: 96 ms vs 82 ms; B = 32: 106 vs 95; TrajControl B = 1: 152 vs 130) -- a graph kernel node costs
+// ~9.8 us against ~8.4 us for a stream launch, and the plain loop's host time only tracks the GPU because the queue
+// back-pressures.  The loop is bound by the GPU-side latency of ~98 small dependent kernels per step; fewer kernels
+// (fusion), not graphs, is what would help.
+static bool graph_replay_ok(int n_steps) {
+    const char* e = getenv("ROHM_TRAJNET_GRAPH");
+    return e && atoi(e) == 1 && !prof::enabled() && n_steps >= 3 && n_steps <= kGraphMaxSteps;
+}
+
+// Captured-graph sample loop (see rohm_trajnet_sample_loop).  Stream capture is not allowed on the legacy default
+// stream torch hands out by default, so the loop runs on a private non-blocking stream fenced with events against
+// the caller's stream.  Returns ROHM_ERR_UNSUPPORTED (nothing enqueued) if capture cannot start.
+static int sample_loop_graph(const rohm_trajnet* h, const TWs& w, float* x, const float* noise, const int64_t* t_model,
+                             const float* coef, float* x0_last, int n_steps, int B, int T, size_t M, size_t n,
+                             hipStream_t caller) {
+    static thread_local hipStream_t gs = nullptr;
+    static thread_local hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    if (!gs) {
+        if (hipStreamCreateWithFlags(&gs, hipStreamNonBlocking) != hipSuccess) { gs = nullptr; return ROHM_ERR_UNSUPPORTED; }
+        if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess)
+            return ROHM_ERR_UNSUPPORTED;
+    }
+    ROHM_HIP_CHECK(hipEventRecord(ev_in, caller));
+    ROHM_HIP_CHECK(hipStreamWaitEvent(gs, ev_in, 0));
+    ROHM_HIP_CHECK(hipMemcpyAsync(w.step_coef, coef, (size_t)n_steps * 3 * sizeof(float), hipMemcpyHostToDevice, gs));
+    ROHM_HIP_CHECK(hipMemcpyAsync(w.step_t, t_model, (size_t)n_steps * sizeof(int64_t), hipMemcpyHostToDevice, gs));
+    ROHM_HIP_CHECK(hipMemsetAsync(w.step_ctr, 0, sizeof(int), gs));
+    auto one_step = [&](hipStream_t s) -> int {
+        int rc;
+        if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;
+        if ((rc = run_time_path(h, w, nullptr, 0, B, s, w.step_t, w.step_ctr))) return rc;
+        if ((rc = run_denoiser(h, w, B, T, 0, w.x0, s))) return rc;
+        if ((rc = launch_ddpm_step_indexed(x, w.x0, noise, w.step_coef, w.step_ctr, x, n, s))) return rc;
+        return launch_advance_counter(w.step_ctr, s);
+    };
+    int rc = one_step(gs);                     // step 0 directly (also sets every kernel's launch attributes)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool captured = false;
+    if (!rc) {
+        if (hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc_cap = one_step(gs);
+            const hipError_t e = hipStreamEndCapture(gs, &graph);
+            captured = !rc_cap && e == hipSuccess && graph &&
+                       hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (!captured) (void)hipGetLastError();        // plain launches on the private stream instead
+        for (int i = 1; i < n_steps && !rc; ++i) {
+            if (captured) rc = (hipGraphLaunch(exec, gs) == hipSuccess) ? ROHM_OK : ROHM_ERR_HIP;
+            else rc = one_step(gs);
+        }
+    }
+    if (!rc && x0_last)
+        ROHM_HIP_CHECK(hipMemcpyAsync(x0_last, w.x0, n * sizeof(float), hipMemcpyDeviceToDevice, gs));
+    (void)hipEventRecord(ev_out, gs);
+    (void)hipStreamWaitEvent(caller, ev_out, 0);
+    (void)hipStreamSynchronize(gs);            // the graph objects must outlive their launches
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc == ROHM_ERR_HIP) set_error("trajnet_sample_loop: hipGraph launch failed");
+    return rc;
 }
 
 }  // namespace rohm
@@ -721,10 +797,19 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         if ((rc = pad_rows(control_cond, w.ctl, M, h->cctrl, kPadCtl, s))) return rc;
     }
     if ((rc = run_cond_encoder(h, w, B, T, s))) return rc;
+    for (int i = 0; i < n_steps; ++i)
+        ROHM_ARG_CHECK(coef[3 * i + 2] == 0.f || noise, "trajnet_sample_loop: noise is required when sigma != 0");
+    if (graph_replay_ok(n_steps)) {
+        // hipGraph replay (opt-in, see graph_replay_ok): one denoising step is captured into a hipGraph whose kernels read
+        // the per-step values (timestep, c1 / c2 / sigma, noise slice) from device tables through a device-side step
+        // counter, and the graph is replayed for the remaining steps.
+        rc = sample_loop_graph(h, w, x, noise, t_model, coef, x0_last, n_steps, B, T, M, n, s);
+        if (rc != ROHM_ERR_UNSUPPORTED) return rc;
+        // capture not available on this stream / runtime: fall through to the plain loop
+    }
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
-        ROHM_ARG_CHECK(sigma == 0.f || noise, "trajnet_sample_loop: noise is required when sigma != 0");
         if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;
         if ((rc = run_time_path(h, w, nullptr, t_model[i], B, s))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;

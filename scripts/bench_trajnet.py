@@ -39,6 +39,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(3):
                 run()
+            t_enq = (time.perf_counter() - t0) / 3          # host time to enqueue (the call returns before the GPU is done)
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) / 3
             _lib.profile_start(1)
@@ -47,7 +48,7 @@ def main():
             prof = _lib.profile_stop()
             ksum = sum(v['total_ms'] for v in prof.values())
             n = sum(v['launches'] for v in prof.values())
-            res[f'{"control" if ctrl else "vanilla"}_B{B}'] = {'wall_ms': round(wall * 1e3, 2), 'kernel_event_ms': round(ksum, 2),
+            res[f'{"control" if ctrl else "vanilla"}_B{B}'] = {'wall_ms': round(wall * 1e3, 2), 'host_enqueue_ms': round(t_enq * 1e3, 2), 'kernel_event_ms': round(ksum, 2),
                                                                 'launches': n, 'clips_per_s': round(B / wall, 1)}
     print(json.dumps(res, indent=1))
 

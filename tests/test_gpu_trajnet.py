@@ -99,3 +99,22 @@ def test_control_loop_vs_oracle():
     fn = lambda x, i: nets.trajnet_forward(sd, x, cond, torch.full((B,), i, dtype=torch.int64), control_cond=cc)
     ref = odiff.p_sample_loop(fn, x_T, noises, odiff.tables(odiff.cosine_betas(100)), list(range(100))[::-1])
     assert max_abs(y.cpu(), ref) < 1e-3
+
+
+def test_graph_replay_loop_is_bit_identical(monkeypatch):
+    """The opt-in hipGraph replay of the sampling loop (ROHM_TRAJNET_GRAPH=1: one captured step, per-step values read
+    from device tables through a step counter) must reproduce the plain loop bit for bit."""
+    net, _ = make_trajnet(81, True)
+    B = 2
+    cond, cc = seeded(5, B, 144, 13), seeded(6, B, 144, 272)
+    x_T, noises = cpu_noise_sequence(8, (B, 144, 13), 100)
+    outs = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('ROHM_TRAJNET_GRAPH', flag)
+        diff = make_diffusion()
+        diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+        _, y = diff.eval_losses(model=net, batch={'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}, shape=[B, 144, 13],
+                                progress=False, clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
+                                compute_loss=False)
+        outs.append(y.clone())
+    assert torch.equal(outs[0], outs[1])
