@@ -4,8 +4,10 @@ This package restates, in plain PyTorch-CPU arithmetic (fp32 by default, fp64 on
 request), the algorithm of the reference's hot path: PoseNet /
 TrajNet / ControlNet forwards, the DDPM ancestral sampling loops, the 6-D-rotation /
 quaternion / axis-angle helpers, SMPL-X (smplx==0.1.28) linear blend skinning and
-the two test-time guidance gradients.  Every function cites the reference
-file:line it follows.
+the two test-time guidance gradients; and, for the rows either side of the samplers,
+the between-stage trajectory re-derivation (`rederive.py`), the drivers' iteration loops
+(`scheme.py`), the evaluation metrics (`metrics.py`) and the DDIM update.  Every
+function cites the reference file:line it follows.
 
 Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py`
 may import it, and only as the checker -- the shipped path (`rohm_amd`) never
