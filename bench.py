@@ -30,6 +30,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA
+# Opt-in precision ladder of the GEMMs (rohm_amd/csrc/gemm_f32.hip): the default and the headline are exact fp32 MFMA.
+_PREC = os.environ.get('ROHM_GEMM_PRECISION', '')
+_PRODUCTS = {'bf16x6': 6, 'bf16x3': 3}.get(_PREC, 0)
 POSENET_GFLOP_PER_CLIP_STEP = 5.298   # SURVEY.md §8(d) / BASELINE.md §2
 
 
@@ -345,7 +349,10 @@ def main():
                        f'denoised 145-frame clips/sec @{S} DDPM steps'),
             'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if not _PRODUCTS else f'f32 emulated with {_PRODUCTS} bf16 MFMA products per product, f32 accumulate '
+                                                  f'(ROHM_GEMM_PRECISION={_PREC}, opt-in)',
+            'data': 'synthetic',
             'config': {'workload': f'PoseNet {S}-step DDPM (x0-pred, fixed-small var), batch={B} synthetic '
                                    f'145-frame clips per GPU (T=143 -> 144 tokens, d=512, 8 layers), no guidance '
                                    f'[BASELINE.json configs[1]]',
@@ -357,9 +364,12 @@ def main():
             'roofline': {
                 'kernel': 'gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region, '
                           f'sampled every {args.profile_stride}th denoising step)',
-                'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None,
-                'traffic': pmc_traffic()[0], 'traffic_unit': 'bytes per launch (HBM side, PMC)',
+                'bound': 'mfma', 'achieved': achieved,
+                'peak': PEAK_F32_MFMA_TFLOPS if not _PRODUCTS else PEAK_BF16_MFMA_TFLOPS / _PRODUCTS, 'unit': 'TFLOP/s',
+                'frac': (achieved / (PEAK_F32_MFMA_TFLOPS if not _PRODUCTS else PEAK_BF16_MFMA_TFLOPS / _PRODUCTS))
+                if achieved else None,
+                'peak_note': 'fp32 MFMA' if not _PRODUCTS else f'bf16 MFMA peak / {_PRODUCTS} products (fp32-equivalent flops)',
+                'traffic': pmc_traffic()[0] if not _PRODUCTS else None, 'traffic_unit': 'bytes per launch (HBM side, PMC)',
                 'traffic_source': pmc_traffic()[1],
                 'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
                 'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,
