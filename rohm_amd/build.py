@@ -47,11 +47,25 @@ def build(force=False, verbose=True):
     hipcc = find_hipcc()
     if hipcc is None:
         raise RuntimeError('hipcc not found: cannot build librohm_hip.so')
-    cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-unused-result', '-o', LIB + '.tmp'] + sources()
-    if verbose:
-        print('[rohm_amd.build]', ' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    # one object per source, compiled concurrently (gemm_f32.hip alone is ~50 s of template instantiations), then linked
+    import concurrent.futures
+    import tempfile
+    flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+    with tempfile.TemporaryDirectory(prefix='rohm_build_') as tmp:
+        objs = [os.path.join(tmp, os.path.basename(f) + '.o') for f in sources()]
+
+        def compile_one(pair):
+            src, obj = pair
+            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+            if verbose:
+                print('[rohm_amd.build]', ' '.join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, zip(sources(), objs)))
+        link = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB + '.tmp'] + objs
+        if verbose:
+            print('[rohm_amd.build]', ' '.join(link), flush=True)
+        subprocess.run(link, check=True, cwd=CSRC)
     os.replace(LIB + '.tmp', LIB)
     return LIB
 
