@@ -9,6 +9,12 @@ synthetic clips per GPU (BASELINE.json configs[1]: B = 64 on one MI355X).  Clips
 with N > 1 every rank denoises its own B clips (weak scaling, no data-path collective) and the ranks
 exchange only the finished results with one RCCL all-gather inside the timed region.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this script under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU over
+RCCL); launched by the driver under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+given.  A world size that disagrees with --gpus, or fewer visible GPUs than ranks, is an error, never a silent
+1-rank run.
+
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the fp32-MFMA GEMM
 family: algorithmic flops / HIP-event-measured launch time, sampled every 16th denoising step of the
 timed region on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle port of the same
@@ -160,48 +166,57 @@ def scheme_bench(args, world, rank, dev, dist):
     diffs = {'posenet': create_gaussian_diffusion(_Args, gdp, SpacedDiffusionPoseNet, S, '', device=dev),
              'trajnet': create_gaussian_diffusion(_Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev),
              'trajnet_control': create_gaussian_diffusion(_Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev)}
-    sargs = types.SimpleNamespace(sample_iter=2, repr_abs_only=True, infill_traj=False, traj_mask_ratio=0.1,
-                                  mask_scheme='lower', input_noise=True, iter2_cond_noisy_traj=True,
-                                  iter2_cond_noisy_pose=True, early_stop=False, cond_fn_with_grad=True,
-                                  timestep_respacing_eval='')
+    ego = args.workload == 'egobody'
     abs_ch = [0, 2, 3, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18]
     clean_t = synth.walking_motion(1000 + rank, B, 144, *s_traj, body_t).to(dev)
     clean_p = synth.walking_motion(1000 + rank, B, 144, *s_pose, body_t).to(dev)
     torch.manual_seed(rank)
     noisy_t, noisy_p = clean_t + 0.05 * torch.randn_like(clean_t), clean_p + 0.05 * torch.randn_like(clean_p)
+    if ego:
+        # SURVEY.md §8(d) cfg 5 (test_prox_egobody.py): sample_iter=3 (--sample_iter, :56), iterations >= 1 through
+        # TrajControl (:230-242), per-channel visibility mask ~80 % visible (:291-294), PROX guidance, early stop
+        from rohm_amd.inference import run_prox_iterations
+        sargs = types.SimpleNamespace(sample_iter=3, repr_abs_only=True, iter2_cond_noisy_traj=False,
+                                      iter2_cond_noisy_pose=False, early_stop=True, cond_fn_with_grad=True,
+                                      timestep_respacing_eval='')
+        pds.cam_R, pds.cam_t = torch.tensor(synth.SYNTH_CAM_R), torch.tensor(synth.SYNTH_CAM_T)
+        pds.joints_num = 22
+        cam = {k: v.to(dev) for k, v in synth.synthetic_camera_batch(rank, B).items()}
+        gvis = torch.Generator().manual_seed(77 + rank)
+        joint_vis = (torch.rand(B, 145, 22, generator=gvis) < 0.8).float()
+        vec = torch.ones(B, 145, 294)
+        for j in range(22):                                  # joint visibility -> channel visibility (local pos / vel / 6-D)
+            vec[:, :, 22 + 3 * j:25 + 3 * j] = joint_vis[:, :, j:j + 1]
+            vec[:, :, 88 + 3 * j:91 + 3 * j] = joint_vis[:, :, j:j + 1]
+            if j > 0:
+                vec[:, :, 154 + 6 * (j - 1):160 + 6 * (j - 1)] = joint_vis[:, :, j:j + 1]
+        mask_vec_vis = vec.to(dev)
+    else:
+        sargs = types.SimpleNamespace(sample_iter=2, repr_abs_only=True, infill_traj=False, traj_mask_ratio=0.1,
+                                      mask_scheme='lower', input_noise=True, iter2_cond_noisy_traj=True,
+                                      iter2_cond_noisy_pose=True, early_stop=False, cond_fn_with_grad=True,
+                                      timestep_respacing_eval='')
 
     def batches():
         bt = {'cond': noisy_t[:, :, abs_ch].contiguous(), 'motion_repr_clean': clean_t.clone(),
               'motion_repr_noisy': noisy_t.clone()}
         bp = {'motion_repr_clean': clean_p.clone(), 'motion_repr_noisy': noisy_p.clone()}
+        if ego:
+            bp.update(cam)
+            bp['mask_vec_vis'] = mask_vec_vis
         return bt, bp
 
     def one_pass():
         bt, bp = batches()
-        pose, _, _ = run_amass_iterations(sargs, nets, diffs, bt, bp, tds, pds, layer)
+        run = run_prox_iterations if ego else run_amass_iterations
+        pose, _, _ = run(sargs, nets, diffs, bt, bp, tds, pds, layer)
         if world > 1:
             sharding.gather_clips(pose, world * B)
         return pose
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        one_pass()
-    sync()
-    _lib.profile_start(args.profile_stride)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = _lib.profile_stop()
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, out, prof = timed_region(one_pass, args, world, dev, dist)
     finite = bool(torch.isfinite(out).all())
+    assert finite, 'non-finite samples'
     if rank == 0:
         clips = world * B * args.steps
         all_ms = sum(v['total_ms'] for v in prof.values())
@@ -212,14 +227,21 @@ def scheme_bench(args, world, rank, dev, dist):
         kernels = {k: {'launches': v['launches'], 'avg_us': round(v['total_ms'] / v['launches'] * 1e3, 2),
                        'time_share': round(v['total_ms'] / all_ms, 4)}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
-        rec = {'metric': f'denoised 145-frame clips/sec, full 2-iteration RoHM scheme (TrajNet 100 + PoseNet {S} '
-                         f'+ TrajControl 100 + PoseNet {S} steps, skating guidance on t<=50)',
+        if ego:
+            metric = (f'denoised 145-frame clips/sec, 3-iteration PROX/EgoBody scheme (TrajNet 100 + 2 x TrajControl 100 + '
+                      f'3 x PoseNet 980 of {S} steps, 2-D + skating guidance on t<=100)')
+            wl = (f'EgoBody scheme [BASELINE.json configs[4] / SURVEY cfg 5], batch={B} clips per GPU, sample_iter=3, '
+                  f'visibility mask 80 % visible, early stop, guidance weights as the reference (3e5 / 1e5)')
+        else:
+            metric = (f'denoised 145-frame clips/sec, full 2-iteration RoHM scheme (TrajNet 100 + PoseNet {S} '
+                      f'+ TrajControl 100 + PoseNet {S} steps, skating guidance on t<=50)')
+            wl = (f'full scheme [BASELINE.json configs[2] / SURVEY cfg 3], batch={B} clips per GPU, '
+                  f'sample_iter=2, mask_scheme=lower, guidance weights as the reference (3e6)')
+        rec = {'metric': metric,
                'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': f'full scheme [BASELINE.json configs[2] / SURVEY cfg 3], batch={B} clips per GPU, '
-                                      f'sample_iter=2, mask_scheme=lower, guidance weights as the reference (3e6)',
-                          'clips_per_gpu': B, 'ddpm_steps': S, 'finite_output': finite,
+               'config': {'workload': wl, 'clips_per_gpu': B, 'ddpm_steps': S, 'finite_output': finite,
                           'sharding': f'{world} x {B} independent clips' if world > 1 else 'single GPU'},
                'roofline': {'kernel': 'gemm_f32_kernel (all fp32-MFMA GEMM / conv-GEMM launches, sampled)', 'bound': 'mfma',
                             'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -227,12 +249,119 @@ def scheme_bench(args, world, rank, dev, dist):
                             'launches_timed': g_n, 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
                             'kernels': kernels}}
         print(json.dumps(rec), flush=True)
+    finish(world, dist)
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n, argv, env=None):
+    """Re-execute this script as `n` ranks of one node under torch.distributed.run (127.0.0.1 rendezvous) and return
+    the launcher's exit code.  Used when `--gpus N` (N > 1) is given without a WORLD_SIZE in the environment."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    e.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=e)
+
+
+def init_ranks(args):
+    """(world, rank, device, dist): one process per GPU; `--gpus` must agree with the launched world size."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                         f'--nproc-per-node {args.gpus} (or drop WORLD_SIZE and let --gpus spawn the ranks)')
+    selftest = args.backend == 'gloo'
+    if selftest:
+        if os.environ.get('ROHM_BENCH_SELFTEST') != '1':
+            raise SystemExit('bench.py: --backend gloo is the CPU self-test of the launcher / timing harness only '
+                             '(set ROHM_BENCH_SELFTEST=1); the hot path has no CPU fallback')
+        dev = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an AMD GPU: the hot path has no CPU fallback')
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f'bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} visible')
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if selftest:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+    return world, rank, dev, dist
+
+
+def timed_region(one_pass, args, world, dev, dist, profile=True):
+    """W untimed warm-up passes, then EXACTLY K passes bracketed by barrier + device synchronize on both sides; the
+    elapsed time is the MAX over ranks.  Returns (elapsed_s, last_output, profiler_dict)."""
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)
+    out = None
+    for _ in range(args.warmup):
+        out = one_pass()
+    sync()
+    prof = {}
+    if profile and dev.type == 'cuda':
+        from rohm_amd import _lib
+        _lib.profile_start(args.profile_stride)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if profile and dev.type == 'cuda':
+        prof = _lib.profile_stop()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, out, prof
+
+
+def finish(world, dist):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main():
+def selftest_bench(args, world, rank, dev, dist):
+    """CPU (gloo) self-test of THIS file's multi-rank plumbing -- spawn, rank binding, barrier-bracketed timing, MAX over
+    ranks, result all-gather, one JSON line from rank 0 -- with a stand-in for the sampler.  It measures nothing and says
+    so in every field; tests/test_bench_launcher.py drives it."""
+    from rohm_amd import sharding
+    B = args.batch
+
+    def one_pass():
+        x0 = torch.full((B, 4), float(rank))
+        time.sleep(0.01 * (rank + 1))
+        return sharding.gather_clips(x0, world * B) if world > 1 else x0
+    elapsed, out, _ = timed_region(one_pass, args, world, dev, dist, profile=False)
+    if rank == 0:
+        ranks_seen = sorted(set(int(v) for v in out[:, 0].tolist()))
+        print(json.dumps({'metric': 'bench launcher self-test (NOT a measurement: stub sampler on CPU/gloo)', 'value': 0.0,
+                          'unit': 'none', 'n_gpus': world, 'world_size': world, 'backend': 'gloo', 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'data': 'selftest-stub',
+                          'gathered_clips': int(out.shape[0]), 'ranks_seen': ranks_seen,
+                          'config': {'workload': 'selftest'}}), flush=True)
+    finish(world, dist)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
@@ -240,27 +369,28 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--ddpm-steps', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['posenet', 'scheme', 'prox'], default='posenet',
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                    help="'nccl' (= RCCL on ROCm) is the only measuring backend; 'gloo' runs the launcher self-test")
+    ap.add_argument('--workload', choices=['posenet', 'scheme', 'prox', 'egobody'], default='posenet',
                     help="'posenet' = BASELINE.json configs[1] (the headline metric); 'scheme' = configs[2]: the full "
                          "two-iteration RoHM scheme per clip (TrajNet 100 -> PoseNet 1000 + skating guidance -> "
                          "TrajControl 100 -> PoseNet 1000 + skating guidance); 'prox' = configs[3]: PoseNet with the PROX "
-                         "test-time guidance (2-D re-projection + skating on t <= 100, early stop at 980 steps); both are "
-                         "extra measurements, not the headline")
+                         "test-time guidance (2-D re-projection + skating on t <= 100, early stop at 980 steps); 'egobody' = "
+                         "configs[4]: the PROX/EgoBody driver loop (run_prox_iterations) with sample_iter=3, a random 80 % "
+                         "visibility mask and PROX guidance; all but 'posenet' are extra measurements, not the headline")
     ap.add_argument('--profile-stride', type=int, default=16)
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an AMD GPU: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not launched by torch.distributed.run: become the launcher (one rank per GPU)
+        if args.backend == 'nccl' and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible')
+        raise SystemExit(spawn_ranks(args.gpus, argv))
+    world, rank, dev, dist = init_ranks(args)
+    if args.backend == 'gloo':
+        return selftest_bench(args, world, rank, dev, dist)
 
     from rohm_amd import _lib
     from rohm_amd.diffusion import gaussian_diffusion_posenet as gdp
@@ -270,7 +400,7 @@ def main():
     from rohm_amd.utils.model_util import create_gaussian_diffusion
 
     B, S = args.batch, args.ddpm_steps
-    if args.workload == 'scheme':
+    if args.workload in ('scheme', 'egobody'):
         return scheme_bench(args, world, rank, dev, dist)
     prox = args.workload == 'prox'
     ds = _Dataset()
@@ -307,27 +437,9 @@ def main():
             sharding.gather_clips(x0, world * B)      # the path's only exchange: finished clips, RCCL all-gather
         return x0
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        one_pass()
-    sync()
-    _lib.profile_start(args.profile_stride)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = _lib.profile_stop()
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, out, prof = timed_region(one_pass, args, world, dev, dist)
     finite = bool(torch.isfinite(out).all())
-    assert finite or prox, 'non-finite samples'
+    assert finite, 'non-finite samples'
 
     if rank == 0:
         clips = world * B * args.steps
@@ -347,15 +459,17 @@ def main():
                        f'{S} DDPM steps (early stop)') if prox else
                       ('denoised 145-frame clips/sec @1000 DDPM steps' if S == 1000 else
                        f'denoised 145-frame clips/sec @{S} DDPM steps'),
-            'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
+            'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'world_size': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if not _PRODUCTS else f'f32 emulated with {_PRODUCTS} bf16 MFMA products per product, f32 accumulate '
                                                   f'(ROHM_GEMM_PRECISION={_PREC}, opt-in)',
             'data': 'synthetic',
-            'config': {'workload': f'PoseNet {S}-step DDPM (x0-pred, fixed-small var), batch={B} synthetic '
-                                   f'145-frame clips per GPU (T=143 -> 144 tokens, d=512, 8 layers), no guidance '
-                                   f'[BASELINE.json configs[1]]',
+            'config': {'workload': (f'PoseNet {S}-step DDPM with PROX test-time guidance, early stop at 980 steps, batch={B} '
+                                    f'synthetic 145-frame clips per GPU [BASELINE.json configs[3]]') if prox else
+                                   (f'PoseNet {S}-step DDPM (x0-pred, fixed-small var), batch={B} synthetic '
+                                    f'145-frame clips per GPU (T=143 -> 144 tokens, d=512, 8 layers), no guidance '
+                                    f'[BASELINE.json configs[1]]'),
                        'guidance': 'prox [BASELINE.json configs[3]]: synthetic camera + OpenPose-style keypoints, weights as '
                                    f'the reference (3e5 / 1e5); finite_output={finite}' if prox else 'none',
                        'clips_per_gpu': B, 'ddpm_steps': S, 'sharding': f'{world} x {B} independent clips, '
@@ -378,11 +492,9 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline and not prox:
-            rec['cpu_baseline'] = cpu_baseline()
+            rec['cpu_baseline'] = cpu_baseline(batch=B)
         print(json.dumps(rec), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(world, dist)
 
 
 if __name__ == '__main__':

@@ -65,7 +65,7 @@ int rohm_profile_stop(rohm_profile_row* rows, int max_rows, int* n_rows);
  * on (nn.Linear in model/heads.py:154,169, nn.TransformerEncoderLayer in
  * model/posenet.py:63-69).  A, W row-major with K contiguous (lda/ldw in floats,
  * multiples of 4, 16-byte aligned); K a multiple of 32; M, N arbitrary.
- * epi: 0 = +bias, 1 = +bias, exact-erf GELU, 2 = +bias +R[M,N](ldr).
+ * epi: 0 = +bias, 1 = +bias, erf-form GELU (erf via A&S 7.1.26, abs err 1.5e-7), 2 = +bias +R[M,N](ldr).
  * bias may be NULL. */
 int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N,
                   int K, const float* bias, const float* R, int ldr, int epi, rohm_stream_t stream);

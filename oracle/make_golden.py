@@ -150,6 +150,65 @@ def golden_eval_losses(ref):
     print('eval_losses.npz', len(out), 'entries')
 
 
+GUIDED_CASES = (('prox', 101), ('prox', 100), ('prox', 50), ('prox', 1), ('prox', 0),
+                ('amass', 51), ('amass', 50), ('amass', 1), ('amass', 0))
+
+
+def guided_step_inputs(g_or_seeds, B=2):
+    """The seeded inputs of tests/golden/guided_step.npz (shared with the tests so both sides build the same bytes)."""
+    s = {k: int(g_or_seeds[k]) for k in ('stats_seed', 'x_seed', 'xn_seed', 'cond_seed', 'cam_seed')}
+    mean, std = synth.synthetic_stats(s['stats_seed'])
+    x = synth.plausible_motion(s['x_seed'], B, 143, mean, std) + 0.05 * seeded(s['xn_seed'], B, 294, 1, 143)
+    cond = synth.plausible_motion(s['cond_seed'], B, 143, mean, std)
+    cam = synth.synthetic_camera_batch(s['cam_seed'], B)
+    return mean, std, x, cond, cam
+
+
+def golden_guided_step(ref):
+    """The reference's OWN `p_sample_with_grad` (gaussian_diffusion_posenet.py:436-480) for grad_type 'prox' (2-D term
+    3e5 then skating 1e5, t[0] <= 100) and 'amass' (skating 3e6, t[0] <= 50), one call per (grad_type, t) from seeded
+    inputs: full-size reference PoseNet, the reference's guide_*_with_smpl hooks around the oracle body model, the
+    reference's SpacedDiffusionPoseNet tables, `th.randn_like` noise from `torch.manual_seed(noise_seed)`."""
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    refload.set_body_model(body)
+    seeds = dict(stats_seed=0, x_seed=61, xn_seed=62, cond_seed=63, cam_seed=2, weight_seed=13, body_seed=0)
+    mean, std, x, cond, cam = guided_step_inputs(seeds)
+
+    class GDS:
+        pose_feat_dim, traj_feat_dim, joints_num = 272, 22, 22
+        Mean, Std = mean, std
+        cam_R = torch.tensor(synth.SYNTH_CAM_R)
+        cam_t = torch.tensor(synth.SYNTH_CAM_T)
+    net = ref.posenet.PoseNet(GDS(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                              device='cpu').eval()
+    net.smplx_model = body
+    sd = synth.posenet_state_dict(seeds['weight_seed'])
+    net.load_state_dict(sd, strict=False)
+    diff = ref.model_util.create_gaussian_diffusion(_Args, ref.gd_posenet, ref.respace.SpacedDiffusionPoseNet,
+                                                    1000, '', device='cpu')
+    out = {}
+    for k, (gt, i) in enumerate(GUIDED_CASES):
+        batch = dict(cam)
+        batch['cond'] = cond
+        t = torch.tensor([i] * 2)
+        torch.manual_seed(700 + k)
+        with torch.no_grad():
+            r = diff.p_sample_with_grad(net, batch, x.clone(), t, clip_denoised=False, grad_type=gt)
+        # which hooks were live (a 0-d return = "no active constraint"), recorded for the tests' sanity asserts
+        with torch.no_grad():
+            o = {'pred_xstart': r['pred_xstart']}
+            live = [float(net.guide_skating_with_smpl(batch, o, t, compute_grad='x_0').dim() != 0)]
+        out[f'case{k}_sample'] = r['sample'].numpy()
+        out[f'case{k}_t'], out[f'case{k}_noise_seed'], out[f'case{k}_skating_live'] = i, 700 + k, live[0]
+        out[f'case{k}_grad_type'] = gt
+        if gt == 'prox' and i in (100, 0):
+            out[f'case{k}_pred_xstart'] = r['pred_xstart'].numpy()
+        print('guided_step', gt, i, 'max|sample|', float(r['sample'].abs().max()), 'skating live', live[0])
+    np.savez_compressed(os.path.join(OUT, 'guided_step.npz'), n_cases=len(GUIDED_CASES), **seeds, **out)
+    print('guided_step.npz', os.path.getsize(os.path.join(OUT, 'guided_step.npz')))
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -184,6 +243,9 @@ def main():
     if sys.argv[1:] == ['rel']:
         warnings.filterwarnings('ignore')
         return golden_rel(refload.load())
+    if sys.argv[1:] == ['guided_step']:
+        warnings.filterwarnings('ignore')
+        return golden_guided_step(refload.load())
     if sys.argv[1:] == ['ddim']:
         warnings.filterwarnings('ignore')
         return golden_ddim(refload.load())
@@ -276,6 +338,7 @@ def main():
     golden_ddim(ref)
     golden_rel(ref)
     golden_eval_losses(ref)
+    golden_guided_step(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -115,7 +115,9 @@ class DDPMSampler:
         return self._tables_cache[key]
 
     def _mapped(self, t):
-        """Network-side timestep (`_WrappedModel`, respace.py:183-195)."""
+        """Network-side timestep (`_WrappedModel`, respace.py:183-195).  The reference's eval_losses hands the raw
+        module (`model.model`) to p_sample_loop and `SpacedDiffusion*.p_mean_variance` re-wraps it (respace.py:92-95),
+        so the map IS applied on the sampling path there too; the fused loops apply the same map on the host."""
         if self.timestep_map == list(range(self.num_timesteps)) and not self.rescale_timesteps:
             return t
         key = str(t.device)
@@ -229,14 +231,27 @@ class DDPMSampler:
         if dump_steps is not None or save_intermediate_result or not self._fused_ok(raw):
             final = None
             dump = []
+            x0s, xts, tls = [], [], []
+            every = max(1, self.num_timesteps // 5)          # `save_steps_all = 5` (gaussian_diffusion_posenet.py:532)
+            k = -1
             for k, out in enumerate(self.p_sample_loop_progressive(
                     model, batch, shape, noise=noise, device=device, progress=progress,
                     cond_fn_with_grad=cond_fn_with_grad, grad_type=grad_type, early_stop=early_stop)):
                 if dump_steps is not None and k in dump_steps:
                     dump.append(out['sample'].clone())
                 final = out
+                if save_intermediate_result and k % every == 0:                       # :556-560
+                    x0s.append(out['pred_xstart'].clone())
+                    xts.append(out['x_t'].clone())
+                    tls.append(self.num_timesteps - k - 1)
             if dump_steps is not None:
                 return dump
+            if save_intermediate_result:
+                # the reference appends the last step once more and returns the 4-tuple, early_stop or not (:570-574)
+                x0s.append(final['pred_xstart'].clone())
+                xts.append(final['x_t'].clone())
+                tls.append(self.num_timesteps - k - 1)
+                return final['sample'], x0s, xts, tls
             return final['pred_xstart'] if early_stop else final['sample']
         return self._fused_loop(raw, batch, shape, noise, device, cond_fn_with_grad, grad_type, early_stop)
 
@@ -257,8 +272,11 @@ class DDPMSampler:
         x0_last = None
         with torch.no_grad():
             pos = 0
+            x_in_last = None
             while pos < n_free:
                 n = min(self.fused_chunk, n_free - pos)
+                if pos + n == len(indices) and n > 1:
+                    n -= 1        # the very last step runs on its own so that its input can be kept for batch['x_t']
                 ts = indices[pos:pos + n]
                 coef = np.empty((n, 3), np.float32)
                 for k, i in enumerate(ts):
@@ -269,6 +287,8 @@ class DDPMSampler:
                 else:
                     nz = torch.randn((n,) + tuple(x.shape), device=x.device, dtype=torch.float32)
                 last = (pos + n == len(indices))
+                if last:
+                    x_in_last = x.clone()
                 x0 = raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz,
                                             want_x0_last=last, batch=batch)
                 if last:
@@ -278,9 +298,11 @@ class DDPMSampler:
             for step in range(n_free, len(indices)):
                 i = indices[step]
                 t = torch.full((B,), i, device=x.device, dtype=torch.int64)
+                x_in_last = x
                 out = self._step(raw, batch, x, t, step, grad_type=grad_type, t_int=i)
                 x, x0_last = out['sample'], out['pred_xstart']
-        batch['x_t'] = x
+        # the reference leaves the INPUT of the last executed step in batch['x_t'] (p_mean_variance, :264)
+        batch['x_t'] = x_in_last if x_in_last is not None else x
         return x0_last if early_stop else x
 
     # ------------------------------------------------------------------ DDIM

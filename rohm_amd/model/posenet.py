@@ -115,7 +115,7 @@ class PoseNet(nn.Module):
                  weight_loss_joint_smooth=0.0, weight_loss_foot_skating=0.0, start_skating_loss_epoch=0):
         super().__init__()
         if activation != 'gelu':
-            raise ValueError('the HIP PoseNet implements the exact-erf GELU feed-forward only')
+            raise ValueError('the HIP PoseNet implements the erf-form ("gelu") feed-forward only')
         self.dataset = dataset
         self.body_feat_dim, self.nfeats, self.traj_feat_dim = body_feat_dim, nfeats, traj_feat_dim
         self.foot_joint_index_list = [7, 10, 8, 11]   # l-ankle, l-toe, r-ankle, r-toe (posenet.py:30-31)
@@ -184,6 +184,10 @@ class PoseNet(nn.Module):
         B, Cc, nf, T = x_t.shape
         if Cc != self.input_feats or nf != 1:
             raise ValueError(f'x_t must be [B, {self.input_feats}, 1, T]; got {tuple(x_t.shape)}')
+        if tuple(cond.shape) != tuple(x_t.shape):
+            raise ValueError(f'cond must have the shape of x_t {tuple(x_t.shape)}, got {tuple(cond.shape)}')
+        if tuple(timesteps.shape) != (B,):
+            raise ValueError(f'timesteps must be [{B}], got {tuple(timesteps.shape)}')
         x_c = x_t.detach().to(torch.float32).contiguous()
         c_c = cond.detach().to(torch.float32).contiguous()
         t_c = timesteps.to(torch.int64).contiguous()
@@ -204,13 +208,18 @@ class PoseNet(nn.Module):
         _lib.require_hip(x, cond, noise)
         nat = self.native(x.device)
         B, Cc, _, T = x.shape
-        assert x.is_contiguous() and cond.is_contiguous()
+        if Cc != self.input_feats or tuple(cond.shape) != tuple(x.shape):
+            raise ValueError(f'x and cond must both be [B, {self.input_feats}, 1, T]; got {tuple(x.shape)} / '
+                             f'{tuple(cond.shape)}')
+        if not (x.is_contiguous() and cond.is_contiguous()):
+            raise ValueError('x and cond must be contiguous')
         n = len(t_model)
         t_arr = np.ascontiguousarray(t_model, dtype=np.int64)
         c_arr = np.ascontiguousarray(coef, dtype=np.float32).reshape(-1)
         assert c_arr.size == 3 * n
-        if noise is not None:
-            assert noise.is_contiguous() and noise.shape[0] >= n and noise[0].numel() == x.numel()
+        if noise is not None and not (noise.is_contiguous() and noise.shape[0] >= n and
+                                      tuple(noise.shape[1:]) == tuple(x.shape)):
+            raise ValueError(f'noise must be contiguous [>= {n}, {B}, {Cc}, 1, {T}], got {tuple(noise.shape)}')
         x0_last = torch.empty_like(x) if want_x0_last else None
         ws = nat.workspace(B, T)
         check(lib().rohm_posenet_sample_loop(nat.handle, ptr(x), ptr(cond),

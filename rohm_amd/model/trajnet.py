@@ -193,11 +193,24 @@ class TrajNet(nn.Module):
         B, T, Cc = x_t.shape
         if Cc != self.traj_feat_dim:
             raise ValueError(f'x_t must be [B, T, {self.traj_feat_dim}], got {tuple(x_t.shape)}')
-        ctrl = None
-        if self.trajcontrol:
-            ctrl = batch['control_cond'].detach().float().contiguous()
-            _lib.require_hip(ctrl)
+        ctrl = self._check_cond(x_t, cond, batch)
         return x_t.detach().float().contiguous(), cond.detach().float().contiguous(), ctrl, B, T
+
+    def _check_cond(self, x_t, cond, batch):
+        """The C ABI takes raw pointers: a cond / control_cond of another shape would be read with the wrong stride
+        (the reference raises inside its first conv instead), so shapes are checked here."""
+        if tuple(cond.shape) != tuple(x_t.shape):
+            raise ValueError(f'cond must have the shape of x_t {tuple(x_t.shape)}, got {tuple(cond.shape)}')
+        if not self.trajcontrol:
+            return None
+        if batch is None or 'control_cond' not in batch:
+            raise KeyError("TrajNet(trajcontrol=True) needs batch['control_cond']")
+        ctrl = batch['control_cond']
+        _lib.require_hip(ctrl)
+        want = (x_t.shape[0], x_t.shape[1], self.control_cond_dim)
+        if tuple(ctrl.shape) != want:
+            raise ValueError(f'control_cond must be {want}, got {tuple(ctrl.shape)}')
+        return ctrl.detach().float().contiguous()
 
     def forward(self, batch, time):
         """model/trajnet.py:177-275."""
@@ -215,11 +228,15 @@ class TrajNet(nn.Module):
         import numpy as np
         _lib.require_hip(x, cond, noise)
         nat = self.native(x.device)
-        B, T, _ = x.shape
-        ctrl = None
-        if self.trajcontrol:
-            ctrl = batch['control_cond'].detach().float().contiguous()
+        B, T, Cc = x.shape
+        if Cc != self.traj_feat_dim:
+            raise ValueError(f'x must be [B, T, {self.traj_feat_dim}], got {tuple(x.shape)}')
+        ctrl = self._check_cond(x, cond, batch)
         n = len(t_model)
+        if noise is not None and (noise.shape[0] < n or tuple(noise.shape[1:]) != tuple(x.shape)):
+            raise ValueError(f'noise must be [>= {n}, {B}, {T}, {Cc}], got {tuple(noise.shape)}')
+        if not (x.is_contiguous() and cond.is_contiguous() and (noise is None or noise.is_contiguous())):
+            raise ValueError('x, cond and noise must be contiguous')
         t_arr = np.ascontiguousarray(t_model, dtype=np.int64)
         c_arr = np.ascontiguousarray(coef, dtype=np.float32).reshape(-1)
         x0_last = torch.empty_like(x) if want_x0_last else None

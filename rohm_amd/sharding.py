@@ -7,10 +7,11 @@ the weights, and the only communication is ONE all-gather of the finished clips 
 collective inside the networks.
 
 Guidance semantics under sharding: the reference normalises the skating loss by a mask count summed over the
-whole batch (model/posenet.py:231,243) and averages the 2-D loss over it (:309).  `shard_batch` implements
+whole batch (model/posenet.py:231,243) and averages the 2-D loss over it (:309).  By default a sharded run has
 REPLICA semantics -- each rank behaves exactly like the reference run with batch_size = its local slice --
-which needs no communication; reproducing the reference at the global batch size would need the two mask
-counts all-reduced per guided step (documented in DESIGN.md, not implemented).
+which needs no communication.  `use_global_batch_guidance` switches a PoseNet to GLOBAL-batch semantics: the two
+skating mask counts are all-reduced (8 bytes) per guided step and the 2-D term is scaled by B_local / B_global,
+reproducing the reference at the full batch size (rohm_amd/guidance.py, tests/test_gpu_guidance.py).
 """
 from __future__ import annotations
 

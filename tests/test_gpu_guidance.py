@@ -204,3 +204,116 @@ def test_global_batch_guidance_equals_full_batch():
     # and per-rank (replica) semantics really is different: the local run normalises by the local counts
     local = guide_skating(net, {}, {'pred_xstart': x0[0:3].contiguous()}, None, 'x_0')
     assert max_abs(local.cpu(), full_s[0:3].cpu()) > 1e-3 * float(full_s.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------- PROX (BASELINE config 4)
+def _prox_net(g):
+    mean, std = synth.synthetic_stats(int(g['stats_seed']))
+    net = _posenet(mean, std)
+    net.load_state_dict(synth.posenet_state_dict(int(g['weight_seed'])), strict=False)
+    return net
+
+
+def _diffusion():
+    from rohm_amd.diffusion import gaussian_diffusion_posenet as gdp
+    from rohm_amd.diffusion.respace import SpacedDiffusionPoseNet
+    from rohm_amd.utils.model_util import create_gaussian_diffusion
+
+    class Args:
+        noise_schedule, sigma_small = 'cosine', True
+    return create_gaussian_diffusion(Args, gdp, SpacedDiffusionPoseNet, 1000, '', device=DEV)
+
+
+def test_guided_step_vs_reference_golden():
+    """`p_sample_with_grad` through the HIP kernels against what the REFERENCE's own p_sample_with_grad returned
+    (tests/golden/guided_step.npz; gaussian_diffusion_posenet.py:436-480): grad_type 'prox' -- 2-D term (3e5) then
+    skating term (1e5), both through the two-gradient path of rohm_ddpm_step_table, t <= 100 -- and 'amass' (3e6,
+    t <= 50), on both sides of each threshold and at t = 0 (variance 0: guidance and noise are no-ops)."""
+    from oracle.make_golden import guided_step_inputs
+    g = golden('guided_step.npz')
+    net = _prox_net(g)
+    mean, std, x, cond, cam = guided_step_inputs(g)
+    diff = _diffusion()
+    for k in range(int(g['n_cases'])):
+        gt, i = str(g[f'case{k}_grad_type']), int(g[f'case{k}_t'])
+        torch.manual_seed(int(g[f'case{k}_noise_seed']))
+        noise = torch.randn(2, 294, 1, 143)
+        diff.noise_source = lambda step, like: noise
+        batch = {kk: v.to(DEV) for kk, v in cam.items()}
+        batch['cond'] = cond.to(DEV)
+        t = torch.full((2,), i, device=DEV, dtype=torch.int64)
+        out = diff.p_sample_with_grad(net, batch, x.to(DEV), t, clip_denoised=False, grad_type=gt)
+        ref = torch.from_numpy(g[f'case{k}_sample'])
+        # pixels x 1/z makes the 2-D gradient ill conditioned (the reference's own fp32 is 1.5e-4 from float64)
+        tol = 1e-3 if (gt == 'prox' and 0 < i <= 100) else 1e-4
+        assert max_abs(out['sample'].cpu(), ref) < tol * max(1.0, float(ref.abs().max())), (gt, i)
+        if f'case{k}_pred_xstart' in g:
+            assert max_abs(out['pred_xstart'].cpu(), torch.from_numpy(g[f'case{k}_pred_xstart'])) < 1e-4
+        assert torch.equal(out['x_t'].cpu(), x)
+
+
+def test_prox_guided_steps_match_oracle_teacher_forced():
+    """grad_type='prox' step by step on the ORACLE's trajectory across the t <= 100 threshold, reference weights."""
+    from oracle import diffusion as odiff
+    from test_oracle_golden import guided_oracle_pieces
+    from helpers import cpu_noise_sequence
+    g = golden('guided_step.npz')
+    net = _prox_net(g)
+    mean, std, x, cond, cam, sd, fn, guid = guided_oracle_pieces(g)
+    idx = [102, 101, 100, 99, 60, 20]
+    _, noises = cpu_noise_sequence(5, (2, 294, 1, 143), len(idx))
+    tab = odiff.tables(odiff.cosine_betas(1000))
+    ref = odiff.p_sample_loop(fn, x, noises, tab, idx, guidance=guid, grad_type='prox', return_all=True)
+    diff = _diffusion()
+    batch = {kk: v.to(DEV) for kk, v in cam.items()}
+    batch['cond'] = cond.to(DEV)
+    xx = x
+    for k, i in enumerate(idx):
+        diff.noise_source = lambda step, like, k=k: noises[k]
+        t = torch.full((2,), i, device=DEV, dtype=torch.int64)
+        out = diff.p_sample_with_grad(net, batch, xx.to(DEV), t, grad_type='prox')
+        scale = max(1.0, float(ref[k][0].abs().max()))
+        assert max_abs(out['sample'].cpu(), ref[k][0]) < 1e-3 * scale, (i, scale)
+        xx = ref[k][0]
+    assert float(ref[2][0].abs().max()) > 2 * float(ref[1][0].abs().max())      # the guided steps moved the sample
+
+
+def test_prox_loop_early_stop_matches_oracle_free_running(monkeypatch):
+    """`eval_losses(grad_type='prox', early_stop=True)`: fused un-guided run, per-step guided tail with BOTH terms,
+    early stop returning the last pred_xstart -- free-running against the oracle with the two weights turned down
+    (3e5 -> 3e2, 1e5 -> 1e2) on both sides so the synthetic problem is well conditioned."""
+    from oracle import diffusion as odiff
+    from rohm_amd.diffusion import ddpm
+    from test_oracle_golden import guided_oracle_pieces
+    from helpers import cpu_noise_sequence
+    monkeypatch.setitem(ddpm.GUIDANCE, 'prox', (100, (('guide_2d_projection_with_smpl', 3e2),
+                                                      ('guide_skating_with_smpl', 1e2))))
+    monkeypatch.setitem(odiff.GUIDANCE, 'prox', (100, (('2d', 3e2), ('skating', 1e2))))
+    g = golden('guided_step.npz')
+    net = _prox_net(g)
+    mean, std, x, cond, cam, sd, fn, guid = guided_oracle_pieces(g)
+    full = [104, 103, 102, 101, 100, 99, 98, 60, 21, 20, 19, 3]     # early stop keeps the first len-2 of these
+    keep = full[:-2]
+    _, noises = cpu_noise_sequence(6, (2, 294, 1, 143), len(full))
+    diff = _diffusion()
+    diff.noise_source = lambda step, like: (x if step == -1 else noises[step])
+    diff._indices = lambda skip=0, early_stop=False: (keep if early_stop else full)
+    batch = {kk: v.to(DEV) for kk, v in cam.items()}
+    batch['cond'] = cond.to(DEV)
+    _, y = diff.eval_losses(model=net, batch=batch, shape=[2, 294, 1, 143], progress=False, clip_denoised=False,
+                            timestep_respacing='', cond_fn_with_grad=True, compute_loss=False, grad_type='prox',
+                            early_stop=True)
+    tab = odiff.tables(odiff.cosine_betas(1000))
+    ref = odiff.p_sample_loop(fn, x, noises, tab, keep, guidance=guid, grad_type='prox', early_stop=True)
+    assert max_abs(y.cpu(), ref) < 1e-3
+    # early_stop returns the x0 prediction of the last executed step, not its sample
+    ref_sample = odiff.p_sample_loop(fn, x, noises, tab, keep, guidance=guid, grad_type='prox', early_stop=False)
+    assert max_abs(y.cpu(), ref_sample) > 1e-2
+
+
+def test_early_stop_index_list_is_the_references():
+    """early_stop keeps indices[0:980] = t 999..20 (gaussian_diffusion_posenet.py:625-626)."""
+    diff = _diffusion()
+    idx = diff._indices(0, True)
+    assert len(idx) == 980 and idx[0] == 999 and idx[-1] == 20
+    assert diff._indices(0, False)[-1] == 0

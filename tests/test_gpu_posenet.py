@@ -133,7 +133,7 @@ def test_full_1000_step_loop_vs_oracle():
     from rohm_amd.body_model import SMPLXLayer
     from rohm_amd.data_loaders.motion_representation import joints_from_repr
     net, sd = make_posenet(31)
-    B, S = 1, 1000
+    B, S = 4, 1000          # SURVEY.md §8(d) cfg 2: parity run at B = 4
     diff = make_diffusion(S)
     mean, std = synth.synthetic_stats(1)
     cond = synth.plausible_motion(7, B, 143, mean, std)
@@ -153,3 +153,44 @@ def test_full_1000_step_loop_vs_oracle():
     print(f'1000-step loop: max|HIP - oracle| = {err:.3e}, MPJPE = {mpjpe_mm:.4f} mm')
     assert err < 1e-3, err
     assert mpjpe_mm < 1.0, mpjpe_mm
+
+
+def test_loop_api_details_of_the_reference():
+    """Drop-in details of p_sample_loop (gaussian_diffusion_posenet.py:483-576): `save_intermediate_result` returns
+    (sample, x0_list, xt_list, t_list) with every (num_timesteps // 5)-th step plus the last one; after a run
+    batch['x_t'] is the INPUT of the last executed step (p_mean_variance writes it, :264) on the fused and the
+    step-wise path alike."""
+    net, sd = make_posenet(3)
+    steps = 10
+    cond = seeded(4, 1, 294, 1, 143)
+    x_T, noises = cpu_noise_sequence(8, (1, 294, 1, 143), steps)
+    src = lambda step, like: (x_T if step == -1 else noises[step])
+    tab = odiff.tables(odiff.cosine_betas(steps))
+    fn = lambda x, i: nets.posenet_forward(sd, x, cond, torch.full((1,), i, dtype=torch.int64))
+    trace = odiff.p_sample_loop(fn, x_T, noises, tab, list(range(steps))[::-1], return_all=True)
+    diff = make_diffusion(steps)
+    diff.noise_source = src
+    batch = {'cond': cond.to(DEV)}
+    sample, x0s, xts, tls = diff.p_sample_loop(net, batch, [1, 294, 1, 143], save_intermediate_result=True)
+    assert tls == [9, 7, 5, 3, 1, 0] and len(x0s) == len(xts) == 6
+    assert max_abs(sample.cpu(), trace[-1][0]) < 1e-3
+    for k, t_left in enumerate(tls):
+        step = steps - 1 - t_left
+        assert max_abs(x0s[k].cpu(), trace[step][1]) < 1e-3
+        x_in = x_T if step == 0 else trace[step - 1][0]
+        assert max_abs(xts[k].cpu(), x_in) < 1e-3
+    for chunk in (50, 4):                      # one fused call / several chunks
+        diff.fused_chunk = chunk
+        batch = {'cond': cond.to(DEV)}
+        y = diff.p_sample_loop(net, batch, [1, 294, 1, 143])
+        assert max_abs(y.cpu(), trace[-1][0]) < 1e-3
+        assert max_abs(batch['x_t'].cpu(), trace[-2][0]) < 1e-3        # input of the last step, not its output
+
+
+def test_shape_errors_are_raised_before_the_c_abi():
+    net, _ = make_posenet(3)
+    x = torch.zeros(2, 294, 1, 143, device=DEV)
+    with pytest.raises(ValueError):
+        net({'x_t': x, 'cond': x[:1]}, torch.zeros(2, dtype=torch.int64, device=DEV))
+    with pytest.raises(ValueError):
+        net({'x_t': x, 'cond': x}, torch.zeros(3, dtype=torch.int64, device=DEV))

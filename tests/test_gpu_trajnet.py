@@ -118,3 +118,19 @@ def test_graph_replay_loop_is_bit_identical(monkeypatch):
                                 compute_loss=False)
         outs.append(y.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_shape_errors_are_raised_before_the_c_abi():
+    """cond / control_cond of the wrong shape must raise (the C ABI takes raw pointers)."""
+    from rohm_amd.model.trajnet import TrajNet
+    net = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=True, device=DEV)
+    net.load_state_dict(synth.trajnet_state_dict(1, trajcontrol=True), strict=True)
+    net = net.to(DEV).eval()
+    x = torch.zeros(2, 144, 13, device=DEV)
+    t = torch.zeros(2, dtype=torch.int64, device=DEV)
+    with pytest.raises(ValueError):
+        net({'x_t': x, 'cond': torch.zeros(2, 144, 22, device=DEV), 'control_cond': torch.zeros(2, 144, 272, device=DEV)}, t)
+    with pytest.raises(ValueError):
+        net({'x_t': x, 'cond': x, 'control_cond': torch.zeros(2, 143, 272, device=DEV)}, t)
+    with pytest.raises(KeyError):
+        net({'x_t': x, 'cond': x}, t)
