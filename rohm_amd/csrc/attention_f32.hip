@@ -2,19 +2,32 @@
 // timestep token), head dim 128, no mask.  Replaces the scaled-dot-product inside
 // nn.MultiheadAttention (model/posenet.py:63-69; op inventory SURVEY.md §2a).
 //
-// One workgroup per (clip, head), nine waves, wave w owns the 16 query rows [16w, 16w+16):
-//   phase 0  K tile [144 x 128] -> LDS (row stride 136 floats: conflict-free ds_read_b128);
-//            V tile is fetched into registers and parked there while phase 1 runs.
-//   phase 1  S^T = K . Q^T on v_mfma_f32_16x16x4_f32 ("swapped QK^T"): the accumulator of key
-//            block kb holds S^T[key = 16kb + 4g + r][query = l & 15], i.e. each lane owns 36 of the
-//            144 scores of ONE query row, so the softmax row reduction is in-register plus two
-//            cross-lane steps (lanes l, l^16, l^32, l^48 share a query).
-//   phase 2  softmax in fp32 (max-subtracted, normalised before P.V like the reference).
-//   phase 3  O^T = V^T . P^T (operands swapped so each lane ends with 4 consecutive output floats = one
-//            16-byte store): the S^T accumulator layout *is* the MFMA operand layout of P
-//            (lane (i = query, g) register j = P[query][16kb + 4g + j]), so P never leaves
-//            registers; V comes from LDS (row stride 132 floats: conflict-free ds_read_b32).
-// Scores never touch LDS or HBM.  LDS: (136 + 132) * 144 * 4 = 154,368 B (of 160 KiB).
+// Work item = one (clip, head): 9 query blocks of 16 rows against 144 keys.  Two launch shapes:
+//   FULL   one workgroup of 8 waves per item (2 waves per SIMD): waves 0..7 OWN query blocks 0..7, block 8 is
+//          computed COOPERATIVELY by all eight waves (split along the keys), so every SIMD carries 2 + 1/4 blocks --
+//          the 9-waves-on-4-SIMDs layout of round 1 left one SIMD with 3 blocks (75 % of the MFMA time at best).
+//   SPLIT  two workgroups of 4 waves per item (query blocks 0..4 / 5..8; the first one's fifth block cooperative) on
+//          the SAME XCD (blocks b and b + 8 share an L2), used while the items alone cannot fill the 256 CUs
+//          (B = 32 clips x 4 heads = 128 items).
+// Data movement: K and V tiles [144 x 128] go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers),
+// all issued in the first microsecond; K arrives in three 48-key groups and the QK^T MFMAs of a group start as soon as
+// that group has landed (counted s_waitcnt vmcnt(N) + raw s_barrier), V lands underneath the QK^T phase.  Round 1
+// loaded everything, THEN computed: with one workgroup per CU the 56 MB of q/k/v (B = 64) cost ~12 us of idle MFMA.
+// The Q rows are staged through the (still empty) V buffer so that no ordinary global load is outstanding beside the
+// DMAs (hipcc would wait vmcnt(0) at its first use and drain the DMA queue).
+//   LDS images: K [144][128] with the 16-byte chunk index XOR-ed by (row & 15) -- applied on the per-lane SOURCE
+//   address, LDS-DMA writes lane-linear -- so the QK^T fragment reads (16 rows x one chunk per lane group) are
+//   conflict-free ds_read_b128; V [144][128] plain: the PV fragment read is 16 consecutive chunks of 4 rows, already
+//   conflict-free.  147,456 B + 2 KiB scratch.
+//   QK^T  S^T = K . Q^T on v_mfma_f32_16x16x4_f32: the accumulator of key block kb holds
+//         S^T[key = 16kb + 4g + r][query = l & 15]: a lane owns 36 of the 144 scores of ONE query, the softmax
+//         reduction is in-register plus two cross-lane steps; scores never touch LDS or HBM.
+//   PV    O = P . V with P straight from those accumulators (they ARE the A-operand layout) and ONE ds_read_b128 of
+//         V[key][64 db + 4 li .. + 3] feeding FOUR MFMAs (output columns 64 db + 4 li + m, m = 0..3): a lane ends
+//         with 4 consecutive output floats per row = 16-byte stores.  (Round 1 issued one ds_read_b32 per MFMA.)
+//   Cooperative block: wave w takes the key tiles kb = w, w + NW, ...; it keeps an un-normalised P_w = exp(s - m_w)
+//         with its own row maximum m_w and row sum l_w, computes O_w = P_w V over its keys, and the waves combine
+//         O = sum_w e^(m_w - M) O_w / sum_w e^(m_w - M) l_w through the (by then free) K buffer.
 #include "common.h"
 
 namespace rohm {
@@ -22,138 +35,319 @@ namespace rohm {
 constexpr int AT_S = 144;      // tokens
 constexpr int AT_DH = 128;     // head dim
 constexpr int AT_NB = 9;       // 16-row blocks
-constexpr int AT_KS = 136;     // K row stride (floats)
-constexpr int AT_VS = 132;     // V row stride (floats)
-constexpr int AT_THREADS = 576;
-constexpr int AT_UNITS = AT_S * AT_DH / 4 / AT_THREADS;   // 16-byte units per thread per tile = 8
+constexpr int AT_TILE = AT_S * AT_DH;              // floats per K / V image
+constexpr int AT_LDS_FLOATS = 2 * AT_TILE + 512;   // + 1 KiB DMA landing zone + 1 KiB statistics
 
-__global__ __launch_bounds__(AT_THREADS) void attention_f32_kernel(const float* __restrict__ qkv,
-                                                                   float* __restrict__ ctx, int n_head) {
+#define AT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define AT_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ void at_dma16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __restrict__ qkv,
+                                                                float* __restrict__ ctx, int n_head, int n_items,
+                                                                int split) {
+    constexpr int OWNED = NW;                       // query blocks owned by one wave each
+    constexpr int NQP = (NW == 8) ? 9 : 10;         // Q staging pieces (1 KiB) per wave
+    constexpr int NKP = 24 / NW;                    // K pieces per wave per 48-key group
+    constexpr int NVP = 72 / NW;                    // V pieces per wave
+    constexpr int NT = (AT_NB + NW - 1) / NW;       // cooperative key tiles per wave (max)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                    // [144][136]
-    float* Vs = smem + AT_S * AT_KS;     // [144][132]
+    float* Ks = smem;
+    float* Vs = smem + AT_TILE;
+    float* dummy = smem + 2 * AT_TILE;              // 256 floats
+    float* stats = dummy + 256;                     // [NW][16][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;           // query block
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int seq = blockIdx.x / n_head, head = blockIdx.x % n_head;
+
+    int item, q0, nq;
+    if (split) {      // blocks b and b + 8 (same XCD) are the two halves of one item
+        const int b = blockIdx.x;
+        item = (b >> 4) * 8 + (b & 7);
+        const int half = (b >> 3) & 1;
+        q0 = half ? 5 : 0;
+        nq = half ? 4 : 5;
+    } else {
+        item = blockIdx.x;
+        q0 = 0;
+        nq = AT_NB;
+    }
+    if (item >= n_items) return;
+    const bool coop = nq > OWNED;
+    const int seq = item / n_head, head = item % n_head;
     const int D = n_head * AT_DH;
     const size_t ldq = (size_t)3 * D;
-    const float* base = qkv + (size_t)seq * AT_S * ldq + head * AT_DH;
-    const float* qg = base;
-    const float* kg = base + D;
-    const float* vg = base + 2 * D;
+    const float* qg = qkv + (size_t)seq * AT_S * ldq + head * AT_DH;
+    const float* kg = qg + D;
+    const float* vg = qg + 2 * D;
 
-    // ---- phase 0: K -> LDS, V -> registers ----------------------------------------------------
-    f32x4 kr[AT_UNITS], vr[AT_UNITS];
+    // ---- issue: Q rows of this workgroup -> V buffer (swizzled like K), all of K -> K buffer ------------------
+    const int half_row = lane >> 5, cphys = lane & 31;
 #pragma unroll
-    for (int i = 0; i < AT_UNITS; ++i) {
-        const int u = tid + i * AT_THREADS;
-        const int row = u >> 5, c4 = u & 31;
-        kr[i] = *reinterpret_cast<const f32x4*>(kg + (size_t)row * ldq + c4 * 4);
-    }
-    // Q fragments for this wave's 16 queries: lane (query li, g) holds Q[q][16*ks + 4g + j]
-    f32x4 qf[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        qf[ks] = *reinterpret_cast<const f32x4*>(qg + (size_t)(wave * 16 + li) * ldq + ks * 16 + lg * 4);
-#pragma unroll
-    for (int i = 0; i < AT_UNITS; ++i) {
-        const int u = tid + i * AT_THREADS;
-        const int row = u >> 5, c4 = u & 31;
-        *reinterpret_cast<f32x4*>(Ks + row * AT_KS + c4 * 4) = kr[i];
+    for (int i = 0; i < NQP; ++i) {
+        const int lp = i * NW + wave;                                   // local piece = local rows 2lp, 2lp + 1
+        const bool ok = lp < nq * 8;
+        const int lr = ok ? 2 * lp + half_row : half_row;
+        const float* src = qg + (size_t)(q0 * 16 + lr) * ldq + ((cphys ^ (lr & 15)) << 2);
+        at_dma16(src, ok ? Vs + lp * 256 : dummy);
     }
 #pragma unroll
-    for (int i = 0; i < AT_UNITS; ++i) {
-        const int u = tid + i * AT_THREADS;
-        const int row = u >> 5, c4 = u & 31;
-        vr[i] = *reinterpret_cast<const f32x4*>(vg + (size_t)row * ldq + c4 * 4);
-    }
-    __syncthreads();
+    for (int G = 0; G < 3; ++G)
+#pragma unroll
+        for (int i = 0; i < NKP; ++i) {
+            const int piece = 24 * G + i * NW + wave;
+            const int row = 2 * piece + half_row;
+            at_dma16(kg + (size_t)row * ldq + ((cphys ^ (row & 15)) << 2), Ks + piece * 256);
+        }
+    AT_WAIT_VM(3 * NKP);                 // this wave's Q pieces have landed
+    __builtin_amdgcn_s_barrier();        // ... and everybody else's
 
-    // ---- phase 1: S^T[key][query] = sum_d K[key][d] Q[query][d] -------------------------------
+    // Q fragments: lane (query li, g) holds Q[q][16 ks + 4 g + j], j = 0..3
+    f32x4 qf[8], qc[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        qf[ks] = *reinterpret_cast<const f32x4*>(Vs + (wave * 16 + li) * AT_DH + (((ks * 4 + lg) ^ li) << 2));
+        qc[ks] = *reinterpret_cast<const f32x4*>(Vs + ((coop ? OWNED : 0) * 16 + li) * AT_DH + (((ks * 4 + lg) ^ li) << 2));
+    }
+    AT_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();        // every wave has its Q: the V buffer may be overwritten
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+        const int piece = i * NW + wave;
+        at_dma16(vg + (size_t)(2 * piece + half_row) * ldq + (cphys << 2), Vs + piece * 256);
+    }
+
+    // ---- QK^T of the owned block, one 48-key group at a time as K lands ----------------------------------------
     f32x4 sacc[AT_NB];
 #pragma unroll
     for (int kb = 0; kb < AT_NB; ++kb) sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int G = 0; G < 3; ++G) {
+        if (G == 0) AT_WAIT_VM(2 * NKP + NVP);
+        else if (G == 1) AT_WAIT_VM(NKP + NVP);
+        else AT_WAIT_VM(NVP);
+        __builtin_amdgcn_s_barrier();
+        auto kread = [&](f32x4* kf, int ks) {
 #pragma unroll
-        for (int kb = 0; kb < AT_NB; ++kb) {
-            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kb * 16 + li) * AT_KS + ks * 16 + lg * 4);
+            for (int c = 0; c < 3; ++c)
+                kf[c] = *reinterpret_cast<const f32x4*>(Ks + ((3 * G + c) * 16 + li) * AT_DH + (((ks * 4 + lg) ^ li) << 2));
+        };
+        f32x4 kf[2][3];                  // fragments of step ks + 1 are in flight under the MFMAs of step ks
+        kread(kf[0], 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8) kread(kf[(ks + 1) & 1], ks + 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j], qf[ks][j], sacc[kb], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    sacc[3 * G + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks & 1][c][j], qf[ks][j], sacc[3 * G + c], 0, 0, 0);
+        }
+    }
+    // cooperative block: this wave's key tiles
+    f32x4 cs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (coop) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int kb = wave + t * NW;
+            if (kb < AT_NB) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kb * 16 + li) * AT_DH + (((ks * 4 + lg) ^ li) << 2));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        cs[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j], qc[ks][j], cs[t], 0, 0, 0);
+                }
+            }
         }
     }
 
-    // park V in LDS now (its global loads were in flight during phase 1)
+    // ---- softmax of the owned block over the 144 keys of query li (normalised before P.V, like the reference) ----
+    constexpr float LOG2E = 1.4426950408889634f;
+    {
+        float mx = sacc[0][0];
 #pragma unroll
-    for (int i = 0; i < AT_UNITS; ++i) {
-        const int u = tid + i * AT_THREADS;
-        const int row = u >> 5, c4 = u & 31;
-        *reinterpret_cast<f32x4*>(Vs + row * AT_VS + c4 * 4) = vr[i];
+        for (int kb = 0; kb < AT_NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mb = mx * LOG2E;
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < AT_NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], LOG2E, -mb));
+                sacc[kb][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kb = 0; kb < AT_NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[kb][r] *= inv;
+    }
+    // cooperative block: un-normalised P_w with this wave's own maximum / sum
+    float c_m = -INFINITY, c_l = 0.f;
+    if (coop) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (wave + t * NW < AT_NB)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c_m = fmaxf(c_m, cs[t][r]);
+        c_m = fmaxf(c_m, __shfl_xor(c_m, 16));
+        c_m = fmaxf(c_m, __shfl_xor(c_m, 32));
+        const float mb = c_m * LOG2E;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (wave + t * NW < AT_NB)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(cs[t][r], LOG2E, -mb));
+                    cs[t][r] = e;
+                    c_l += e;
+                }
+        c_l += __shfl_xor(c_l, 16);
+        c_l += __shfl_xor(c_l, 32);
     }
 
-    // ---- phase 2: softmax over the 144 keys of query li ---------------------------------------
-    float mx = sacc[0][0];
-#pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float e = expf(sacc[kb][r] - mx);
-            sacc[kb][r] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int kb = 0; kb < AT_NB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[kb][r] *= inv;
+    AT_WAIT_VM(0);                       // V has landed
+    __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading K
 
-    __syncthreads();   // V visible
-
-    // ---- phase 3: O[query][d] = sum_key P[query][key] V[key][d] -------------------------------
-    float* out = ctx + ((size_t)seq * AT_S + wave * 16) * D + head * AT_DH;
+    // ---- P.V of the owned block ----------------------------------------------------------------------------------
+    {
+        float* out = ctx + ((size_t)seq * AT_S + (q0 + wave) * 16) * D + head * AT_DH;
 #pragma unroll
-    for (int db = 0; db < 8; ++db) {
-        f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int db = 0; db < 2; ++db) {
+            f32x4 oacc[4];
 #pragma unroll
-        for (int kb = 0; kb < AT_NB; ++kb) {
-            const float* vp = Vs + (kb * 16 + lg * 4) * AT_VS + db * 16 + li;
+            for (int m = 0; m < 4; ++m) oacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto vread = [&](int st) {      // step st = 4 kb + j: keys 16 kb + 4 g + j
+                return *reinterpret_cast<const f32x4*>(Vs + ((st >> 2) * 16 + lg * 4 + (st & 3)) * AT_DH + db * 64 + li * 4);
+            };
+            f32x4 vf[3];                    // two steps (8 MFMAs) of read latency cover
+            vf[0] = vread(0);
+            vf[1] = vread(1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)   // operands swapped (V on the "A" side): the tile comes out as O^T
-                oacc = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[j * AT_VS], sacc[kb][j], oacc, 0, 0, 0);
+            for (int st = 0; st < 4 * AT_NB; ++st) {
+                if (st + 2 < 4 * AT_NB) vf[(st + 2) % 3] = vread(st + 2);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[st >> 2][st & 3], vf[st % 3][m], oacc[m], 0, 0, 0);
+            }
+            // oacc[m][r] = O[query 4g + r][d = 64 db + 4 li + m]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<f32x4*>(out + (size_t)(lg * 4 + r) * D + db * 64 + li * 4) =
+                    f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]};
         }
-        // oacc[r] = O[query = li][d = 16*db + 4*lg + r]: four consecutive floats -> one 16-byte store
-        *reinterpret_cast<f32x4*>(out + (size_t)li * D + db * 16 + lg * 4) = oacc;
     }
+    if (!coop) return;                   // uniform per workgroup
+
+    // ---- cooperative block: partial O_w over this wave's keys -> LDS (K buffer) -> combine ---------------------------
+    float* part = Ks + wave * (16 * AT_DH);     // [16][128]
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        f32x4 oacc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) oacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int kb = wave + t * NW;
+            if (kb < AT_NB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (kb * 16 + lg * 4 + j) * AT_DH + db * 64 + li * 4);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cs[t][j], vf[m], oacc[m], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4*>(part + (lg * 4 + r) * AT_DH + db * 64 + li * 4) =
+                f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]};
+    }
+    if (lg == 0) {
+        stats[(wave * 16 + li) * 2 + 0] = c_m;
+        stats[(wave * 16 + li) * 2 + 1] = c_l;
+    }
+    AT_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    {
+        float* out = ctx + ((size_t)seq * AT_S + (q0 + OWNED) * 16) * D + head * AT_DH;
+        for (int u = tid; u < 16 * 32; u += NW * 64) {
+            const int q = u >> 5, c4 = u & 31;
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) M = fmaxf(M, stats[(w * 16 + q) * 2]);
+            float e[NW], L = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                e[w] = __builtin_amdgcn_exp2f((stats[(w * 16 + q) * 2] - M) * LOG2E);
+                L = fmaf(e[w], stats[(w * 16 + q) * 2 + 1], L);
+            }
+            const float inv = 1.0f / L;
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(Ks + w * (16 * AT_DH) + q * AT_DH + c4 * 4);
+                const float s = e[w] * inv;
+                o[0] = fmaf(s, pv[0], o[0]);
+                o[1] = fmaf(s, pv[1], o[1]);
+                o[2] = fmaf(s, pv[2], o[2]);
+                o[3] = fmaf(s, pv[3], o[3]);
+            }
+            *reinterpret_cast<f32x4*>(out + (size_t)q * D + c4 * 4) = o;
+        }
+    }
+}
+
+template <int NW>
+static int set_lds_attr(int dev) {
+    static bool attr_set[64] = {};
+    if (dev < 64 && !attr_set[dev]) {
+        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel<NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(AT_LDS_FLOATS * sizeof(float))));
+        attr_set[dev] = true;
+    }
+    return ROHM_OK;
 }
 
 int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, hipStream_t s) {
     ROHM_ARG_CHECK(n_seq > 0 && n_head > 0, "attention: empty problem");
-    ROHM_ARG_CHECK(((uintptr_t)qkv % 16) == 0, "attention: qkv must be 16-byte aligned");
-    const size_t lds = (size_t)AT_S * (AT_KS + AT_VS) * sizeof(float);
-    static bool attr_set[64] = {};
+    ROHM_ARG_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 16) == 0, "attention: qkv / ctx must be 16-byte aligned");
+    const size_t lds = AT_LDS_FLOATS * sizeof(float);
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 64 && !attr_set[dev]) {
-        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
+    const int items = n_seq * n_head;
+    // One 8-wave workgroup per item takes ~1.6x the time of a 4-wave half-item workgroup: split while the halves
+    // still fit the chip in fewer (weighted) rounds.
+    constexpr int kCUs = 256;
+    const int rounds_full = (items + kCUs - 1) / kCUs, rounds_split = (2 * items + kCUs - 1) / kCUs;
+    const bool split = 10 * rounds_split <= 16 * rounds_full;
+    prof::Scope ps("attention", 4.0 * AT_S * AT_S * AT_DH * (double)items, 4.0 * 4.0 * AT_S * AT_DH * (double)items, s);
+    if (split) {
+        if (int e = set_lds_attr<4>(dev)) return e;
+        const int grid = ((items + 7) / 8) * 16;
+        hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(grid), dim3(256), lds, s, qkv, ctx, n_head, items, 1);
+    } else {
+        if (int e = set_lds_attr<8>(dev)) return e;
+        hipLaunchKernelGGL(attention_f32_kernel<8>, dim3(items), dim3(512), lds, s, qkv, ctx, n_head, items, 0);
     }
-    prof::Scope ps("attention", 4.0 * AT_S * AT_S * AT_DH * (double)n_seq * n_head,
-                   4.0 * 4.0 * AT_S * AT_DH * (double)n_seq * n_head, s);
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(n_seq * n_head), dim3(AT_THREADS), lds, s, qkv, ctx, n_head);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }

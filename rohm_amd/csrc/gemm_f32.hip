@@ -48,7 +48,7 @@ __device__ __forceinline__ int lds_off(int row, int slot) {   // float index ins
     return row * BK + ((slot ^ ((row >> 1) & 7)) << 2);
 }
 
-// Exact-erf GELU (activation="gelu", model/posenet.py:67).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <=
+// erf-form GELU (activation="gelu", model/posenet.py:67; NOT the tanh approximation).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <=
 // 1.5e-7, i.e. at fp32 resolution of the 1 + erf term) -- branch-free, one rcp + one exp, ~3x cheaper than the
 // library erff in a 72-element-per-lane epilogue.
 __device__ __forceinline__ float gelu_erf(float x) {
