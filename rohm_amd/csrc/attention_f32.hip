@@ -38,18 +38,33 @@ constexpr int AT_NB = 9;       // 16-row blocks
 constexpr int AT_TILE = AT_S * AT_DH;              // floats per K / V image
 constexpr int AT_LDS_FLOATS = 2 * AT_TILE + 512;   // + 1 KiB DMA landing zone + 1 KiB statistics
 
-#define AT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define AT_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15), through the
+// builtin so that hipcc's own wait-count bookkeeping sees the DMA queue drain: while it believes an LDS-DMA is pending
+// it degrades every LDS wait to lgkmcnt(0).
+#define AT_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+#define AT_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14))
 
 __device__ __forceinline__ void at_dma16(const float* src, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// Phase stamps for scripts/probes/attn_timeline.hip (compiled only there, with -DAT_TIMELINE).
+#ifdef AT_TIMELINE
+#define AT_TL_PARAM , unsigned long long* __restrict__ tl
+#define AT_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        if (lane == 0) tl[((size_t)blockIdx.x * NW + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+#else
+#define AT_TL_PARAM
+#define AT_STAMP(i)
+#endif
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __restrict__ qkv,
                                                                 float* __restrict__ ctx, int n_head, int n_items,
-                                                                int split) {
+                                                                int split AT_TL_PARAM) {
     constexpr int OWNED = NW;                       // query blocks owned by one wave each
     constexpr int NQP = (NW == 8) ? 9 : 10;         // Q staging pieces (1 KiB) per wave
     constexpr int NKP = 24 / NW;                    // K pieces per wave per 48-key group
@@ -79,6 +94,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
         nq = AT_NB;
     }
     if (item >= n_items) return;
+    AT_STAMP(0);
     const bool coop = nq > OWNED;
     const int seq = item / n_head, head = item % n_head;
     const int D = n_head * AT_DH;
@@ -97,16 +113,20 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
         const float* src = qg + (size_t)(q0 * 16 + lr) * ldq + ((cphys ^ (lr & 15)) << 2);
         at_dma16(src, ok ? Vs + lp * 256 : dummy);
     }
-#pragma unroll
-    for (int G = 0; G < 3; ++G)
+    // Only what the first MFMA needs goes out first (Q + the first 48 keys): with the rest of K and V queued behind
+    // them every CU's first bytes arrive later (measured: first MFMA at 7.2 us instead of ~5 at B = 64).
+    auto issue_k = [&](int G) {
 #pragma unroll
         for (int i = 0; i < NKP; ++i) {
             const int piece = 24 * G + i * NW + wave;
             const int row = 2 * piece + half_row;
             at_dma16(kg + (size_t)row * ldq + ((cphys ^ (row & 15)) << 2), Ks + piece * 256);
         }
-    AT_WAIT_VM(3 * NKP);                 // this wave's Q pieces have landed
+    };
+    issue_k(0);
+    AT_WAIT_VM(NKP);                     // this wave's Q pieces have landed
     __builtin_amdgcn_s_barrier();        // ... and everybody else's
+    AT_STAMP(1);
 
     // Q fragments: lane (query li, g) holds Q[q][16 ks + 4 g + j], j = 0..3
     f32x4 qf[8], qc[8];
@@ -117,6 +137,8 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     }
     AT_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();        // every wave has its Q: the V buffer may be overwritten
+    issue_k(1);
+    issue_k(2);
 #pragma unroll
     for (int i = 0; i < NVP; ++i) {
         const int piece = i * NW + wave;
@@ -129,22 +151,30 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     for (int kb = 0; kb < AT_NB; ++kb) sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int G = 0; G < 3; ++G) {
-        if (G == 0) AT_WAIT_VM(2 * NKP + NVP);
+        if (G == 0) AT_WAIT_VM(2 * NKP + NVP);       // (group 0 was issued before groups 1, 2 and V)
         else if (G == 1) AT_WAIT_VM(NKP + NVP);
         else AT_WAIT_VM(NVP);
         __builtin_amdgcn_s_barrier();
+        AT_STAMP(2 + G);
         auto kread = [&](f32x4* kf, int ks) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 kf[c] = *reinterpret_cast<const f32x4*>(Ks + ((3 * G + c) * 16 + li) * AT_DH + (((ks * 4 + lg) ^ li) << 2));
         };
-        f32x4 kf[2][3];                  // fragments of step ks + 1 are in flight under the MFMAs of step ks
+        // While a DMA is in flight hipcc waits lgkmcnt(0) before the first MFMA of every step, so the prefetch of step
+        // ks + 1 is issued AFTER that wait (behind the first three MFMAs) and has nine MFMAs to land.
+        f32x4 kf[2][3];
         kread(kf[0], 0);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            if (ks + 1 < 8) kread(kf[(ks + 1) & 1], ks + 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int c = 0; c < 3; ++c)
+                sacc[3 * G + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks & 1][c][0], qf[ks][0], sacc[3 * G + c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < 8) kread(kf[(ks + 1) & 1], ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     sacc[3 * G + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks & 1][c][j], qf[ks][j], sacc[3 * G + c], 0, 0, 0);
@@ -170,6 +200,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
         }
     }
 
+    AT_STAMP(5);
     // ---- softmax of the owned block over the 144 keys of query li (normalised before P.V, like the reference) ----
     constexpr float LOG2E = 1.4426950408889634f;
     {
@@ -222,8 +253,44 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
         c_l += __shfl_xor(c_l, 32);
     }
 
+    AT_STAMP(6);
     AT_WAIT_VM(0);                       // V has landed
     __builtin_amdgcn_s_barrier();        // ... for every wave; and every wave is done reading K
+    AT_STAMP(7);
+
+    // ---- cooperative block first: partial O_w over this wave's keys -> LDS (the K buffer is free now); the combine
+    // comes after the owned block, so the LDS writes and the statistics land underneath 288 MFMAs ---------------------
+    if (coop) {
+        float* part = Ks + wave * (16 * AT_DH);     // [16][128]
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            f32x4 oacc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) oacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int kb = wave + t * NW;
+                if (kb < AT_NB) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (kb * 16 + lg * 4 + j) * AT_DH + db * 64 + li * 4);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cs[t][j], vf[m], oacc[m], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<f32x4*>(part + (lg * 4 + r) * AT_DH + db * 64 + li * 4) =
+                    f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]};
+        }
+        if (lg == 0) {
+            stats[(wave * 16 + li) * 2 + 0] = c_m;
+            stats[(wave * 16 + li) * 2 + 1] = c_l;
+        }
+    }
+    AT_STAMP(9);
 
     // ---- P.V of the owned block ----------------------------------------------------------------------------------
     {
@@ -236,15 +303,26 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
             auto vread = [&](int st) {      // step st = 4 kb + j: keys 16 kb + 4 g + j
                 return *reinterpret_cast<const f32x4*>(Vs + ((st >> 2) * 16 + lg * 4 + (st & 3)) * AT_DH + db * 64 + li * 4);
             };
-            f32x4 vf[3];                    // two steps (8 MFMAs) of read latency cover
-            vf[0] = vread(0);
-            vf[1] = vread(1);
+            // steps are taken in pairs (8 MFMAs); the two reads of the next pair go out behind the first MFMA
+            f32x4 vf[2][2];
+            vf[0][0] = vread(0);
+            vf[0][1] = vread(1);
 #pragma unroll
-            for (int st = 0; st < 4 * AT_NB; ++st) {
-                if (st + 2 < 4 * AT_NB) vf[(st + 2) % 3] = vread(st + 2);
+            for (int sp = 0; sp < 2 * AT_NB; ++sp) {
+                const int st = 2 * sp;
+                oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[st >> 2][st & 3], vf[sp & 1][0][0], oacc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sp + 1 < 2 * AT_NB) {
+                    vf[(sp + 1) & 1][0] = vread(st + 2);
+                    vf[(sp + 1) & 1][1] = vread(st + 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 1; m < 4; ++m)
+                    oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[st >> 2][st & 3], vf[sp & 1][0][m], oacc[m], 0, 0, 0);
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[st >> 2][st & 3], vf[st % 3][m], oacc[m], 0, 0, 0);
+                    oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[(st + 1) >> 2][(st + 1) & 3], vf[sp & 1][1][m], oacc[m], 0, 0, 0);
             }
             // oacc[m][r] = O[query 4g + r][d = 64 db + 4 li + m]
 #pragma unroll
@@ -253,39 +331,12 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
                     f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]};
         }
     }
+    AT_STAMP(8);
     if (!coop) return;                   // uniform per workgroup
 
-    // ---- cooperative block: partial O_w over this wave's keys -> LDS (K buffer) -> combine ---------------------------
-    float* part = Ks + wave * (16 * AT_DH);     // [16][128]
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        f32x4 oacc[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) oacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int kb = wave + t * NW;
-            if (kb < AT_NB) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (kb * 16 + lg * 4 + j) * AT_DH + db * 64 + li * 4);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cs[t][j], vf[m], oacc[m], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<f32x4*>(part + (lg * 4 + r) * AT_DH + db * 64 + li * 4) =
-                f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]};
-    }
-    if (lg == 0) {
-        stats[(wave * 16 + li) * 2 + 0] = c_m;
-        stats[(wave * 16 + li) * 2 + 1] = c_l;
-    }
     AT_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
+    AT_STAMP(10);
     {
         float* out = ctx + ((size_t)seq * AT_S + (q0 + OWNED) * 16) * D + head * AT_DH;
         for (int u = tid; u < 16 * 32; u += NW * 64) {
@@ -313,8 +364,10 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
             *reinterpret_cast<f32x4*>(out + (size_t)q * D + c4 * 4) = o;
         }
     }
+    AT_STAMP(11);
 }
 
+#ifndef AT_TIMELINE
 template <int NW>
 static int set_lds_attr(int dev) {
     static bool attr_set[64] = {};
@@ -351,5 +404,6 @@ int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, hipStr
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
+#endif  // AT_TIMELINE
 
 }  // namespace rohm

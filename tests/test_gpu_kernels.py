@@ -52,7 +52,7 @@ def test_layernorm(M):
     assert max_abs(out.cpu(), ref) < 5e-6
 
 
-@pytest.mark.parametrize('n_seq,n_head', [(1, 4), (3, 4), (2, 2)])
+@pytest.mark.parametrize('n_seq,n_head', [(1, 4), (3, 4), (2, 2), (32, 4), (33, 4), (64, 4), (100, 4)])   # split / full launch shapes
 def test_attention(n_seq, n_head):
     from rohm_amd import ops
     D = n_head * 128
