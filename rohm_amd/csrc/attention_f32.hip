@@ -69,6 +69,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     constexpr int NQP = (NW == 8) ? 9 : 10;         // Q staging pieces (1 KiB) per wave
     constexpr int NKP = 24 / NW;                    // K pieces per wave per 48-key group
     constexpr int NVP = 72 / NW;                    // V pieces per wave
+    constexpr int NV3 = NVP / 3;                    // ... per instalment
     constexpr int NT = (AT_NB + NW - 1) / NW;       // cooperative key tiles per wave (max)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
@@ -137,13 +138,18 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     }
     AT_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();        // every wave has its Q: the V buffer may be overwritten
-    issue_k(1);
-    issue_k(2);
+    // The rest of K and V is issued in three instalments, one ahead of each QK^T group: issuing all 27 (54) DMA
+    // instructions here stalls every wave in the issue loop until the CU's memory queue has drained (measured: first
+    // MFMA at 16k cycles although Q had landed at 8k).
+    auto issue_v = [&](int part) {
 #pragma unroll
-    for (int i = 0; i < NVP; ++i) {
-        const int piece = i * NW + wave;
-        at_dma16(vg + (size_t)(2 * piece + half_row) * ldq + (cphys << 2), Vs + piece * 256);
-    }
+        for (int i = part * NV3; i < (part + 1) * NV3; ++i) {
+            const int piece = i * NW + wave;
+            at_dma16(vg + (size_t)(2 * piece + half_row) * ldq + (cphys << 2), Vs + piece * 256);
+        }
+    };
+    issue_k(1);
+    issue_v(0);
 
     // ---- QK^T of the owned block, one 48-key group at a time as K lands ----------------------------------------
     f32x4 sacc[AT_NB];
@@ -151,9 +157,17 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     for (int kb = 0; kb < AT_NB; ++kb) sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int G = 0; G < 3; ++G) {
-        if (G == 0) AT_WAIT_VM(2 * NKP + NVP);       // (group 0 was issued before groups 1, 2 and V)
-        else if (G == 1) AT_WAIT_VM(NKP + NVP);
-        else AT_WAIT_VM(NVP);
+        // issue order: Q, K0 | K1, V0 | K2, V1 | V2  (vmcnt retires in issue order)
+        if (G == 0) {
+            AT_WAIT_VM(NKP + NV3);                   // K0 landed; K1, V0 may be in flight
+        } else if (G == 1) {
+            issue_k(2);
+            issue_v(1);
+            AT_WAIT_VM(NV3 + NKP + NV3);             // K1 landed; V0, K2, V1 in flight
+        } else {
+            issue_v(2);
+            AT_WAIT_VM(2 * NV3);                     // K2 (and V0) landed; V1, V2 in flight
+        }
         __builtin_amdgcn_s_barrier();
         AT_STAMP(2 + G);
         auto kread = [&](f32x4* kf, int ks) {
