@@ -209,6 +209,134 @@ def golden_guided_step(ref):
     print('guided_step.npz', os.path.getsize(os.path.join(OUT, 'guided_step.npz')))
 
 
+SCHEME_CASES = (
+    ('amass', dict(mask_scheme='lower')),
+    ('amass', dict(mask_scheme='upper', iter2_cond_noisy_pose=False, iter2_cond_noisy_traj=False)),
+    ('amass', dict(mask_scheme='full', full_seed=5)),
+    ('amass', dict(mask_scheme='full', infill_traj=True)),
+    ('amass', dict(mask_scheme='lower', input_noise=False)),
+    ('amass', dict(mask_scheme='full', input_noise=False, infill_traj=True, sample_iter=3)),
+    ('amass', dict(mask_scheme='lower', repr_abs_only=False)),
+    ('prox', dict(sample_iter=3)),
+    ('prox', dict(sample_iter=2, iter2_cond_noisy_pose=True, iter2_cond_noisy_traj=True)),
+)
+
+
+def scheme_case(kind, kw, B=2):
+    """Seeded inputs, pre-made stage outputs and the args namespace of one driver-loop case (shared by the generator
+    and the tests).  Stage outputs are pre-made tensors: the glue under test is everything BETWEEN the samplers."""
+    import types
+    a = dict(sample_iter=2, repr_abs_only=True, infill_traj=False, traj_mask_ratio=0.1, mask_scheme='lower',
+             input_noise=True, iter2_cond_noisy_traj=(kind == 'amass'), iter2_cond_noisy_pose=(kind == 'amass'),
+             early_stop=(kind == 'prox'), cond_fn_with_grad=True, timestep_respacing_eval='', full_seed=None)
+    a.update(kw)
+    args = types.SimpleNamespace(**a)
+    tfd = 13 if args.repr_abs_only else 22
+    abs_ch = [0, 2, 3, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18]
+    body_t = synth.synthetic_smplx_tensors(0)
+    s_traj, s_pose = synth.synthetic_stats(0), synth.synthetic_stats(1)
+    f32 = lambda seed, shape: torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32))
+    clean_t = synth.walking_motion(50, B, 144, *s_traj, body_t)
+    noisy_t = clean_t + 0.05 * f32(51, clean_t.shape)
+    clean_p = synth.walking_motion(50, B, 144, *s_pose, body_t)
+    noisy_p = clean_p + 0.05 * f32(52, clean_p.shape)
+    sel = abs_ch if args.repr_abs_only else list(range(22))
+    bt = {'cond': noisy_t[:, :, sel].contiguous(), 'motion_repr_clean': clean_t, 'motion_repr_noisy': noisy_t}
+    bp = {'motion_repr_clean': clean_p, 'motion_repr_noisy': noisy_p}
+    if kind == 'prox':
+        g = np.random.Generator(np.random.PCG64(53))
+        jv = (g.uniform(size=(B, 145, 22)) < 0.8).astype(np.float32)
+        vec = np.ones((B, 145, 294), np.float32)
+        for j in range(22):
+            vec[:, :, 22 + 3 * j:25 + 3 * j] = jv[:, :, j:j + 1]
+            vec[:, :, 88 + 3 * j:91 + 3 * j] = jv[:, :, j:j + 1]
+            if j > 0:
+                vec[:, :, 154 + 6 * (j - 1):160 + 6 * (j - 1)] = jv[:, :, j:j + 1]
+        bp['mask_joint_vis'], bp['mask_vec_vis'] = torch.from_numpy(jv), torch.from_numpy(vec)
+    n = args.sample_iter
+    traj_out = [synth.walking_motion(60 + i, B, 144, *s_traj, body_t)[:, :, sel].contiguous() for i in range(n)]
+    pose_out = [synth.walking_motion(70 + i, B, 143, *s_pose, body_t).permute(0, 2, 1).unsqueeze(2).contiguous() for i in range(n)]
+    return args, tfd, body_t, s_traj, s_pose, bt, bp, traj_out, pose_out
+
+
+def digest(t, n_proj=6):
+    """Shape + seeded random projections of a tensor (float64): pins every element to ~1e-7 relative at 6 numbers."""
+    x = np.asarray(t.detach().cpu().double().numpy() if torch.is_tensor(t) else t, dtype=np.float64).reshape(-1)
+    g = np.random.Generator(np.random.PCG64(x.size % 9973 + 17))
+    return np.concatenate([[x.size, x.sum(), np.abs(x).sum()], g.standard_normal((n_proj, x.size)) @ x])
+
+
+def golden_scheme(ref):
+    """The drivers' inference-iteration loops, EXECUTED from the reference scripts' own text (test_amass_full.py:217-384,
+    test_prox_egobody.py:214-324; the scripts cannot be imported -- configargparse / datasets / checkpoints at module
+    level) with stub samplers that return pre-made outputs and log what each stage was handed.  Stored: digests of
+    every stage input, of traj_rec_full per iteration and of the dict entries the scripts rely on afterwards."""
+    import textwrap
+    import types
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    src = {'amass': (open(os.path.join(refload.REF_ROOT, 'test_amass_full.py')).read().split('\n'), 216, 384),
+           'prox': (open(os.path.join(refload.REF_ROOT, 'test_prox_egobody.py')).read().split('\n'), 213, 324)}
+    out = {}
+    for ci, (kind, kw) in enumerate(SCHEME_CASES):
+        args, tfd, body_t, s_traj, s_pose, bt, bp, traj_out, pose_out = scheme_case(kind, kw)
+        lines, lo, hi = src[kind]
+        block = textwrap.dedent('\n'.join(lines[lo:hi]))
+        log = []
+
+        class Stub:
+            def __init__(self, outs, name):
+                self.outs, self.name = list(outs), name
+
+            def eval_losses(self, model=None, batch=None, shape=None, **kw2):
+                o = self.outs.pop(0)
+                assert list(o.shape) == list(shape), (self.name, o.shape, shape)
+                log.append((self.name, {k: batch[k].detach().clone() for k in ('cond', 'control_cond') if k in batch},
+                            {k: kw2.get(k) for k in ('grad_type', 'early_stop', 'cond_fn_with_grad')}))
+                return None, o
+        tds = types.SimpleNamespace(traj_feat_dim=tfd, pose_feat_dim=272, Mean=s_traj[0], Std=s_traj[1])
+        pds = types.SimpleNamespace(traj_feat_dim=22, pose_feat_dim=272, Mean=s_pose[0], Std=s_pose[1])
+        ns = {'np': np, 'torch': torch, 'print': lambda *a, **k: None, 'args': args,
+              'dist_util': types.SimpleNamespace(dev=lambda: torch.device('cpu')),
+              'test_batch_traj': {k: v.clone() for k, v in bt.items()}, 'test_batch_pose': {k: v.clone() for k, v in bp.items()},
+              'test_traj_dataset': tds, 'test_pose_dataset': pds,
+              'diffusion_trajnet_eval': Stub(traj_out[:1], 'traj'), 'diffusion_trajnet_control_eval': Stub(traj_out[1:], 'traj'),
+              'diffusion_posenet_eval': Stub(pose_out, 'pose'),
+              'model_trajnet': None, 'model_trajnet_control': None, 'model_posenet': None, 'smplx_neutral': body,
+              'REPR_LIST': ref.other_utils.REPR_LIST, 'REPR_DIM_DICT': ref.other_utils.REPR_DIM_DICT,
+              'recover_from_repr_smpl': ref.motion_repr.recover_from_repr_smpl, 'get_repr_smplx': ref.motion_repr.get_repr_smplx,
+              'rot6d_to_rotmat': ref.quaternion.rot6d_to_rotmat, 'rotation_matrix_to_angle_axis': ref.konia.rotation_matrix_to_angle_axis}
+        if args.full_seed is not None:
+            torch.manual_seed(args.full_seed)
+        exec(compile(block, f'{kind}[{lo + 1}:{hi}]', 'exec'), ns)
+        pre = f'case{ci}_'
+        out[pre + 'n_calls'] = len(log)
+        for k, (name, tens, kws) in enumerate(log):
+            out[pre + f'call{k}_name'] = name
+            out[pre + f'call{k}_kw'] = repr(sorted(kws.items()))
+            for kk, v in tens.items():
+                out[pre + f'call{k}_{kk}'] = digest(v)
+                out[pre + f'call{k}_{kk}_shape'] = np.asarray(v.shape)
+        out[pre + 'traj_rec_full'] = digest(ns['traj_rec_full'])
+        if args.full_seed is not None:
+            # the script draws `torch.FloatTensor(bs).uniform_(0, clip_len - 1).long()` once per masked iteration and
+            # nothing else touches the generator: replay the draws
+            torch.manual_seed(args.full_seed)
+            n_draw = args.sample_iter if args.iter2_cond_noisy_pose else 1
+            # clip_len = motion_repr_clean.shape[1]: 143 in iteration 0, 294 once the tensor is [bs, 294, 1, T] (:335, :375)
+            starts = np.stack([torch.FloatTensor(2).uniform_(0, (143 if k == 0 else 294) - 1).long().numpy() for k in range(n_draw)])
+            assert np.array_equal(starts[-1], ns['start'].numpy()), (starts, ns['start'])
+            out[pre + 'full_mask_start'] = starts
+        tb, pb = ns['test_batch_traj'], ns['test_batch_pose']
+        out[pre + 'after_traj_noisy'] = digest(tb['motion_repr_noisy'])
+        out[pre + 'after_traj_cond'] = digest(tb['cond'])
+        out[pre + 'after_pose_noisy_shape'] = np.asarray(pb['motion_repr_noisy'].shape)
+        out[pre + 'after_pose_clean_shape'] = np.asarray(pb['motion_repr_clean'].shape)
+        print('scheme case', ci, kind, kw, [n for n, _, _ in log])
+    np.savez_compressed(os.path.join(OUT, 'scheme.npz'), n_cases=len(SCHEME_CASES), **out)
+    print('scheme.npz', os.path.getsize(os.path.join(OUT, 'scheme.npz')))
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -243,6 +371,9 @@ def main():
     if sys.argv[1:] == ['rel']:
         warnings.filterwarnings('ignore')
         return golden_rel(refload.load())
+    if sys.argv[1:] == ['scheme']:
+        warnings.filterwarnings('ignore')
+        return golden_scheme(refload.load())
     if sys.argv[1:] == ['guided_step']:
         warnings.filterwarnings('ignore')
         return golden_guided_step(refload.load())
@@ -339,6 +470,7 @@ def main():
     golden_rel(ref)
     golden_eval_losses(ref)
     golden_guided_step(ref)
+    golden_scheme(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -2,10 +2,11 @@
 (test_amass_full.py:218-386): TrajNet -> trajectory re-derivation -> condition / occlusion-mask assembly ->
 PoseNet -> (next iteration) TrajControl -> ... on top of the oracle networks, sampler and geometry.
 
-The driver is a script (argparse + datasets + checkpoints), not an importable function, so this glue cannot be
-executed from the reference here: PARITY UNPINNED for the glue itself; every block it calls is pinned
-(nets / sampler / guidance / re-derivation goldens).  Noise is injected; the random start of the 'full' mask
-(:365) is an argument.
+The drivers are scripts (argparse + datasets + checkpoints at module level), not importable functions; their loop
+bodies are pinned by EXECUTING the scripts' own text (test_amass_full.py:217-384, test_prox_egobody.py:214-324) with stub
+samplers in oracle/make_golden.py::golden_scheme -> tests/golden/scheme.npz, which tests/test_scheme_oracle.py holds
+this restatement to (9 configurations).  Noise is injected; the random starts of the 'full' mask (:363-367, one draw per
+masked iteration) are an argument.
 """
 from __future__ import annotations
 
@@ -128,8 +129,14 @@ def amass_iterations(traj_stage, pose_stage, batch_traj, batch_pose, stats_traj,
         mask_iter_num = args.sample_iter if args.iter2_cond_noisy_pose else 1               # :338-339
         if it < mask_iter_num:
             if args.mask_scheme == 'full' and not args.infill_traj:
-                start = args.full_mask_start.long()
-                end = torch.clamp(start + 30, max=cond.shape[1])
+                # the script draws a NEW random start in every masked iteration (:363-367); `full_mask_start` is the
+                # list of those draws (or one tensor reused for all iterations)
+                # `clip_len` there is motion_repr_clean.shape[1] (:335), which is T = 143 in iteration 0 and 294 afterwards
+                # (the tensor was permuted to [bs, 294, 1, T] at :375): later draws range over [0, 293) and mostly fall
+                # outside the clip.  Reproduced as is.
+                fms = args.full_mask_start
+                start = (fms[it] if isinstance(fms, (list, tuple)) else fms).long()
+                end = torch.clamp(start + 30, max=batch_pose['motion_repr_clean'].shape[1])
             elif args.mask_scheme == 'full':
                 start = torch.full((B,), 65, dtype=torch.long)
                 end = start + int(args.traj_mask_ratio * 145)

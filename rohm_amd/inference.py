@@ -97,7 +97,8 @@ def run_amass_iterations(args, models, diffusions, test_batch_traj, test_batch_p
     'posenet' (the objects the script builds at :132-188).  `args`: the script's namespace (sample_iter,
     repr_abs_only, infill_traj, traj_mask_ratio, iter2_cond_noisy_traj, iter2_cond_noisy_pose, input_noise,
     mask_scheme, cond_fn_with_grad, early_stop, timestep_respacing_eval).  `full_mask_start`: the random start
-    frames of the 'full' mask (drawn with the script's formula if None).
+    frames of the 'full' mask: None = drawn with the script's formula in every masked iteration, as the script does; a
+    tensor [bs] = the same starts in every iteration; a list = one tensor per iteration.
     Returns (val_output_pose [bs,294,1,143], val_output_traj [bs,144,tfd], [traj_rec_full per iteration])."""
     dev = test_batch_traj['cond'].device
     tfd, pfd = test_traj_dataset.traj_feat_dim, test_traj_dataset.pose_feat_dim
@@ -143,10 +144,16 @@ def run_amass_iterations(args, models, diffusions, test_batch_traj, test_batch_p
         mask_iter_num = args.sample_iter if args.iter2_cond_noisy_pose else 1               # :338-339
         if it < mask_iter_num:
             if args.mask_scheme == 'full' and not args.infill_traj:                         # :361-368
-                bs, clip_len = cond.shape[:2]
+                # The script draws a NEW start in every masked iteration with `clip_len = motion_repr_clean.shape[1]`
+                # (:335, :363-367), which is T = 143 in iteration 0 and 294 afterwards (the tensor is [bs, 294, 1, T]
+                # from :375 on): later draws range over [0, 293) and mostly fall outside the clip.  Reproduced as is.
+                bs, clip_len = test_batch_pose['motion_repr_clean'].shape[:2]
                 if full_mask_start is None:
-                    full_mask_start = torch.FloatTensor(bs).uniform_(0, clip_len - 1).long()
-                start = full_mask_start.to(dev)
+                    start = torch.FloatTensor(bs).uniform_(0, clip_len - 1).long().to(dev)
+                elif isinstance(full_mask_start, (list, tuple)):
+                    start = full_mask_start[it].to(dev)
+                else:
+                    start = full_mask_start.to(dev)
                 end = torch.clamp(start + 30, max=clip_len)
             apply_occlusion_mask(cond, args.mask_scheme, test_pose_dataset.traj_feat_dim, start, end)
         test_batch_pose['cond'] = cond.permute(0, 2, 1).unsqueeze(-2)                       # :374 (view, as the script)

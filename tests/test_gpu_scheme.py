@@ -277,3 +277,46 @@ def test_real_networks_teacher_forced(guided, monkeypatch):
         den = rec_repr.numpy() * s_traj[1] + s_traj[0]
         joints = G.joints_from_smplx(G.split_repr(torch.from_numpy(den)), body).numpy()
         _close(a.cpu().numpy(), b.numpy(), joints)
+
+
+@pytest.mark.parametrize('ci', range(9))
+def test_glue_vs_reference_script_golden(ci):
+    """rohm_amd.inference against what the REFERENCE scripts' own statements did (tests/golden/scheme.npz, recorded
+    while test_amass_full.py:217-384 / test_prox_egobody.py:214-324 were executed with stub samplers): every tensor
+    handed to a stage, the re-derived trajectory and the dict entries the scripts use afterwards."""
+    from helpers import golden
+    from oracle.make_golden import SCHEME_CASES, digest, scheme_case
+    from test_scheme_oracle import close
+    from rohm_amd import inference as INF
+    from rohm_amd.body_model import SMPLXLayer
+    g = golden('scheme.npz')
+    assert int(g['n_cases']) == len(SCHEME_CASES) == 9
+    kind, kw = SCHEME_CASES[ci]
+    args, tfd, body_t, s_traj, s_pose, bt, bp, traj_out, pose_out = scheme_case(kind, kw)
+    pre = f'case{ci}_'
+    fms = [torch.from_numpy(r) for r in g[pre + 'full_mask_start']] if pre + 'full_mask_start' in g else None
+    glog = []
+    diffs = {'trajnet': StubDiffusion([traj_out[0].to(DEV)], glog, 'traj'),
+             'trajnet_control': StubDiffusion([t.to(DEV) for t in traj_out[1:]], glog, 'traj'),
+             'posenet': StubDiffusion([p.to(DEV) for p in pose_out], glog, 'pose')}
+    models = {'trajnet': None, 'trajnet_control': None, 'posenet': None}
+    tds, pds = TrajDataset(*s_traj), PoseDataset(*s_pose)
+    tds.traj_feat_dim = tfd
+    gbt, gbp = _clone(bt, DEV), _clone(bp, DEV)
+    layer = SMPLXLayer.from_tensors(body_t).to(DEV)
+    if kind == 'amass':
+        _, _, recs = INF.run_amass_iterations(args, models, diffs, gbt, gbp, tds, pds, layer, full_mask_start=fms)
+    else:
+        _, _, recs = INF.run_prox_iterations(args, models, diffs, gbt, gbp, tds, pds, layer)
+    assert len(glog) == int(g[pre + 'n_calls'])
+    for k, (name, tens) in enumerate(glog):
+        assert name == str(g[pre + f'call{k}_name'])
+        assert set(tens) == {kk for kk in ('cond', 'control_cond') if pre + f'call{k}_{kk}' in g}, (k, name)
+        for kk, v in tens.items():
+            assert list(v.shape) == list(g[pre + f'call{k}_{kk}_shape']), (k, kk)
+            assert close(digest(v), g[pre + f'call{k}_{kk}'], tol=2e-5), (k, name, kk)
+    assert close(digest(recs[-1]), g[pre + 'traj_rec_full'], tol=2e-5)
+    assert close(digest(gbt['motion_repr_noisy']), g[pre + 'after_traj_noisy'], tol=2e-5)
+    assert close(digest(gbt['cond']), g[pre + 'after_traj_cond'], tol=2e-5)
+    assert list(gbp['motion_repr_noisy'].shape) == list(g[pre + 'after_pose_noisy_shape'])
+    assert list(gbp['motion_repr_clean'].shape) == list(g[pre + 'after_pose_clean_shape'])
