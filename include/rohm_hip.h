@@ -204,6 +204,15 @@ void rohm_smplx_destroy(rohm_smplx_t* h);
 int rohm_smplx_joints(const rohm_smplx_t* h, const float* pose, int n_pose, const float* betas,
                       const float* transl, int N, float* joints, int n_out, rohm_stream_t stream);
 
+/* Dataset-side per-frame SMPL-X work, batched over the frames of a recording (data_loaders/dataloader_video.py:121-142,
+ * :282-300 -- one smplx call, one cam2world transform and one update_globalRT_for_smplx (utils/other_utils.py:189-240)
+ * PER FRAME there): axis-angle global_orient [N,3], body_pose [N,63], betas [N,10], transl [N,3] (device, float32),
+ * rigid = cam2world [4,4] row-major (device float32) -> joints_world [N,22,3] (float32) and orient_transl_world [N,6]
+ * (float64: new global_orient, new transl -- the two entries of the parameter dict the function rewrites). */
+int rohm_smplx_frames_to_world(const rohm_smplx_t* h, const float* global_orient, const float* body_pose,
+                               const float* betas, const float* transl, const float* rigid, int N, float* joints_world,
+                               double* orient_transl_world, rohm_stream_t stream);
+
 size_t rohm_guidance_workspace_bytes(int B, int T);
 
 /* guide_skating_with_smpl (model/posenet.py:196-257, compute_grad='x_0'): x0 [B,294,1,T] normalised

@@ -337,6 +337,46 @@ def golden_scheme(ref):
     print('scheme.npz', os.path.getsize(os.path.join(OUT, 'scheme.npz')))
 
 
+def frames_inputs(seed=0, N=40):
+    """Seeded per-frame SMPL-X parameters + a rigid cam2world (float32, as the pickles / json of the datasets hold)."""
+    g = np.random.Generator(np.random.PCG64(900 + seed))
+    f = lambda *sh, s=1.0: (g.standard_normal(sh) * s).astype(np.float32)
+    params = {'transl': f(N, 3) + np.array([0, 0, 3], np.float32), 'global_orient': f(N, 3, s=1.2),
+              'betas': f(N, 10), 'body_pose': f(N, 63, s=0.4)}
+    params['global_orient'][0] = 0.0                         # identity and tiny rotations (scipy's small-angle branches)
+    params['global_orient'][1] = np.array([1e-5, -2e-5, 3e-5], np.float32)
+    params['global_orient'][2] = np.array([3.1, 0.2, -0.1], np.float32)          # close to pi
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, :3] = synth._rodrigues_np(np.array([[0.9, -1.7, 0.4]]))[0].astype(np.float32)
+    c2w[:3, 3] = np.array([0.3, -1.2, 2.5], np.float32)
+    return params, c2w
+
+
+def golden_frames(ref):
+    """The per-frame dataset statements of data_loaders/dataloader_video.py:121-142, one frame at a time as the loader
+    runs them, through the reference's OWN `update_globalRT_for_smplx` (utils/other_utils.py:189-240) and the oracle body
+    model in place of smplx."""
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    params, cam2world_np = frames_inputs()
+    cam2world = torch.from_numpy(cam2world_np).float()
+    cam_R, cam_t = cam2world[:3, :3].reshape([3, 3]), cam2world[:3, 3].reshape([1, 3])
+    joints_world, smplx_world = [], []
+    for i in range(len(params['transl'])):
+        param = {k: v[i:i + 1] for k, v in params.items()}
+        torch_param = {k: torch.tensor(v) for k, v in param.items()}
+        smpl_output = body(return_verts=True, **torch_param)
+        joints_cam = smpl_output.joints[:, 0:22, :]
+        joints = torch.matmul(cam_R, joints_cam.permute(0, 2, 1)).permute(0, 2, 1) + cam_t
+        joints_world.append(joints[0].detach().numpy())
+        d = ref.other_utils.update_globalRT_for_smplx(dict(param), cam2world.detach().cpu().numpy(),
+                                                      delta_T=joints_cam[:, 0].detach().cpu().numpy() - param['transl'])
+        smplx_world.append(np.concatenate([d['global_orient'], d['transl'], d['betas'], d['body_pose']], axis=-1)[0])
+    np.savez_compressed(os.path.join(OUT, 'frames.npz'), seed=0, body_seed=0, joints_world=np.asarray(joints_world),
+                        smplx_world=np.asarray(smplx_world))
+    print('frames.npz', os.path.getsize(os.path.join(OUT, 'frames.npz')), np.asarray(smplx_world).dtype)
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -371,6 +411,9 @@ def main():
     if sys.argv[1:] == ['rel']:
         warnings.filterwarnings('ignore')
         return golden_rel(refload.load())
+    if sys.argv[1:] == ['frames']:
+        warnings.filterwarnings('ignore')
+        return golden_frames(refload.load())
     if sys.argv[1:] == ['scheme']:
         warnings.filterwarnings('ignore')
         return golden_scheme(refload.load())
@@ -471,6 +514,7 @@ def main():
     golden_eval_losses(ref)
     golden_guided_step(ref)
     golden_scheme(ref)
+    golden_frames(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     'rohm_smplx_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int]),
     'rohm_smplx_destroy': (None, [C.c_void_p]),
+    'rohm_smplx_frames_to_world': (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rohm_smplx_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_int, C.c_void_p]),
     'rohm_guidance_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),

@@ -277,6 +277,104 @@ __global__ __launch_bounds__(64) void smplx_joints_kernel(const float* __restric
         for (int c = 0; c < 3; ++c) out[((size_t)n * n_out + j) * 3 + c] = f.P[j][c] + transl[(size_t)n * 3 + c];
 }
 
+
+// ---- dataset-side per-frame work -------------------------------------------------------------
+// data_loaders/dataloader_video.py:121-142 / :282-300 run, for every frame of a recording: one SMPL-X forward ->
+// joints in camera coordinates -> joints to world -> update_globalRT_for_smplx (utils/other_utils.py:221-240: the
+// global orientation / translation re-expressed in the world frame; float64 numpy + scipy Rotation).  Here: one thread
+// per frame, FK in float32 (as smplx computes it), the rigid-transform part in float64 with scipy's own formulas
+// (from_rotvec / from_matrix / as_rotvec incl. their small-angle series) so results agree to rounding.
+__device__ __forceinline__ void rotvec_to_matrix_f64(const double* rv, double* M) {
+    const double a2 = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
+    const double a = sqrt(a2);
+    const double sc = (a <= 1e-3) ? 0.5 - a2 / 48.0 + a2 * a2 / 3840.0 : sin(a / 2.0) / a;
+    const double x = sc * rv[0], y = sc * rv[1], z = sc * rv[2], w = cos(a / 2.0);
+    const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+    const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+    M[0] = x2 - y2 - z2 + w2; M[1] = 2 * (xy - zw);       M[2] = 2 * (xz + yw);
+    M[3] = 2 * (xy + zw);       M[4] = -x2 + y2 - z2 + w2; M[5] = 2 * (yz - xw);
+    M[6] = 2 * (xz - yw);       M[7] = 2 * (yz + xw);       M[8] = -x2 - y2 + z2 + w2;
+}
+
+__device__ __forceinline__ void matrix_to_rotvec_f64(const double* M, double* rv) {
+    // scipy Rotation.from_matrix (Markley's quaternion extraction) followed by as_rotvec
+    double dec[4] = {M[0], M[4], M[8], M[0] + M[4] + M[8]};
+    int choice = 0;
+    for (int i = 1; i < 4; ++i)
+        if (dec[i] > dec[choice]) choice = i;
+    double q[4];
+    if (choice != 3) {
+        const int i = choice, j = (i + 1) % 3, k = (j + 1) % 3;
+        q[i] = 1 - dec[3] + 2 * M[i * 3 + i];
+        q[j] = M[j * 3 + i] + M[i * 3 + j];
+        q[k] = M[k * 3 + i] + M[i * 3 + k];
+        q[3] = M[k * 3 + j] - M[j * 3 + k];
+    } else {
+        q[0] = M[7] - M[5];
+        q[1] = M[2] - M[6];
+        q[2] = M[3] - M[1];
+        q[3] = 1 + dec[3];
+    }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+    if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    const double ang = 2 * atan2(sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]), q[3]);
+    const double a2 = ang * ang;
+    const double sc = (ang <= 1e-3) ? 2 + a2 / 12 + 7 * a2 * a2 / 2880 : ang / sin(ang / 2);
+    rv[0] = sc * q[0]; rv[1] = sc * q[1]; rv[2] = sc * q[2];
+}
+
+__global__ __launch_bounds__(64) void frames_to_world_kernel(const float* __restrict__ global_orient,
+                                                             const float* __restrict__ body_pose,
+                                                             const float* __restrict__ betas,
+                                                             const float* __restrict__ transl,
+                                                             const float* __restrict__ rigid,      // [4,4] row-major
+                                                             const float* __restrict__ Jt, const float* __restrict__ Js,
+                                                             const int* __restrict__ parents,
+                                                             float* __restrict__ joints_world,     // [N,22,3]
+                                                             double* __restrict__ orient_transl,   // [N,6]
+                                                             int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    FkCtx f;
+    rodrigues(global_orient + (size_t)n * 3, f.R[0]);
+    for (int j = 1; j < NJ; ++j) rodrigues(body_pose + ((size_t)n * (NJ - 1) + (j - 1)) * 3, f.R[j]);
+    float beta[NBETA];
+    for (int k = 0; k < NBETA; ++k) beta[k] = betas[(size_t)n * NBETA + k];
+    rest_joints(Jt, Js, beta, f.Jr);
+    fk_forward(f, parents);
+    const float t[3] = {transl[(size_t)n * 3], transl[(size_t)n * 3 + 1], transl[(size_t)n * 3 + 2]};
+    float pelvis[3];
+    for (int j = 0; j < NJ; ++j) {
+        float pc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pc[c] = f.P[j][c] + t[c];                 // camera coordinates (float32, as smplx)
+        if (j == 0) { pelvis[0] = pc[0]; pelvis[1] = pc[1]; pelvis[2] = pc[2]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)                                           // torch.matmul(cam_R, joints^T)^T + cam_t
+            joints_world[((size_t)n * NJ + j) * 3 + c] =
+                rigid[c * 4] * pc[0] + rigid[c * 4 + 1] * pc[1] + rigid[c * 4 + 2] * pc[2] + rigid[c * 4 + 3];
+    }
+    // update_globalRT_for_smplx: delta_T and (transl + delta_T) are float32 there, the rest float64
+    float dT[3], tp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dT[c] = pelvis[c] - t[c]; tp[c] = t[c] + dT[c]; }
+    const double rv[3] = {(double)global_orient[(size_t)n * 3], (double)global_orient[(size_t)n * 3 + 1],
+                          (double)global_orient[(size_t)n * 3 + 2]};
+    double Rb[9], Rn[9], rvn[3];
+    rotvec_to_matrix_f64(rv, Rb);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rn[i * 3 + j] = (double)rigid[i * 4] * Rb[j] + (double)rigid[i * 4 + 1] * Rb[3 + j] + (double)rigid[i * 4 + 2] * Rb[6 + j];
+    matrix_to_rotvec_f64(Rn, rvn);
+    for (int c = 0; c < 3; ++c) {
+        const double tn = (double)rigid[c * 4] * tp[0] + (double)rigid[c * 4 + 1] * tp[1] + (double)rigid[c * 4 + 2] * tp[2] +
+                          (double)rigid[c * 4 + 3];
+        orient_transl[(size_t)n * 6 + c] = rvn[c];
+        orient_transl[(size_t)n * 6 + 3 + c] = tn - (double)dT[c];
+    }
+}
+
 // fold of the joint regressor: one block per (joint, coord[, beta]) row, fp64 accumulation
 __global__ __launch_bounds__(256) void fold_regressor_kernel(const float* __restrict__ Jreg, const float* __restrict__ src,
                                                              int src_stride, int src_off, int V, float* __restrict__ out,
@@ -369,6 +467,19 @@ int rohm_smplx_joints(const rohm_smplx_t* h, const float* pose, int n_pose, cons
     prof::Scope ps("smplx_joints", 0.0, 4.0 * N * (n_pose * 3 + 13 + n_out * 3), (hipStream_t)stream);
     hipLaunchKernelGGL(smplx_joints_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, n_pose, betas,
                        transl, h->d_Jt, h->d_Js, h->d_parents, joints, n_out, N);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+int rohm_smplx_frames_to_world(const rohm_smplx_t* h, const float* global_orient, const float* body_pose,
+                               const float* betas, const float* transl, const float* rigid, int N, float* joints_world,
+                               double* orient_transl_world, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && global_orient && body_pose && betas && transl && rigid && joints_world && orient_transl_world,
+                   "smplx_frames_to_world: null argument");
+    if (N <= 0) return ROHM_OK;
+    prof::Scope ps("frames_to_world", 0.0, 4.0 * N * (3 + 63 + 10 + 3 + 66) + 8.0 * N * 6, (hipStream_t)stream);
+    hipLaunchKernelGGL(frames_to_world_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, global_orient,
+                       body_pose, betas, transl, rigid, h->d_Jt, h->d_Js, h->d_parents, joints_world, orient_transl_world, N);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
