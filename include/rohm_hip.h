@@ -75,11 +75,13 @@ int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, in
 int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, int D,
                        rohm_stream_t stream);
 
-/* Multi-head self-attention over S = 144 tokens, head dim 128, for n_seq sequences:
- * qkv[n_seq*144, 3*n_head*128] (q | k | v blocks, q already scaled by 128^-1/2)
- * -> ctx[n_seq*144, n_head*128].  Replaces the scaled-dot-product inside
- * nn.MultiheadAttention (model/posenet.py:63-69). */
-int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, rohm_stream_t stream);
+/* Multi-head self-attention over n_tok tokens, head dim 64 or 128, for n_seq sequences:
+ * qkv[n_seq*n_tok, 3*n_head*head_dim] (q | k | v blocks, q already scaled by head_dim^-1/2)
+ * -> ctx[n_seq*n_tok, n_head*head_dim].  Replaces the scaled-dot-product inside
+ * nn.MultiheadAttention (model/posenet.py:63-69).  n_tok = 144, head_dim = 128 (every released
+ * configuration) runs the specialised kernel; other shapes the general one. */
+int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, int n_tok, int head_dim,
+                       rohm_stream_t stream);
 
 /* One DDPM ancestral update, elementwise over n floats:
  *   x_prev = c1*x0 + c2*x_t + guid_scale*guid_grad + sigma*noise

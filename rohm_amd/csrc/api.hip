@@ -106,9 +106,10 @@ int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, i
     return launch_layernorm(x, gamma, beta, M, D, (hipStream_t)stream);
 }
 
-int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, rohm_stream_t stream) {
+int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, int n_tok, int head_dim,
+                       rohm_stream_t stream) {
     ROHM_ARG_CHECK(qkv && ctx, "attention: null pointer");
-    return launch_attention(qkv, ctx, n_seq, n_head, (hipStream_t)stream);
+    return launch_attention(qkv, ctx, n_seq, n_head, n_tok, head_dim, (hipStream_t)stream);
 }
 
 int rohm_ddpm_step(const float* x_t, const float* x0, const float* noise, const float* guid_grad, float c1,

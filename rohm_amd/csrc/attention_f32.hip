@@ -382,6 +382,122 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
 }
 
 #ifndef AT_TIMELINE
+
+// ---- any sequence length / head dim 64 or 128 ----------------------------------------------------------------------
+// The reference class takes any clip length and its default width is 256 = 4 heads x 64 (model/posenet.py:12-20); the
+// kernel above is specialised to the shape of every released configuration (S = 144, d_h = 128).  This one is the
+// general path: one workgroup of four waves per (item, group of four 16-query blocks), keys streamed through LDS in
+// chunks of 64 with an online softmax (running row maximum / sum, accumulators rescaled when the maximum moves), keys
+// beyond S masked, rows beyond S not stored.  Same MFMA, same fragment layouts; correctness first (register-staged
+// loads, b32 V fragment reads), ~half the speed of the specialised kernel at its own shape.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_f32_generic_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                                    int n_head, int S) {
+    constexpr int KS = DH + 8, VS = DH + 4, CH = 64, NDB = DH / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                 // [CH][KS]
+    float* Vs = smem + CH * KS;       // [CH][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nqg = (S + 63) / 64;
+    const int item = blockIdx.x / nqg, qg = blockIdx.x % nqg;
+    const int seq = item / n_head, head = item % n_head;
+    const int D = n_head * DH;
+    const size_t ldq = (size_t)3 * D;
+    const float* qg_ = qkv + (size_t)seq * S * ldq + head * DH;
+    const float* kg = qg_ + D;
+    const float* vg = qg_ + 2 * D;
+    const int q_row = qg * 64 + wave * 16 + li;                       // this lane's query
+    f32x4 qf[DH / 16];
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks)
+        qf[ks] = (q_row < S) ? *reinterpret_cast<const f32x4*>(qg_ + (size_t)q_row * ldq + ks * 16 + lg * 4)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 oacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int k0 = 0; k0 < S; k0 += CH) {
+        __syncthreads();                                              // previous chunk fully consumed
+        for (int u = tid; u < CH * (DH / 4); u += 256) {
+            const int r = u / (DH / 4), c4 = u % (DH / 4);
+            const bool ok = k0 + r < S;
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 kv = ok ? *reinterpret_cast<const f32x4*>(kg + (size_t)(k0 + r) * ldq + c4 * 4) : z;
+            const f32x4 vv = ok ? *reinterpret_cast<const f32x4*>(vg + (size_t)(k0 + r) * ldq + c4 * 4) : z;
+            *reinterpret_cast<f32x4*>(Ks + r * KS + c4 * 4) = kv;
+            *reinterpret_cast<f32x4*>(Vs + r * VS + c4 * 4) = vv;
+        }
+        __syncthreads();
+        const int nkb = (min(CH, S - k0) + 15) / 16;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};                    // S^T[key 16kb + 4g + r][query li]
+#pragma unroll
+            for (int ks = 0; ks < DH / 16; ++ks) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kb * 16 + li) * KS + ks * 16 + lg * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j], qf[ks][j], sc, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k0 + kb * 16 + lg * 4 + r >= S) sc[r] = -INFINITY;
+                mx = fmaxf(mx, sc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);                     // finite: the first block always has a valid key
+            const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);      // exp(-inf) = 0 on the first block
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[r] = __builtin_amdgcn_exp2f((sc[r] - m_new) * LOG2E);
+                ps += sc[r];
+            }
+            ps += __shfl_xor(ps, 16);
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * corr + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[db][r] *= corr;
+                const float* vp = Vs + (kb * 16 + lg * 4) * VS + db * 16 + li;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)      // O^T = V^T P^T: the lane ends with O[query li][16 db + 4 g + r]
+                    oacc[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[j * VS], sc[j], oacc[db], 0, 0, 0);
+            }
+        }
+    }
+    if (q_row < S) {
+        const float inv = 1.0f / l_run;
+        float* out = ctx + ((size_t)seq * S + q_row) * D + head * DH;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+            *reinterpret_cast<f32x4*>(out + db * 16 + lg * 4) =
+                f32x4{oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv};
+    }
+}
+
+template <int DH>
+static int launch_generic(const float* qkv, float* ctx, int n_seq, int n_head, int S, hipStream_t s) {
+    const size_t lds = (size_t)64 * (2 * DH + 12) * sizeof(float);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    ROHM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev]) {
+        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_generic_kernel<DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    const int items = n_seq * n_head;
+    prof::Scope ps("attention_generic", 4.0 * S * S * DH * (double)items, 4.0 * 4.0 * S * DH * (double)items, s);
+    hipLaunchKernelGGL(attention_f32_generic_kernel<DH>, dim3(items * ((S + 63) / 64)), dim3(256), lds, s, qkv, ctx, n_head, S);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
 template <int NW>
 static int set_lds_attr(int dev) {
     static bool attr_set[64] = {};
@@ -394,9 +510,15 @@ static int set_lds_attr(int dev) {
     return ROHM_OK;
 }
 
-int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, hipStream_t s) {
-    ROHM_ARG_CHECK(n_seq > 0 && n_head > 0, "attention: empty problem");
+int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, int n_tok, int head_dim, hipStream_t s) {
+    ROHM_ARG_CHECK(n_seq > 0 && n_head > 0 && n_tok > 0, "attention: empty problem");
     ROHM_ARG_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 16) == 0, "attention: qkv / ctx must be 16-byte aligned");
+    if (n_tok != AT_S || head_dim != AT_DH) {
+        if (head_dim == 128) return launch_generic<128>(qkv, ctx, n_seq, n_head, n_tok, s);
+        if (head_dim == 64) return launch_generic<64>(qkv, ctx, n_seq, n_head, n_tok, s);
+        set_error("attention: head dim must be 64 or 128 (got %d)", head_dim);
+        return ROHM_ERR_UNSUPPORTED;
+    }
     const size_t lds = AT_LDS_FLOATS * sizeof(float);
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));

@@ -119,7 +119,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 
 // ---- other kernels -----------------------------------------------------------------------
 int launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
-int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, hipStream_t s);
+int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, int n_tok, int head_dim, hipStream_t s);
 // Graph-replayable variants: per-step values come from device tables indexed by a device-side step counter.
 int launch_ddpm_step_indexed(const float* x_t, const float* x0, const float* noise_base, const float* coef_tab,
                              const int* step_ctr, float* out, size_t n, hipStream_t s);

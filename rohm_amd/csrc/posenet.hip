@@ -41,6 +41,7 @@ struct rohm_posenet {
     float* pe;         // [pe_len, D]
     int pe_len;
     float *t_w0T, *t_b0, *t_w2T, *t_b2;   // time MLP, weights stored [in][out]
+    float* tok_table;  // [pe_len, D]  timestep token of every t (time MLP output + pe[0]), built once at create
     float *out_w, *out_b;                 // [Cout, D], [Cout]
     float *out_c;                         // LayerNorm folding of the last norm2 into the output head
     bool ln_fold;                         // LayerNorm folded into the surrounding GEMMs (default) or run as a kernel
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(1024) void timestep_token_kernel(const float* __res
     float* e = sh;
     float* h = sh + D;
     const int n = threadIdx.x;
-    int64_t t = t_dev ? t_dev[blockIdx.x] : t_host;
+    int64_t t = t_dev ? t_dev[blockIdx.x] : (t_host == -1 ? (int64_t)blockIdx.x : t_host);   // -1: row index = t (table build)
     if (t < 0) t = 0;
     if (t >= pe_len) t = pe_len - 1;
     e[n] = pe[(size_t)t * D + n];
@@ -102,6 +103,18 @@ __global__ __launch_bounds__(1024) void timestep_token_kernel(const float* __res
     float o = b2[n];
     for (int k = 0; k < D; ++k) o = fmaf(h[k], w2T[(size_t)k * D + n], o);
     tab0[(size_t)blockIdx.x * D + n] = o + pe[n];
+}
+
+// tab0[b] = tok_table[clamp(t_b)]: the timestep token of every possible t is computed ONCE at create (the time MLP only
+// depends on t), so a forward with per-sample timesteps -- every guided step of the PROX / AMASS tails -- gathers B rows
+// instead of running B x two 512x512 mat-vecs (77 us -> ~3 us per step at B = 32).
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ table, int rows,
+                                                            const int64_t* __restrict__ t_dev,
+                                                            float* __restrict__ tab0, int D) {
+    int64_t t = t_dev[blockIdx.x];
+    if (t < 0) t = 0;
+    if (t >= rows) t = rows - 1;
+    for (int n = threadIdx.x; n < D; n += blockDim.x) tab0[(size_t)blockIdx.x * D + n] = table[(size_t)t * D + n];
 }
 
 // x0[:, :traj] = cond[:, :traj] (posenet.py:94-95); optionally the DDPM update
@@ -220,7 +233,6 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
 static int check_shape(const rohm_posenet* p, int B, int T) {
     ROHM_ARG_CHECK(p != nullptr, "posenet: null handle");
     ROHM_ARG_CHECK(B > 0, "posenet: batch must be positive (got %d)", B);
-    ROHM_ARG_CHECK(T + 1 == 144, "posenet: this build supports T = 143 frames (144 tokens); got T=%d", T);
     ROHM_ARG_CHECK(T + 1 <= kMaxTok && T + 1 <= p->pe_len, "posenet: sequence too long");
     return ROHM_OK;
 }
@@ -231,11 +243,14 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     const int S = T + 1, D = p->D, M = B * S;
     // timestep token(s): per sample from device timesteps, or one precomputed row shared by the batch
     if (!tok_pre) {
-        const int rows = t_dev ? B : 1;
-        prof::Scope ps("timestep_token", 4.0 * D * D * rows, 8.0 * D * D, s);
-        hipLaunchKernelGGL(timestep_token_kernel, dim3(rows), dim3(D), 2 * D * sizeof(float), s, p->pe, p->pe_len,
-                           t_dev, t_host, p->t_w0T, p->t_b0, p->t_w2T, p->t_b2, w.tab0, D);
-        ROHM_LAUNCH_CHECK();
+        if (t_dev) {
+            prof::Scope ps("gather_tokens", 0.0, 8.0 * D * B, s);
+            hipLaunchKernelGGL(gather_tokens_kernel, dim3(B), dim3(256), 0, s, p->tok_table, p->pe_len, t_dev, w.tab0, D);
+            ROHM_LAUNCH_CHECK();
+        } else {
+            int64_t t = t_host < 0 ? 0 : (t_host >= p->pe_len ? p->pe_len - 1 : t_host);
+            tok_pre = p->tok_table + (size_t)t * D;
+        }
     }
     int rc;
     {   // fused input embed (+cond embed, + biases, + positional table)
@@ -263,7 +278,7 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         g.bias = lw.in_b; g.qcols = D; g.qscale = 1.0f / sqrtf((float)(D / p->H));
         if (fold && l > 0) ln_operand(g, w.stats_b, lw.in_c);
         if ((rc = launch_gemm(g, EPI_QKV, s))) return rc;
-        if ((rc = launch_attention(w.qkv, w.ctx, B, p->H, s))) return rc;
+        if ((rc = launch_attention(w.qkv, w.ctx, B, p->H, S, D / p->H, s))) return rc;
         g = GemmParams{};
         g.A = w.ctx; g.lda = D; g.W = lw.out_w; g.ldw = D; g.C = y; g.ldc = D; g.M = M; g.N = D; g.K = D;
         g.bias = lw.out_b; g.R = h; g.ldr = D;
@@ -331,8 +346,8 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
                         int n_layer, int c_in, int c_out, int traj_dim, int device) {
     ROHM_ARG_CHECK(out && w && w->layers, "posenet_create: null argument");
     ROHM_ARG_CHECK(d_model % 256 == 0 && d_model <= 1024, "posenet_create: d_model must be 256/512/1024");
-    ROHM_ARG_CHECK(n_head > 0 && d_model / n_head == 128 && d_model % n_head == 0,
-                   "posenet_create: head dim must be 128 (d_model=%d, n_head=%d)", d_model, n_head);
+    ROHM_ARG_CHECK(n_head > 0 && d_model % n_head == 0 && (d_model / n_head == 128 || d_model / n_head == 64),
+                   "posenet_create: head dim must be 64 or 128 (d_model=%d, n_head=%d)", d_model, n_head);
     ROHM_ARG_CHECK(d_ff % 64 == 0 && n_layer > 0, "posenet_create: bad d_ff/n_layer");
     ROHM_ARG_CHECK(c_out + traj_dim == c_in, "posenet_create: c_out + traj_dim must equal c_in");
     ROHM_ARG_CHECK(w->pe_len >= kMaxTok, "posenet_create: positional table too short");
@@ -345,6 +360,7 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
     size_t total = 0;
     auto cnt = [&](size_t n) { size_t o = total; total += align_up(n, 64); return o; };
     const size_t o_embed = cnt(D * p->KP), o_tab = cnt((size_t)kMaxTok * D), o_pe = cnt((size_t)w->pe_len * D);
+    const size_t o_tok = cnt((size_t)w->pe_len * D);
     const size_t o_w0 = cnt(D * D), o_b0 = cnt(D), o_w2 = cnt(D * D), o_b2 = cnt(D);
     const size_t o_ow = cnt((size_t)c_out * D), o_ob = cnt(c_out), o_oc = cnt(c_out);
     const size_t o_tmp = cnt(D * D);                      // staging for transposes / embed build
@@ -373,7 +389,7 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
             return ROHM_ERR_HIP;                                                        \
         }                                                                               \
     } while (0)
-    p->w_embed = a + o_embed; p->tab = a + o_tab; p->pe = a + o_pe;
+    p->w_embed = a + o_embed; p->tab = a + o_tab; p->pe = a + o_pe; p->tok_table = a + o_tok;
     p->t_w0T = a + o_w0; p->t_b0 = a + o_b0; p->t_w2T = a + o_w2; p->t_b2 = a + o_b2;
     p->out_w = a + o_ow; p->out_b = a + o_ob; p->out_c = a + o_oc;
     {
@@ -406,6 +422,9 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
     PUT(bc, w->in_c_b, D);
     hipLaunchKernelGGL(build_embed_kernel, dim3((unsigned)((D * p->KP + th - 1) / th)), dim3(th), 0, 0, wx, wc, p->w_embed, (int)D, c_in, p->KP);
     hipLaunchKernelGGL(build_tab_kernel, dim3((unsigned)((kMaxTok * D + th - 1) / th)), dim3(th), 0, 0, p->pe, bx, bc, p->tab, kMaxTok, (int)D);
+    // timestep tokens of every t in [0, pe_len)
+    hipLaunchKernelGGL(timestep_token_kernel, dim3((unsigned)w->pe_len), dim3((unsigned)D), 2 * D * sizeof(float), 0, p->pe,
+                       p->pe_len, (const int64_t*)nullptr, (int64_t)-1, p->t_w0T, p->t_b0, p->t_w2T, p->t_b2, p->tok_table, (int)D);
     ROHM_HIP_CHECK(hipDeviceSynchronize());
     float* lp = a + o_layers;
     p->layers.resize(n_layer);
@@ -493,21 +512,14 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
     ROHM_ARG_CHECK(n_steps <= kLoopChunk, "posenet_sample_loop: at most %d steps per call", kLoopChunk);
     if (n_steps == 0) return ROHM_OK;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;   // cond is constant over the loop
-    // all timestep tokens of this call in one launch (the embedder depends on t only, heads.py:145-146)
-    ROHM_HIP_CHECK(hipMemcpyAsync(w.t_all, t_model, (size_t)n_steps * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    {
-        prof::Scope ps("timestep_token", 4.0 * h->D * h->D * n_steps, 8.0 * h->D * h->D, s);
-        hipLaunchKernelGGL(timestep_token_kernel, dim3(n_steps), dim3(h->D), 2 * h->D * sizeof(float), s, h->pe,
-                           h->pe_len, w.t_all, (int64_t)0, h->t_w0T, h->t_b0, h->t_w2T, h->t_b2, w.tok_all, h->D);
-        ROHM_LAUNCH_CHECK();
-    }
+    // timestep tokens come from the table built at create (the embedder depends on t only, heads.py:145-146)
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
         ROHM_ARG_CHECK(sigma == 0.f || noise, "posenet_sample_loop: noise is required when sigma != 0");
         if ((rc = launch_pack(h, x, w.apack, B, T, 0, s))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
-        if ((rc = run_network(h, w, nullptr, t_model[i], w.tok_all + (size_t)i * h->D, x0, B, T, s))) return rc;
+        if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s))) return rc;
         if ((rc = launch_finish(x0, cond, x, noise ? noise + (size_t)i * n : nullptr, x, c1, c2, sigma, h->traj,
                                 h->Cin, T, n, s)))
             return rc;

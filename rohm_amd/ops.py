@@ -35,11 +35,14 @@ def layernorm_(x, gamma, beta):
     return x
 
 
-def attention(qkv, n_seq, n_head):
-    """qkv [n_seq*144, 3*n_head*128] (q pre-scaled) -> ctx [n_seq*144, n_head*128]."""
+def attention(qkv, n_seq, n_head, n_tok=144, head_dim=128):
+    """qkv [n_seq*n_tok, 3*n_head*head_dim] (q pre-scaled) -> ctx [n_seq*n_tok, n_head*head_dim]."""
     _lib.require_hip(qkv)
-    ctx = torch.empty(qkv.shape[0], n_head * 128, device=qkv.device, dtype=torch.float32)
-    check(lib().rohm_attention_f32(ptr(qkv), ptr(ctx), n_seq, n_head, stream_ptr(qkv.device)), 'rohm_attention_f32')
+    if qkv.shape != (n_seq * n_tok, 3 * n_head * head_dim):
+        raise ValueError(f'qkv must be [{n_seq * n_tok}, {3 * n_head * head_dim}], got {tuple(qkv.shape)}')
+    ctx = torch.empty(qkv.shape[0], n_head * head_dim, device=qkv.device, dtype=torch.float32)
+    check(lib().rohm_attention_f32(ptr(qkv), ptr(ctx), n_seq, n_head, n_tok, head_dim, stream_ptr(qkv.device)),
+          'rohm_attention_f32')
     return ctx
 
 

@@ -30,7 +30,7 @@ def main():
         net.load_state_dict(synth.trajnet_state_dict(1, trajcontrol=ctrl), strict=True)
         net = net.to(dev).eval()
         diff = create_gaussian_diffusion(Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev)
-        for B in (1, 32, 256):
+        for B in ((1, 32, 256) if len(sys.argv) < 2 else tuple(int(a) for a in sys.argv[1:])):
             batch = {'cond': torch.randn(B, 144, 13, device=dev), 'control_cond': torch.randn(B, 144, 272, device=dev)}
             run = lambda: diff.eval_losses(model=net, batch=batch, shape=[B, 144, 13], progress=False, clip_denoised=False,
                                            timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
@@ -49,7 +49,10 @@ def main():
             ksum = sum(v['total_ms'] for v in prof.values())
             n = sum(v['launches'] for v in prof.values())
             res[f'{"control" if ctrl else "vanilla"}_B{B}'] = {'wall_ms': round(wall * 1e3, 2), 'host_enqueue_ms': round(t_enq * 1e3, 2), 'kernel_event_ms': round(ksum, 2),
-                                                                'launches': n, 'clips_per_s': round(B / wall, 1)}
+                                                                'launches': n, 'clips_per_s': round(B / wall, 1),
+                                                                'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['total_ms'] / v['launches'] * 1e3, 2),
+                                                                                'share': round(v['total_ms'] / ksum, 3)}
+                                                                            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}}
     print(json.dumps(res, indent=1))
 
 

@@ -72,6 +72,25 @@ def test_attention(n_seq, n_head):
     assert max_abs(out2.cpu(), ref2) < 5e-6
 
 
+@pytest.mark.parametrize('n_seq,n_head,S,dh', [(2, 4, 100, 64), (1, 2, 77, 128), (3, 4, 144, 64), (2, 4, 200, 128),
+                                                (1, 1, 5, 64), (2, 3, 64, 128), (1, 4, 145, 128)])
+def test_attention_general_shapes(n_seq, n_head, S, dh):
+    """Any sequence length, head dim 64 / 128 (the reference class takes any clip length and defaults to 4 x 64)."""
+    from rohm_amd import ops
+    D = n_head * dh
+    qkv = seeded(n_seq * 7 + S, n_seq * S, 3 * D)
+    qkv[:, :D] *= dh ** -0.5
+    q, k, v = qkv.double().view(n_seq, S, 3, n_head, dh).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * S, D)
+    out = ops.attention(qkv.to(_dev()), n_seq, n_head, S, dh)
+    assert max_abs(out.cpu(), ref) < 5e-6
+    # un-scaled scores (|s| up to ~40): the running-maximum rescaling is exercised
+    qkv2 = seeded(n_seq * 7 + S + 1, n_seq * S, 3 * D)
+    q, k, v = qkv2.double().view(n_seq, S, 3, n_head, dh).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * S, D)
+    assert max_abs(ops.attention(qkv2.to(_dev()), n_seq, n_head, S, dh).cpu(), ref) < 1e-4
+
+
 def test_ddpm_step_kernels():
     from rohm_amd import ops
     from oracle import diffusion as odiff

@@ -194,3 +194,30 @@ def test_shape_errors_are_raised_before_the_c_abi():
         net({'x_t': x, 'cond': x[:1]}, torch.zeros(2, dtype=torch.int64, device=DEV))
     with pytest.raises(ValueError):
         net({'x_t': x, 'cond': x}, torch.zeros(3, dtype=torch.int64, device=DEV))
+
+
+@pytest.mark.parametrize('latent,heads,ff,T,B', [(256, 4, 1024, 99, 3), (512, 4, 1024, 60, 2), (512, 8, 512, 143, 2),
+                                                 (256, 2, 256, 195, 1)])
+def test_forward_other_widths_and_clip_lengths(latent, heads, ff, T, B):
+    """The reference class is not tied to the released configuration (model/posenet.py:12-20: latent_dim=256, 4 heads by
+    default, any clip length): widths 256 / 512, head dims 64 / 128 and other T go through the general attention kernel."""
+    from rohm_amd.model.posenet import PoseNet
+    net = PoseNet(PoseDataset(), 294, latent_dim=latent, ff_size=ff, num_layers=2, num_heads=heads, traj_feat_dim=22,
+                  body_model_path=torch.nn.Identity(), device=DEV)
+    sd = synth.posenet_state_dict(41, latent_dim=latent, ff_size=ff, num_layers=2)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    x, c = seeded(3, B, 294, 1, T), seeded(4, B, 294, 1, T)
+    t = torch.tensor([(337 * i + 11) % 1000 for i in range(B)])
+    ref = nets.posenet_forward(sd, x, c, t, n_head=heads, dtype=torch.float64)
+    y = net({'x_t': x.to(DEV), 'cond': c.to(DEV)}, t.to(DEV)).cpu()
+    assert max_abs(y, ref) < 1e-4
+    # and a short fused loop at this shape
+    diff = make_diffusion(6)
+    x_T, noises = cpu_noise_sequence(5, (B, 294, 1, T), 6)
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    _, out = diff.eval_losses(model=net, batch={'cond': c.to(DEV)}, shape=[B, 294, 1, T], progress=False,
+                              clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+    fn = lambda xx, i: nets.posenet_forward(sd, xx, c, torch.full((B,), i, dtype=torch.int64), n_head=heads)
+    ref = odiff.p_sample_loop(fn, x_T, noises, odiff.tables(odiff.cosine_betas(6)), list(range(6))[::-1])
+    assert max_abs(out.cpu(), ref) < 1e-3
