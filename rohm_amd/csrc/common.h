@@ -102,6 +102,7 @@ struct GemmParams {
     // chunks of its split and stores the raw partial tile to partial[split][m][n] (row stride ld_partial); a second
     // kernel sums the splits in a fixed order, adds the bias and writes C.  ksplit <= 1: off.  EPI_BIAS only.
     int ksplit; float* partial; int ld_partial;
+    int ksplit_defer;            // 1: leave the partial slabs un-reduced (the consumer sums them: trajnet.hip GroupNorm)
     // ---- LayerNorm folded into the GEMMs around it (posenet.hip).  A producer (bias+residual epilogue) writes
     // per-row partial sums of its OUTPUT, one (sum, sum of squares) pair per column tile: out_stats[m][tile_n][2].
     // A consumer whose normalised operand is LN(x) = (x - mu) rstd gamma + beta runs on the RAW x with

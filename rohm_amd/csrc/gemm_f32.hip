@@ -692,7 +692,7 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);
     ROHM_LAUNCH_CHECK();
     }
-    if (ksplit > 1) {
+    if (ksplit > 1 && !p.ksplit_defer) {
         prof::Scope pr("splitk_reduce", 0.0, 4.0 * ((double)ksplit + 1.0) * p.M * p.N, s);
         const long n = (long)p.M * ((p.N + 3) / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.partial, ksplit, p.M,

@@ -122,54 +122,148 @@ __global__ __launch_bounds__(256) void time_path_kernel(const int64_t* __restric
 // -> (+ residual) -> (+ second residual), channels-last (heads.py:98-104, 50-54; trajnet.py:240,259-271).
 // One block per (sample, group).
 struct GnArgs {
-    const float* y; int ldy;
+    const float* y; int ldy;            // conv output [B*T, ldy] -- or, with ksplit > 1, `ksplit` partial slabs of it
+    int ksplit; size_t slab;            //   (slab s at y + s * slab, row stride ldy) that still lack the conv bias
+    const float* cbias;
     const float *gamma, *beta;
     int C, T;
     const float* tb; int ldtb;          // [rows or 1][...] time bias slice for this block (nullable)
-    const float* res; int ldres;        // residual (nullable)
+    const float* res; int ldres;        // residual (nullable) -- or `res_ksplit` partial slabs of a 1x1 residual conv
+    int res_ksplit; size_t res_slab; const float* res_bias;
     const float* add2; int ldadd2;      // control residual (nullable)
     float* dst; int lddst;
     float* dst2; int lddst2;            // optional second destination (skip / concat copy)
 };
 
+// One block per (sample, group).  A group is (C/8 channels) x T <= 1280 values: each thread keeps its <= 5 values in
+// registers (ONE pass over memory; round 1 made three, with two 8-step block reductions), the statistics are two
+// wave-shuffle reductions + one LDS exchange each.  With split-K the block sums the partial slabs itself -- the
+// separate reduction kernel (35 of the 98 launches of a denoising step) disappears for every conv that feeds a
+// GroupNorm, and so does the round trip of the reduced tensor through memory.
+constexpr int kGnMaxPerThread = 5;
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();                    // sh may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// VEC: 16-byte accesses (every leading dimension a multiple of 4 floats, 16-byte aligned bases -- the layouts this
+// file builds); the scalar variant is the fallback for foreign strides.
+template <bool VEC>
 __global__ __launch_bounds__(256) void gn_mish_kernel(GnArgs a) {
+    constexpr int W = VEC ? 4 : 1;                  // floats per unit
+    constexpr int NU = VEC ? 2 : kGnMaxPerThread;   // units per thread
     const int b = blockIdx.x, g = blockIdx.y;
-    const int cg = a.C / 8;
-    const int n = cg * a.T;
-    const float* yb = a.y + (size_t)b * a.T * a.ldy + g * cg;
-    __shared__ float red[256];
+    const int cg = a.C >> 3;                        // channels per group: a power of two (4 .. 64)
+    const int ug = cg / W;                          // units per row of the group
+    const int sh_ug = 31 - __clz(ug);
+    const int n = cg * a.T, nu = n / W;
+    __shared__ float sh[4];
+    float v[NU][W];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += yb[(size_t)(i / cg) * a.ldy + (i % cg)];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
+    auto ldv = [&](const float* p, float* o) {
+        if constexpr (VEC) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+        else o[0] = *p;
+    };
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int i = threadIdx.x + k * 256;
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[k][e] = 0.f;
+        if (i < nu) {
+            const int t = i >> sh_ug, c = g * cg + (i & (ug - 1)) * W;
+            const float* p = a.y + ((size_t)b * a.T + t) * a.ldy + c;
+            ldv(p, v[k]);
+            if (a.ksplit > 1) {                     // fixed summation order (deterministic); 4 slabs in flight
+                int sp = 1;
+                for (; sp + 3 < a.ksplit; sp += 4) {
+                    float t0[W], t1[W], t2[W], t3[W];
+                    ldv(p + (size_t)sp * a.slab, t0);
+                    ldv(p + (size_t)(sp + 1) * a.slab, t1);
+                    ldv(p + (size_t)(sp + 2) * a.slab, t2);
+                    ldv(p + (size_t)(sp + 3) * a.slab, t3);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) v[k][e] = (((v[k][e] + t0[e]) + t1[e]) + t2[e]) + t3[e];
+                }
+                for (; sp < a.ksplit; ++sp) {
+                    float t0[W];
+                    ldv(p + (size_t)sp * a.slab, t0);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) v[k][e] += t0[e];
+                }
+                float cb[W];
+                ldv(a.cbias + c, cb);
+#pragma unroll
+                for (int e = 0; e < W; ++e) v[k][e] += cb[e];
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) s += v[k][e];
+        }
     }
-    const float mean = red[0] / (float)n;
-    __syncthreads();
+    const float mean = block_sum_256(s, sh) / (float)n;
     float q = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float d = yb[(size_t)(i / cg) * a.ldy + (i % cg)] - mean;
-        q += d * d;
-    }
-    red[threadIdx.x] = q;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    const float rstd = 1.0f / sqrtf(red[0] / (float)n + 1e-5f);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int t = i / cg, c = g * cg + (i % cg);
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+        if (threadIdx.x + k * 256 < nu)
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                const float d = v[k][e] - mean;
+                q += d * d;
+            }
+    const float rstd = 1.0f / sqrtf(block_sum_256(q, sh) / (float)n + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i >= nu) continue;
+        const int t = i >> sh_ug, c = g * cg + (i & (ug - 1)) * W;
         const size_t row = (size_t)b * a.T + t;
-        float v = (a.y[row * a.ldy + c] - mean) * rstd * a.gamma[c] + a.beta[c];
-        v = mishf(v);
-        if (a.tb) v += a.tb[(size_t)(a.ldtb ? b : 0) * a.ldtb + c];
-        if (a.res) v += a.res[row * a.ldres + c];
-        if (a.add2) v += a.add2[row * a.ldadd2 + c];
-        a.dst[row * a.lddst + c] = v;
-        if (a.dst2) a.dst2[row * a.lddst2 + c] = v;
+        float ga[W], be[W], o[W];
+        ldv(a.gamma + c, ga);
+        ldv(a.beta + c, be);
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = mishf((v[k][e] - mean) * rstd * ga[e] + be[e]);
+        if (a.tb) {
+            float x[W];
+            ldv(a.tb + (size_t)(a.ldtb ? b : 0) * a.ldtb + c, x);
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] += x[e];
+        }
+        if (a.res) {
+            float r[W];
+            const float* rp = a.res + row * a.ldres + c;
+            ldv(rp, r);
+            if (a.res_ksplit > 1) {
+                for (int sp = 1; sp < a.res_ksplit; ++sp) {
+                    float x[W];
+                    ldv(rp + (size_t)sp * a.res_slab, x);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) r[e] += x[e];
+                }
+                float x[W];
+                ldv(a.res_bias + c, x);
+#pragma unroll
+                for (int e = 0; e < W; ++e) r[e] += x[e];
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] += r[e];
+        }
+        if (a.add2) {
+            float x[W];
+            ldv(a.add2 + row * a.ldadd2 + c, x);
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] += x[e];
+        }
+        if constexpr (VEC) {
+            *reinterpret_cast<f32x4*>(a.dst + row * a.lddst + c) = f32x4{o[0], o[1], o[2], o[3]};
+            if (a.dst2) *reinterpret_cast<f32x4*>(a.dst2 + row * a.lddst2 + c) = f32x4{o[0], o[1], o[2], o[3]};
+        } else {
+            a.dst[row * a.lddst + c] = o[0];
+            if (a.dst2) a.dst2[row * a.lddst2 + c] = o[0];
+        }
     }
 }
 
@@ -213,11 +307,17 @@ static inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
 // enough splits to give every CU a workgroup, at least 4 K chunks per split.  The partial-tile buffer is part of the
 // caller's workspace; forward() publishes it here for the launch helpers of this host thread.
 constexpr size_t kSplitKFloats = (size_t)256 * 144 * 128;
+constexpr int kTbSteps = 128;             // loop steps whose time path is evaluated by one launch
 constexpr int kGraphMaxSteps = 1024;       // steps per sample-loop call that the captured-graph path accepts
-static thread_local float* tl_splitk = nullptr;
+static thread_local float* tl_splitk = nullptr;       // partial slabs of the conv feeding the next kernel
+static thread_local float* tl_splitk_res = nullptr;   // partial slabs of a block's 1x1 residual conv (alive until its 2nd GroupNorm)
 
-static void plan_split(GemmParams& g) {
-    if (!tl_splitk) return;
+// A conv whose consumer is the GroupNorm kernel leaves its split-K slabs un-reduced; this says where they are.
+struct SplitInfo { int S = 1; size_t slab = 0; int ldp = 0; const float* base = nullptr; };
+
+static void plan_split(GemmParams& g, float* buf = nullptr, SplitInfo* defer = nullptr) {
+    if (!buf) buf = tl_splitk;
+    if (!buf) return;
     const int tm = (g.M + 143) / 144;
     const int bn = (tm * ((g.N + 127) / 128) >= 256 && g.N % 128 == 0) ? 128 : 64;
     const int tiles = tm * ((g.N + bn - 1) / bn);
@@ -225,30 +325,36 @@ static void plan_split(GemmParams& g) {
     const int S = std::min(256 / tiles, nk / 4);
     const int ldp = (g.N + 3) / 4 * 4;
     if (tiles > 128 || S < 2 || (size_t)S * g.M * ldp > kSplitKFloats) return;
-    g.ksplit = S; g.partial = tl_splitk; g.ld_partial = ldp;
+    g.ksplit = S; g.partial = buf; g.ld_partial = ldp;
+    if (defer) {
+        g.ksplit_defer = 1;
+        defer->S = S; defer->slab = (size_t)g.M * ldp; defer->ldp = ldp; defer->base = buf;
+    }
 }
 
 static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int tin, int tq,
-                     int stride, const int* offs, float* out, int ldo, int orow_mul, int orow_add, hipStream_t s) {
+                     int stride, const int* offs, float* out, int ldo, int orow_mul, int orow_add, hipStream_t s,
+                     SplitInfo* defer = nullptr) {
     GemmParams g{};
     g.A = x; g.lda = ldx; g.W = w.w; g.ldw = w.taps * w.cin_pad; g.C = out; g.ldc = ldo;
     g.M = B * tq; g.N = w.cout; g.K = w.taps * w.cin_pad; g.bias = w.b;
     g.conv_taps = w.taps; g.conv_cin_pad = w.cin_pad; g.conv_tin = tin; g.conv_tq = tq; g.conv_stride = stride;
     for (int j = 0; j < w.taps; ++j) g.conv_off[j] = offs[j];
     g.zero_page = h->zero_page; g.orow_mul_m1 = orow_mul - 1; g.orow_add = orow_add;
-    plan_split(g);
+    plan_split(g, nullptr, defer);
     return launch_gemm(g, EPI_BIAS, s);
 }
 static int conv5(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
-                 hipStream_t s) {
+                 hipStream_t s, SplitInfo* defer = nullptr) {
     static const int offs[5] = {-2, -1, 0, 1, 2};
-    return conv_gemm(h, w, x, ldx, B, T, T, 1, offs, out, ldo, 1, 0, s);
+    return conv_gemm(h, w, x, ldx, B, T, T, 1, offs, out, ldo, 1, 0, s, defer);
 }
-static int conv1(const ConvW& w, const float* x, int ldx, int M, float* out, int ldo, hipStream_t s) {
+static int conv1(const ConvW& w, const float* x, int ldx, int M, float* out, int ldo, hipStream_t s,
+                 SplitInfo* defer = nullptr) {
     GemmParams g{};
     g.A = x; g.lda = ldx; g.W = w.w; g.ldw = w.cin_pad; g.C = out; g.ldc = ldo; g.M = M; g.N = w.cout;
     g.K = w.cin_pad; g.bias = w.b;
-    plan_split(g);
+    plan_split(g, defer ? tl_splitk_res : nullptr, defer);
     return launch_gemm(g, EPI_BIAS, s);
 }
 static int down(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
@@ -263,12 +369,26 @@ static int upsample(const rohm_trajnet* h, const UpW& w, const float* x, int ldx
     if (rc) return rc;
     return conv_gemm(h, w.odd, x, ldx, B, Tq, Tq, 1, off_odd, out, ldo, 2, 1, s);
 }
-static int gn(const BlockW& bw, const float* y, int ldy, int B, int T, const float* tb, int ldtb, const float* res,
-              int ldres, const float* add2, int ldadd2, float* dst, int lddst, float* dst2, int lddst2,
-              hipStream_t s) {
-    GnArgs a{y, ldy, bw.g, bw.be, bw.conv.cout, T, tb, ldtb, res, ldres, add2, ldadd2, dst, lddst, dst2, lddst2};
-    prof::Scope ps("gn_mish", 0.0, 12.0 * B * T * bw.conv.cout, s);
-    hipLaunchKernelGGL(gn_mish_kernel, dim3(B, 8), dim3(256), 0, s, a);
+static int gn(const BlockW& bw, const float* y, int ldy, const SplitInfo& sy, int B, int T, const float* tb, int ldtb,
+              const float* res, int ldres, const SplitInfo& sr, const float* res_bias, const float* add2, int ldadd2,
+              float* dst, int lddst, float* dst2, int lddst2, hipStream_t s) {
+    GnArgs a{};
+    a.y = sy.S > 1 ? sy.base : y; a.ldy = sy.S > 1 ? sy.ldp : ldy; a.ksplit = sy.S; a.slab = sy.slab; a.cbias = bw.conv.b;
+    a.gamma = bw.g; a.beta = bw.be; a.C = bw.conv.cout; a.T = T; a.tb = tb; a.ldtb = ldtb;
+    a.res = sr.S > 1 ? sr.base : res; a.ldres = sr.S > 1 ? sr.ldp : ldres; a.res_ksplit = sr.S; a.res_slab = sr.slab;
+    a.res_bias = res_bias;
+    a.add2 = add2; a.ldadd2 = ldadd2; a.dst = dst; a.lddst = lddst; a.dst2 = dst2; a.lddst2 = lddst2;
+    if ((bw.conv.cout >> 3) * T > 256 * kGnMaxPerThread || (bw.conv.cout & (bw.conv.cout - 1)) != 0) {
+        set_error("trajnet: GroupNorm group of %d x %d values is not supported", bw.conv.cout >> 3, T);
+        return ROHM_ERR_UNSUPPORTED;
+    }
+    auto ok4 = [](const void* p, long ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0); };
+    const bool vec = ok4(a.y, a.ldy) && ok4(a.y, (long)(a.slab % 4)) && ok4(a.res, a.ldres) && ok4(a.res, (long)(a.res_slab % 4)) &&
+                     ok4(a.add2, a.ldadd2) && ok4(a.dst, a.lddst) && ok4(a.dst2, a.lddst2) && ok4(a.tb, a.ldtb) &&
+                     ok4(a.gamma, 0) && ok4(a.beta, 0) && ok4(a.cbias, 0) && ok4(a.res_bias, 0) && (a.C >> 3) % 4 == 0;
+    prof::Scope ps("gn_mish", 0.0, 4.0 * B * T * bw.conv.cout * (2.0 + sy.S), s);
+    if (vec) hipLaunchKernelGGL(gn_mish_kernel<true>, dim3(B, 8), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gn_mish_kernel<false>, dim3(B, 8), dim3(256), 0, s, a);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
@@ -281,17 +401,18 @@ static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int l
                      const Scratch& sc, hipStream_t s) {
     int rc;
     const int co = r.cout;
-    if ((rc = conv5(h, r.b0.conv, x, ldx, B, T, sc.ya, co, s))) return rc;
-    const float* tb = (r.tb_off >= 0) ? tb_all + r.tb_off : nullptr;
-    if ((rc = gn(r.b0, sc.ya, co, B, T, tb, ldtb, nullptr, 0, nullptr, 0, sc.hb, co, nullptr, 0, s))) return rc;
-    if ((rc = conv5(h, r.b1.conv, sc.hb, co, B, T, sc.ya, co, s))) return rc;
+    SplitInfo s0, s1, sr, none;
+    if ((rc = conv5(h, r.b0.conv, x, ldx, B, T, sc.ya, co, s, &s0))) return rc;
     const float* res = x;
     int ldres = ldx;
-    if (r.has_res) {
-        if ((rc = conv1(r.res, x, ldx, B * T, sc.rc, co, s))) return rc;
+    if (r.has_res) {       // before the GroupNorm so that its slabs (own buffer) are the only thing kept alive
+        if ((rc = conv1(r.res, x, ldx, B * T, sc.rc, co, s, &sr))) return rc;
         res = sc.rc; ldres = co;
     }
-    return gn(r.b1, sc.ya, co, B, T, nullptr, 0, res, ldres, add2, ldadd2, dst, lddst, dst2, lddst2, s);
+    const float* tb = (r.tb_off >= 0) ? tb_all + r.tb_off : nullptr;
+    if ((rc = gn(r.b0, sc.ya, co, s0, B, T, tb, ldtb, nullptr, 0, none, nullptr, nullptr, 0, sc.hb, co, nullptr, 0, s))) return rc;
+    if ((rc = conv5(h, r.b1.conv, sc.hb, co, B, T, sc.ya, co, s, &s1))) return rc;
+    return gn(r.b1, sc.ya, co, s1, B, T, nullptr, 0, res, ldres, sr, r.res.b, add2, ldadd2, dst, lddst, dst2, lddst2, s);
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------
@@ -304,9 +425,10 @@ struct TWs {
     float *cz, *ctrl[4], *ctrl_mid;         // control residuals
     float *fin;                             // final conv block output [M, 32]
     float *tb_all;                          // [B or 1][tb_total]
+    float *tb_steps;                        // [kTbSteps][tb_total]: time biases of a run of loop steps (one launch)
     Scratch sc;
     float *x0, *cond_keep;                  // loop: network output [B,T,13]
-    float *splitk;                          // split-K partial tiles (plan_split)
+    float *splitk, *splitk_res;             // split-K partial tiles (plan_split)
     float *step_coef;                       // graph replay: (c1, c2, sigma) per step, timesteps, step counter
     int64_t* step_t;
     int* step_ctr;
@@ -338,12 +460,14 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     w.cz = take(M * kPadC);
     w.fin = take(M * kPadC);
     w.tb_all = take((size_t)B * h->tb_total);
+    w.tb_steps = take((size_t)kTbSteps * h->tb_total);
     w.sc.ya = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
     w.sc.hb = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
     w.sc.rc = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
     w.x0 = take(M * h->ctraj);
     w.cond_keep = take(16);
     w.splitk = take(kSplitKFloats);
+    w.splitk_res = take(kSplitKFloats);
     w.step_coef = take(3 * (size_t)kGraphMaxSteps);
     w.step_t = reinterpret_cast<int64_t*>(take(2 * (size_t)kGraphMaxSteps));
     w.step_ctr = reinterpret_cast<int*>(take(16));
@@ -381,10 +505,11 @@ static int run_cond_encoder(const rohm_trajnet* h, const TWs& w, int B, int T, h
 }
 
 // everything that depends on x_t / t (and control_cond): trajnet.py:211-275
-static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int ldtb, float* out, hipStream_t s) {
+static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int ldtb, float* out, hipStream_t s,
+                        const float* tb_row = nullptr) {
     const int m = h->mid;
     const int ch[4] = {m / 8, m / 4, m / 2, m};
-    const float* tb = w.tb_all;
+    const float* tb = tb_row ? tb_row : w.tb_all;      // tb_row: this step's row of the table built at loop start
     int rc;
     if (h->control) {   // ControlNet.forward, trajnet.py:43-75
         if ((rc = conv1(h->c_zero0, w.ctl, kPadCtl, B * T, w.cz, kPadC, s))) return rc;   // cols 13..63 stay zero
@@ -438,8 +563,10 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
         x = w.d[i]; ldx = ldd;
     }
     // head: Conv1dBlock(32, 32, k5) + Conv1d(32, 13, 1)  (trajnet.py:158-161)
-    if ((rc = conv5(h, h->final_blk.conv, w.d[0], kPadC, B, T, w.sc.ya, 32, s))) return rc;
-    if ((rc = gn(h->final_blk, w.sc.ya, 32, B, T, nullptr, 0, nullptr, 0, nullptr, 0, w.fin, kPadC, nullptr, 0, s))) return rc;
+    SplitInfo sf, none;
+    if ((rc = conv5(h, h->final_blk.conv, w.d[0], kPadC, B, T, w.sc.ya, 32, s, &sf))) return rc;
+    if ((rc = gn(h->final_blk, w.sc.ya, 32, sf, B, T, nullptr, 0, nullptr, 0, none, nullptr, nullptr, 0, w.fin, kPadC, nullptr, 0, s)))
+        return rc;
     return conv1(h->final_conv, w.fin, kPadC, B * T, out, h->ctraj, s);
 }
 
@@ -762,6 +889,7 @@ int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float*
         return ROHM_ERR_WORKSPACE;
     }
     tl_splitk = w.splitk;
+    tl_splitk_res = w.splitk_res;
     const size_t M = (size_t)B * T;
     if ((rc = pad_rows(x_t, w.xin, M, h->ctraj, kPadC, s))) return rc;
     if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;
@@ -789,6 +917,7 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         return ROHM_ERR_WORKSPACE;
     }
     tl_splitk = w.splitk;
+    tl_splitk_res = w.splitk_res;
     const size_t M = (size_t)B * T, n = M * h->ctraj;
     // cond / control_cond do not change over the loop: pad them and run the (time-free) cond encoder once
     if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;
@@ -811,9 +940,19 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
         if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;
-        if ((rc = run_time_path(h, w, nullptr, t_model[i], B, s))) return rc;
+        if (i % kTbSteps == 0) {
+            // the time path depends on t only (trajnet.py:120-125, heads.py:35-38): one launch covers the next run of
+            // steps (37 us per step before)
+            const int run = (n_steps - i < kTbSteps) ? n_steps - i : kTbSteps;
+            ROHM_HIP_CHECK(hipMemcpyAsync(w.step_t, t_model + i, (size_t)run * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            prof::Scope ps("time_path", 0.0, 4.0 * h->tb_total * h->tdim * run, s);
+            hipLaunchKernelGGL(time_path_kernel, dim3(run), dim3(256), 0, s, w.step_t, (int64_t)0, (const int64_t*)nullptr,
+                               (const int*)nullptr, h->tdim, h->t_w1T, h->t_b1, h->t_w3T, h->t_b3, h->tb_wT, h->tb_b,
+                               h->tb_total, w.tb_steps);
+            ROHM_LAUNCH_CHECK();
+        }
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
-        if ((rc = run_denoiser(h, w, B, T, 0, x0, s))) return rc;
+        if ((rc = run_denoiser(h, w, B, T, 0, x0, s, w.tb_steps + (size_t)(i % kTbSteps) * h->tb_total))) return rc;
         if ((rc = launch_ddpm_step(x, x0, noise ? noise + (size_t)i * n : nullptr, nullptr, c1, c2, sigma, 0.f, x, n, s)))
             return rc;
     }
