@@ -51,6 +51,8 @@ def build(force=False, verbose=True):
     import concurrent.futures
     import tempfile
     flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+    if os.environ.get('ROHM_DIAG') == '1':      # diagnostic GEMM variants / knobs for scripts/gemm_*.py (never shipped)
+        flags.append('-DROHM_GEMM_DIAGNOSTICS')
     with tempfile.TemporaryDirectory(prefix='rohm_build_') as tmp:
         objs = [os.path.join(tmp, os.path.basename(f) + '.o') for f in sources()]
 

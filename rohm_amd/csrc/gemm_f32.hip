@@ -649,6 +649,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (nb + q < N) cp[q] = acc[q] + (bias ? bias[nb + q] : 0.f);
 }
 
+// Diagnostic builds only (`ROHM_DIAG=1 python -m rohm_amd.build` defines ROHM_GEMM_DIAGNOSTICS): schedule variants
+// 5 / 6 / 7, forced tile widths and the occupancy / LDS-padding / target-workgroup knobs used by scripts/gemm_*.  The
+// shipped library has none of them: no environment lookups on the launch path, no diagnostic kernels in the binary.
+#ifdef ROHM_GEMM_DIAGNOSTICS
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -657,13 +661,25 @@ static int gemm_variant() {
     }
     return v;
 }
+static int diag_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+#else
+static constexpr int gemm_variant() { return 0; }
+#endif
 
 template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 static int launch_one(const GemmParams& p, hipStream_t s) {
     const int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * ksplit;
-    static int lds_pad = -1;
-    if (lds_pad < 0) { const char* e = getenv("ROHM_GEMM_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+#ifdef ROHM_GEMM_DIAGNOSTICS
+    static const int lds_pad = diag_env_int("ROHM_GEMM_LDS_PAD", 0);
+    static const bool occ2 = getenv("ROHM_GEMM_OCC2") != nullptr;      // allow two workgroups per CU
+#else
+    constexpr int lds_pad = 0;
+    constexpr bool occ2 = false;
+#endif
     // One workgroup per CU on purpose: with two co-resident workgroups the hardware hands BOTH freed slots of
     // a CU to the next tiles, so a 3-tiles-per-CU GEMM degenerates to 4 + 2 (measured 158 us vs 128 us); the
     // schedule already hides LDS / L2 latency without a partner wave.  Requesting more than half of the
@@ -671,7 +687,6 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + lds_pad;
     lds += 2048;                           // landing zone of the dummy DMA pieces
     lds += 4 * BM * 2 * sizeof(float);     // row-stat exchange of the LayerNorm-producing epilogue
-    static const bool occ2 = getenv("ROHM_GEMM_OCC2") != nullptr;      // diagnostics: allow two workgroups per CU
     // the split-bf16 variants WANT two workgroups per CU: one wave's plane splitting (VALU) runs under the other's MFMAs
     if (lds < 84 * 1024 && !occ2 && VAR != 8 && VAR != 9) lds = 84 * 1024;
     static bool attr_set[64] = {};
@@ -729,12 +744,12 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
 // Workgroups a launch should at least produce before a wider tile is preferred: one per CU of the MI355X, or
 // fewer when the caller runs several independent launches side by side (ROHM_GEMM_TARGET_WGS).
 static int target_wgs() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ROHM_GEMM_TARGET_WGS");
-        v = (e && atoi(e) > 0) ? atoi(e) : 256;
-    }
+#ifdef ROHM_GEMM_DIAGNOSTICS
+    static const int v = diag_env_int("ROHM_GEMM_TARGET_WGS", 256) > 0 ? diag_env_int("ROHM_GEMM_TARGET_WGS", 256) : 256;
     return v;
+#else
+    return 256;
+#endif
 }
 
 template <int EPI>
@@ -742,8 +757,9 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
     const int tm = (p.M + BM - 1) / BM;
     const int tiles128 = tm * ((p.N + 127) / 128);
     const int want = target_wgs();
+#ifdef ROHM_GEMM_DIAGNOSTICS
     const int var = gemm_variant();
-    const int force_bn = var / 10;            // diagnostics: 6x -> BN 64, 12x -> BN 128
+    const int force_bn = var / 10;            // 6x -> BN 64, 12x -> BN 128
     if constexpr (EPI == EPI_BIAS) {
         switch (var % 10) {                   // schedule variants exist for the plain epilogue only
             case 5: return force_bn == 6 ? launch_t<64, EPI, 5>(p, s) : launch_t<128, EPI, 5>(p, s);
@@ -759,6 +775,7 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
     }
     if (force_bn == 6) return launch_t<64, EPI>(p, s);
     if (force_bn == 12) return launch_t<128, EPI>(p, s);
+#endif
     // Opt-in precision ladder (ROHM_GEMM_PRECISION=bf16x6 | bf16x3): split-bf16 products for the plain GEMMs (PoseNet);
     // convolutions, split-K and the LayerNorm-folding epilogues stay on the exact fp32 MFMA path.
     static const int prec = [] {

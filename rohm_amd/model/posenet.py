@@ -84,13 +84,16 @@ class _NativePoseNet:
         self._ws = {}
 
     def workspace(self, B, T):
-        key = (B, T)
+        """Caller-owned workspace of the C ABI, one per (shape, HIP stream): forwards issued on different streams get
+        distinct workspaces (the library's calls are re-entrant across streams only under that condition)."""
+        key = (B, T, torch.cuda.current_stream(self.device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = lib().rohm_posenet_workspace_bytes(self.handle, B, T)
             if nbytes == 0:
                 raise _lib.RohmHipError('rohm_posenet_workspace_bytes returned 0 (bad shape)')
-            self._ws.clear()
+            for k in [k for k in self._ws if k[2] == key[2]]:      # one live shape per stream
+                del self._ws[k]
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
         return ws

@@ -105,14 +105,17 @@ class _NativeTrajNet:
         self._ws = {}
 
     def workspace(self, B, T):
-        ws = self._ws.get((B, T))
+        """One workspace per (shape, HIP stream), see `_NativePoseNet.workspace`."""
+        key = (B, T, torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._ws.get(key)
         if ws is None:
             n = lib().rohm_trajnet_workspace_bytes(self.handle, B, T)
             if n == 0:
                 raise _lib.RohmHipError(f'TrajNet: unsupported shape B={B}, T={T} (T must be a multiple of 16)')
-            self._ws.clear()
+            for k in [k for k in self._ws if k[2] == key[2]]:
+                del self._ws[k]
             ws = torch.empty(n, dtype=torch.uint8, device=self.device)
-            self._ws[(B, T)] = ws
+            self._ws[key] = ws
         return ws
 
     def __del__(self):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Per-workgroup phase timeline of the GEMM kernel (diagnostic build path ROHM_GEMM_VARIANT=7 / 127):
+"""(Diagnostic GEMM variants: build the library with `ROHM_DIAG=1 python -m rohm_amd.build --force` first.)
+Per-workgroup phase timeline of the GEMM kernel (diagnostic build path ROHM_GEMM_VARIANT=7 / 127):
 every workgroup stamps the 100 MHz wall clock at entry, after its prologue landed, after the main loop, after the
 epilogue stores were issued and after they were acknowledged.  Prints where one launch's time goes.
 usage (GPU box): ROHM_GEMM_VARIANT=7 python scripts/gemm_timeline.py"""

@@ -221,3 +221,22 @@ def test_forward_other_widths_and_clip_lengths(latent, heads, ff, T, B):
     fn = lambda xx, i: nets.posenet_forward(sd, xx, c, torch.full((B,), i, dtype=torch.int64), n_head=heads)
     ref = odiff.p_sample_loop(fn, x_T, noises, odiff.tables(odiff.cosine_betas(6)), list(range(6))[::-1])
     assert max_abs(out.cpu(), ref) < 1e-3
+
+
+def test_two_streams_get_distinct_workspaces_and_agree():
+    """The C ABI is re-entrant across streams given distinct workspaces; the binding hands out one per stream."""
+    net, sd = make_posenet(77)
+    x, c = seeded(1, 2, 294, 1, 143).to(DEV), seeded(2, 2, 294, 1, 143).to(DEV)
+    t = torch.tensor([5, 700], device=DEV)
+    ref = net({'x_t': x, 'cond': c}, t)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for st in (s1, s2):
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                outs.append(net({'x_t': x, 'cond': c}, t))
+    torch.cuda.synchronize()
+    assert len({k[2] for k in net.native()._ws}) >= 2
+    for o in outs:
+        assert torch.equal(o, ref)
