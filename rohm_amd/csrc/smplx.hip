@@ -22,37 +22,6 @@ namespace rohm {
 
 
 // ---------------------------------------------------------------------------------------- skating guidance
-// pass 1: foot joints of both recoveries for every frame -> feet[B, T, 2, 4, 3]
-__global__ __launch_bounds__(64) void skating_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
-                                                         const float* __restrict__ stdv, const float* __restrict__ Jt,
-                                                         const float* __restrict__ Js, const int* __restrict__ parents,
-                                                         float* __restrict__ feet, int B, int T) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * T) return;
-    const int b = idx / T, t = idx % T;
-    const size_t base = (size_t)b * C_TOTAL * T + t;
-    FrameIn in;
-    load_frame(x0, mean, stdv, base, T, in);
-    FkCtx f;
-    smplx_fk(in, Jt, Js, parents, f);
-    const float ang = ld(x0, mean, stdv, base, T, CH_ROOT_ANG);
-    const float pos[3] = {ld(x0, mean, stdv, base, T, CH_ROOT_POS), ld(x0, mean, stdv, base, T, CH_ROOT_POS + 1),
-                          ld(x0, mean, stdv, base, T, CH_ROOT_H)};
-    float* o = feet + (size_t)idx * 24;
-    for (int k = 0; k < 4; ++k) {
-        const int j = kFoot[k];
-        const float v[3] = {ld(x0, mean, stdv, base, T, CH_LOCAL + 3 * j), ld(x0, mean, stdv, base, T, CH_LOCAL + 3 * j + 1),
-                            ld(x0, mean, stdv, base, T, CH_LOCAL + 3 * j + 2)};
-        float a[3];
-        abs_joint(ang, pos, v, a);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            o[k * 3 + c] = a[c];
-            o[12 + k * 3 + c] = f.P[j][c] + in.trans[c];
-        }
-    }
-}
-
 // pass 2: mask counts of both recoveries (posenet.py:224-246).  counts[0] = abs-traj, counts[1] = smplx.
 __global__ __launch_bounds__(256) void skating_count_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
                                                             const float* __restrict__ stdv,
@@ -110,65 +79,6 @@ __device__ __forceinline__ void skating_djoint(const float* __restrict__ x0, con
     }
 }
 
-// Writes one gradient column (all 294 channels of frame (b, t)) from the SMPL-X reverse pass results.
-__device__ __forceinline__ void write_column(float* __restrict__ grad, const float* __restrict__ stdv, size_t base, int T,
-                                             const float* dlocal /*[NJ*3] or null*/, const float (*d6)[6],
-                                             const float* dbeta) {
-    for (int c = 0; c < C_TOTAL; ++c) {
-        float v = 0.f;
-        if (c >= CH_LOCAL && c < CH_LOCAL + NJ * 3) v = dlocal ? dlocal[c - CH_LOCAL] : 0.f;
-        else if (c >= CH_POSE6D && c < CH_POSE6D + 126) v = d6[1 + (c - CH_POSE6D) / 6][(c - CH_POSE6D) % 6];
-        else if (c >= CH_BETAS && c < CH_BETAS + NBETA) v = dbeta[c - CH_BETAS];
-        // channels [0, 22) and [290, 294) are zeroed by the reference (posenet.py:251-252); local_vel never
-        // enters either recovery.
-        grad[base + (size_t)c * T] = v * stdv[c];
-    }
-}
-
-// pass 3: gradient column of every frame
-__global__ __launch_bounds__(64) void skating_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
-                                                         const float* __restrict__ stdv, const float* __restrict__ Jt,
-                                                         const float* __restrict__ Js, const int* __restrict__ parents,
-                                                         const float* __restrict__ feet, const float* __restrict__ counts,
-                                                         float* __restrict__ grad, int B, int T) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * T) return;
-    const int b = idx / T, t = idx % T;
-    const size_t base = (size_t)b * C_TOTAL * T + t;
-    const float inv0 = counts[0] > 0.f ? 1.f / counts[0] : 0.f;
-    const float inv1 = counts[1] > 0.f ? 1.f / counts[1] : 0.f;
-    // abs-trajectory recovery: only local_positions of the foot joints receive gradient
-    float dlocal[NJ * 3];
-    for (int i = 0; i < NJ * 3; ++i) dlocal[i] = 0.f;
-    const float ang = ld(x0, mean, stdv, base, T, CH_ROOT_ANG);
-    for (int k = 0; k < 4; ++k) {
-        float g[3], gl[3];
-        skating_djoint(x0, mean, stdv, feet, b, t, T, 0, k, inv0, g);
-        abs_joint_T(ang, g, gl);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dlocal[kFoot[k] * 3 + c] = gl[c];
-    }
-    // SMPL-X recovery
-    FrameIn in;
-    load_frame(x0, mean, stdv, base, T, in);
-    FkCtx f;
-    smplx_fk(in, Jt, Js, parents, f);
-    float gP[NJ][3];
-    for (int j = 0; j < NJ; ++j) gP[j][0] = gP[j][1] = gP[j][2] = 0.f;
-    for (int k = 0; k < 4; ++k) skating_djoint(x0, mean, stdv, feet, b, t, T, 1, k, inv1, gP[kFoot[k]]);
-    float dR[NJ][9], dJr[NJ][3], d6[NJ][6], dbeta[NBETA];
-    fk_backward(f, parents, gP, dR, dJr);
-    for (int j = 1; j < NJ; ++j) rot6d_bwd(in.x6[j], dR[j], d6[j]);
-    for (int k = 0; k < NBETA; ++k) {
-        float s = 0.f;
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) s = fmaf(dJr[j][c], Js[(j * 3 + c) * NBETA + k], s);
-        dbeta[k] = s;
-    }
-    write_column(grad, stdv, base, T, dlocal, d6, dbeta);
-}
-
 // ---------------------------------------------------------------------------------------- 2-D re-projection
 __device__ __forceinline__ void inv3(const float* a, float* o) {
     const float c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
@@ -179,76 +89,268 @@ __device__ __forceinline__ void inv3(const float* a, float* o) {
     o[6] = c02 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
 }
 
-// cam2[b] = {Rc (3x3 of inv(transf_matrix)), Tc (3), Ri = inv(cam_R) (9)}: 21 floats per clip.
-// transf_matrix is affine ([R t; 0 1]), so inv = [R^-1, -R^-1 t] (torch.linalg.inv, posenet.py:286).
-__global__ void proj_prep_kernel(const float* __restrict__ transf, const float* __restrict__ camR, float* __restrict__ cam2,
-                                 int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float* m = transf + (size_t)b * 16;
-    const float R[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
-    const float tr[3] = {m[3], m[7], m[11]};
-    float* o = cam2 + (size_t)b * 21;
-    inv3(R, o);
-    float tt[3];
-    mat_vec(o, tr, tt);
-    o[9] = -tt[0]; o[10] = -tt[1]; o[11] = -tt[2];
-    inv3(camR, o + 12);
-}
+// ---------------------------------------------------------------------------------------- lanes over joints
+// Round 1 gave every frame ONE thread: a 22-joint FK context (R, G, rest joints, posed joints = 528 floats) plus the
+// reverse-pass arrays per thread live in scratch memory, and B*T = 4576 threads are 72 waves on a 256-CU chip: 150-180
+// us per kernel at B = 32, two orders of magnitude off the 5 MB they move.  Here a frame is 32 lanes (lane = joint, 22
+// used), a workgroup is a tile of 8 consecutive frames of one clip:
+//   * the 294 channels of the tile are staged through LDS with coalesced loads (de-normalised on the way in) and the
+//     gradient tile goes back the same way (every channel written, zeros where the reference zeroes);
+//   * FK runs level by level down the kinematic tree, a lane fetching its parent's world rotation / position with
+//     wave shuffles (a frame never leaves its half-wave: no barriers);
+//   * the reverse pass runs the levels upwards, a parent gathering the 15 numbers (dP, -dJrest, dG) each of its <= 3
+//     children contributes; 6-D Gram-Schmidt forward / backward are lane-local; d(beta) is a 5-step butterfly.
+// Everything stays in registers; the grid is B * ceil(T / 8) workgroups of 256 threads.  The tree (parent, depth,
+// children of each joint) travels in the kernel arguments: no pointer chasing through global memory.
+constexpr int GF = 8;                  // frames per workgroup (B = 32: 576 workgroups of 256 threads, 2-3 per CU)
+constexpr int GMAXKID = 3;             // children per joint (SMPL-X body: pelvis and spine3 have three)
 
-__global__ __launch_bounds__(64) void proj2d_kernel(const float* __restrict__ x0, const float* __restrict__ mean,
-                                                    const float* __restrict__ stdv, const float* __restrict__ Jt,
-                                                    const float* __restrict__ Js, const int* __restrict__ parents,
-                                                    const float* __restrict__ cam2, const float* __restrict__ camT,
-                                                    const float* __restrict__ focal, const float* __restrict__ center,
-                                                    const float* __restrict__ kp2d, int kp_frames,
-                                                    float* __restrict__ grad, int B, int T) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * T) return;
-    const int b = idx / T, t = idx % T;
-    const size_t base = (size_t)b * C_TOTAL * T + t;
-    FrameIn in;
-    load_frame(x0, mean, stdv, base, T, in);
-    FkCtx f;
-    smplx_fk(in, Jt, Js, parents, f);
-    const float* Rc = cam2 + (size_t)b * 21;
-    const float* Tc = Rc + 9;
-    const float* Ri = Rc + 12;
-    const float fx = focal[b * 2], fy = focal[b * 2 + 1], cx = center[b * 2], cy = center[b * 2 + 1];
-    const float inv_n = 1.f / ((float)B * (float)T * 20.f);      // .mean() over B*T*10*2 (posenet.py:308-309)
-    float gP[NJ][3];
-    for (int j = 0; j < NJ; ++j) gP[j][0] = gP[j][1] = gP[j][2] = 0.f;
-    for (int k = 0; k < 10; ++k) {
-        const int j = kProj[k];
-        const float p[3] = {f.P[j][0] + in.trans[0], f.P[j][1] + in.trans[1], f.P[j][2] + in.trans[2]};
-        float sc[3], cm[3];
-        mat_vec(Rc, p, sc);
-        const float d[3] = {sc[0] + Tc[0] - camT[0], sc[1] + Tc[1] - camT[1], sc[2] + Tc[2] - camT[2]};
-        mat_vec(Ri, d, cm);
-        const float iz = 1.f / cm[2];
-        const float u = fx * (cm[0] * iz) + cx, v = fy * (cm[1] * iz) + cy;
-        const float* kp = kp2d + (((size_t)b * kp_frames + t) * NJ + j) * 3;
-        const float conf = kp[2];
-        const float du = u - kp[0], dv = v - kp[1];
-        // d(-mean |.| conf): -sign(diff) conf / N
-        const float gu = -((du > 0.f) - (du < 0.f)) * conf * inv_n;
-        const float gv = -((dv > 0.f) - (dv < 0.f)) * conf * inv_n;
-        const float gc[3] = {gu * fx * iz, gv * fy * iz, -(gu * fx * cm[0] + gv * fy * cm[1]) * iz * iz};
-        float gs[3];
-        matT_vec(Ri, gc, gs);
-        matT_vec(Rc, gs, gP[j]);
+struct GuideArgs {
+    const float *x0, *mean, *stdv, *Jt, *Js;
+    signed char parent[NJ], depth[NJ], kid[NJ][GMAXKID];     // kinematic tree of the 22 body joints (-1 = none)
+    int max_depth;
+    int B, T;
+    float* feet;                 // [B, T, 2, 4, 3]      MODE 0 out, MODE 1 in
+    const float* counts;         // [2]                  MODE 1
+    float* grad;                 // [B, 294, 1, T]       MODE 1 / 2 out
+    // MODE 2 (guide_2d_projection_with_smpl, model/posenet.py:260-317)
+    const float *transf, *camR, *camT, *focal, *center, *kp2d;
+    int kp_frames;
+};
+
+__device__ __forceinline__ float shfl_in(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// MODE 0: foot joints of both recoveries (skating, pass 1);  1: skating gradient;  2: 2-D re-projection gradient
+template <int MODE>
+__global__ __launch_bounds__(GF * 32) void guide_lanes_kernel(GuideArgs a) {
+    __shared__ float xs[C_TOTAL * GF];          // input tile, then gradient tile
+    __shared__ float cam[21];                   // MODE 2: Rc (9), Tc (3), Ri (9)
+    const int tid = threadIdx.x;
+    const int j = tid & 31, fl = tid >> 5;      // joint lane, frame within the tile
+    const int half = (tid & 63) & 32;           // first lane of this frame's half-wave
+    const int ntile = (a.T + GF - 1) / GF;
+    const int b = blockIdx.x / ntile, t0 = (blockIdx.x % ntile) * GF;
+    const int t = t0 + fl, T = a.T;
+    const bool active = (t < T) && (j < NJ);
+    const int jj = (j < NJ) ? j : 0;            // idle lanes shadow joint 0 (never written anywhere)
+
+    for (int idx = tid; idx < C_TOTAL * GF; idx += GF * 32) {
+        const int c = idx / GF, f = idx % GF;
+        xs[idx] = (t0 + f < T) ? a.x0[((size_t)b * C_TOTAL + c) * T + t0 + f] * a.stdv[c] + a.mean[c] : 0.f;
     }
-    float dR[NJ][9], dJr[NJ][3], d6[NJ][6], dbeta[NBETA];
-    fk_backward(f, parents, gP, dR, dJr);
-    for (int j = 1; j < NJ; ++j) rot6d_bwd(in.x6[j], dR[j], d6[j]);
-    for (int k = 0; k < NBETA; ++k) {
-        float s = 0.f;
-        for (int j = 0; j < NJ; ++j)
+    if (MODE == 2 && tid == 0) {
+        // cano -> scene: inv of the affine transf_matrix = [R^-1, -R^-1 t] (torch.linalg.inv, posenet.py:286); inv(cam_R)
+        const float* m = a.transf + (size_t)b * 16;
+        const float R[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+        const float tr[3] = {m[3], m[7], m[11]};
+        float o[9], tt[3], ri[9];
+        inv3(R, o);
+        mat_vec(o, tr, tt);
+        inv3(a.camR, ri);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) s = fmaf(dJr[j][c], Js[(j * 3 + c) * NBETA + k], s);
-        dbeta[k] = s;
+        for (int i = 0; i < 9; ++i) { cam[i] = o[i]; cam[12 + i] = ri[i]; }
+        cam[9] = -tt[0]; cam[10] = -tt[1]; cam[11] = -tt[2];
     }
-    write_column(grad, stdv, base, T, nullptr, d6, dbeta);
+    __syncthreads();
+    auto X = [&](int c) { return xs[c * GF + fl]; };
+
+    // ---- lane-local: rotation from the 6-D vector, rest joint, place in the tree --------------------------------
+    float x6[6], R[9], Jr[3], trans[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x6[k] = X(jj == 0 ? CH_ROT6D + k : CH_POSE6D + (jj - 1) * 6 + k);
+    rot6d_fwd(x6, R);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = a.Jt[jj * 3 + c];
+#pragma unroll
+        for (int k = 0; k < NBETA; ++k) v = fmaf(a.Js[(jj * 3 + c) * NBETA + k], X(CH_BETAS + k), v);
+        Jr[c] = v;
+        trans[c] = X(CH_TRANS + c);
+    }
+    const int par = (jj > 0) ? a.parent[jj] : 0;
+    const int depth = a.depth[jj];
+    int kid[GMAXKID];
+#pragma unroll
+    for (int s2 = 0; s2 < GMAXKID; ++s2) kid[s2] = (j < NJ) ? a.kid[jj][s2] : -1;
+
+    // ---- forward kinematics, level by level ------------------------------------------------------------------------
+    float off[3], G[9], P[3], Gp[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) off[c] = Jr[c] - shfl_in(Jr[c], half + par);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { G[i] = R[i]; Gp[i] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) P[c] = Jr[c];
+    for (int d = 1; d <= a.max_depth; ++d) {
+        float gi[9], pi[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gi[i] = shfl_in(G[i], half + par);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pi[c] = shfl_in(P[c], half + par);
+        if (depth == d) {
+            float w[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Gp[i] = gi[i];
+            mat_mul(Gp, R, G);
+            mat_vec(Gp, off, w);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) P[c] = pi[c] + w[c];
+        }
+    }
+
+    if constexpr (MODE == 0) {
+        // feet[b, t, path, k, :]: path 0 = abs-trajectory recovery, 1 = SMPL-X recovery (posenet.py:213-216)
+        if (t < T) {
+            float* o = a.feet + ((size_t)b * T + t) * 24;
+            if (j < 4) {
+                const int fj = kFoot[j];
+                const float pos[3] = {X(CH_ROOT_POS), X(CH_ROOT_POS + 1), X(CH_ROOT_H)};
+                const float v[3] = {X(CH_LOCAL + 3 * fj), X(CH_LOCAL + 3 * fj + 1), X(CH_LOCAL + 3 * fj + 2)};
+                float r[3];
+                abs_joint(X(CH_ROOT_ANG), pos, v, r);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[j * 3 + c] = r[c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (j == kFoot[k]) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o[12 + k * 3 + c] = P[c] + trans[c];
+                }
+        }
+        return;
+    } else {
+        // ---- dL/dP of this lane's joint ----------------------------------------------------------------------------
+        float gP[3] = {0.f, 0.f, 0.f}, dl[3] = {0.f, 0.f, 0.f};
+        int foot_k = -1;
+        if constexpr (MODE == 1) {
+            const float inv0 = a.counts[0] > 0.f ? 1.f / a.counts[0] : 0.f;
+            const float inv1 = a.counts[1] > 0.f ? 1.f / a.counts[1] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (j == kFoot[k]) foot_k = k;
+            if (active && foot_k >= 0) {
+                float g[3];
+                skating_djoint(a.x0, a.mean, a.stdv, a.feet, b, t, T, 0, foot_k, inv0, g);
+                abs_joint_T(X(CH_ROOT_ANG), g, dl);       // abs-trajectory recovery: only local_positions get gradient
+                skating_djoint(a.x0, a.mean, a.stdv, a.feet, b, t, T, 1, foot_k, inv1, gP);
+            }
+        } else {
+            bool proj = false;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) proj = proj || (j == kProj[k]);
+            if (active && proj) {
+                const float* Rc = cam;
+                const float* Tc = cam + 9;
+                const float* Ri = cam + 12;
+                const float fx = a.focal[b * 2], fy = a.focal[b * 2 + 1], cx = a.center[b * 2], cy = a.center[b * 2 + 1];
+                const float inv_n = 1.f / ((float)a.B * (float)T * 20.f);      // .mean() over B*T*10*2 (posenet.py:308-309)
+                const float p[3] = {P[0] + trans[0], P[1] + trans[1], P[2] + trans[2]};
+                float sc[3], cm[3];
+                mat_vec(Rc, p, sc);
+                const float dd[3] = {sc[0] + Tc[0] - a.camT[0], sc[1] + Tc[1] - a.camT[1], sc[2] + Tc[2] - a.camT[2]};
+                mat_vec(Ri, dd, cm);
+                const float iz = 1.f / cm[2];
+                const float u = fx * (cm[0] * iz) + cx, v = fy * (cm[1] * iz) + cy;
+                const float* kp = a.kp2d + (((size_t)b * a.kp_frames + t) * NJ + j) * 3;
+                const float conf = kp[2];
+                const float du = u - kp[0], dv = v - kp[1];
+                // d(-mean |.| conf): -sign(diff) conf / N
+                const float gu = -((du > 0.f) - (du < 0.f)) * conf * inv_n;
+                const float gv = -((dv > 0.f) - (dv < 0.f)) * conf * inv_n;
+                const float gc[3] = {gu * fx * iz, gv * fy * iz, -(gu * fx * cm[0] + gv * fy * cm[1]) * iz * iz};
+                float gs[3];
+                matT_vec(Ri, gc, gs);
+                matT_vec(Rc, gs, gP);
+            }
+        }
+
+        // ---- reverse pass of the kinematic chain, levels upwards (fk_backward of smplx_fk.h, one joint per lane) -----
+        float dG[9], dR[9], dJr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { dG[i] = 0.f; dR[i] = 0.f; }
+        for (int d = a.max_depth; d >= 1; --d) {
+            float cb[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) cb[i] = 0.f;
+            if (active && depth == d) {
+                // P[j] = P[p] + G[p] off,  G[j] = G[p] R[j]
+                float doff[3];
+                matT_vec(Gp, gP, doff);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { dJr[c] += doff[c]; cb[c] = gP[c]; cb[3 + c] = -doff[c]; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float sg = 0.f, sr = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            sg += dG[r * 3 + k] * R[c * 3 + k];        // dG[j] R[j]^T
+                            sr += Gp[k * 3 + r] * dG[k * 3 + c];       // G[p]^T dG[j]
+                        }
+                        cb[6 + r * 3 + c] = gP[r] * off[c] + sg;
+                        dR[r * 3 + c] = sr;
+                    }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < GMAXKID; ++s2) {
+                const bool take = active && kid[s2] >= 0 && depth + 1 == d;
+                const int src = half + (kid[s2] >= 0 ? kid[s2] : jj);
+#pragma unroll
+                for (int i = 0; i < 15; ++i) {
+                    const float v = shfl_in(cb[i], src);
+                    if (take) {
+                        if (i < 3) gP[i] += v;
+                        else if (i < 6) dJr[i - 3] += v;
+                        else dG[i - 6] += v;
+                    }
+                }
+            }
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dJr[c] += gP[c];
+        }
+        float d6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (active && j >= 1) rot6d_bwd(x6, dR, d6);
+        float dbeta[NBETA];
+#pragma unroll
+        for (int k = 0; k < NBETA; ++k) {
+            float v = 0.f;
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v = fmaf(dJr[c], a.Js[(jj * 3 + c) * NBETA + k], v);
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);      // stays inside the frame's 32 lanes
+            dbeta[k] = v;
+        }
+
+        // ---- gradient tile: every channel written (zeros where the reference zeroes: [0, 22), [290, 294); local_vel
+        // never enters either recovery), scaled by d(denormalised)/d(normalised) = Std --------------------------------
+        __syncthreads();
+        for (int idx = tid; idx < C_TOTAL * GF; idx += GF * 32) xs[idx] = 0.f;
+        __syncthreads();
+        if (active) {
+            if (j >= 1) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) xs[(CH_POSE6D + (j - 1) * 6 + k) * GF + fl] = d6[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NBETA; ++k) xs[(CH_BETAS + k) * GF + fl] = dbeta[k];
+            }
+            if (MODE == 1 && foot_k >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xs[(CH_LOCAL + 3 * j + c) * GF + fl] = dl[c];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < C_TOTAL * GF; idx += GF * 32) {
+            const int c = idx / GF, f = idx % GF;
+            if (t0 + f < T) a.grad[((size_t)b * C_TOTAL + c) * T + t0 + f] = xs[idx] * a.stdv[c];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------- body-model forward
@@ -396,6 +498,24 @@ __global__ __launch_bounds__(256) void fold_regressor_kernel(const float* __rest
     if (threadIdx.x == 0) out[row] = (float)sh[0];
 }
 
+static void fill_tree(const rohm_smplx* h, GuideArgs& ga) {
+    int n[NJ] = {0};
+    for (int j = 0; j < NJ; ++j)
+        for (int s2 = 0; s2 < GMAXKID; ++s2) ga.kid[j][s2] = -1;
+    ga.parent[0] = -1; ga.depth[0] = 0;
+    for (int j = 1; j < NJ; ++j) {
+        ga.parent[j] = (signed char)h->parents[j];
+        int d = 0;
+        for (int q = j; q > 0; q = h->parents[q]) ++d;
+        ga.depth[j] = (signed char)d;
+    }
+    for (int j = NJ - 1; j >= 1; --j) {          // descending: the order the serial reverse pass visited the children
+        const int p = h->parents[j];
+        ga.kid[p][n[p]++] = (signed char)j;
+    }
+    ga.max_depth = h->max_depth22;
+}
+
 }  // namespace rohm
 
 using namespace rohm;
@@ -439,6 +559,19 @@ int rohm_smplx_create(rohm_smplx_t** out, const float* v_template, const float* 
             set_error("smplx_create: parents[%d] = %d is not an earlier joint", j, h->parents[j]);
             return fail("kinematic tree", hipSuccess);
         }
+    {   // the guidance kernels walk the 22-joint tree level by level, at most GMAXKID children per joint
+        int nkid[NJ] = {0};
+        h->max_depth22 = 0;
+        for (int j = 1; j < NJ; ++j) {
+            int d = 0;
+            for (int q = j; q > 0; q = h->parents[q]) ++d;
+            if (d > h->max_depth22) h->max_depth22 = d;
+            if (++nkid[h->parents[j]] > GMAXKID) {
+                set_error("smplx_create: joint %d has more than %d children among the first %d joints", h->parents[j], GMAXKID, NJ);
+                return fail("kinematic tree", hipSuccess);
+            }
+        }
+    }
     hipLaunchKernelGGL(fold_regressor_kernel, dim3(J * 3), dim3(256), 0, 0, d_jr, d_vt, 1, 0, V, h->d_Jt, 3);
     hipLaunchKernelGGL(fold_regressor_kernel, dim3(J * 3 * NBETA), dim3(256), 0, 0, d_jr, d_sd, n_shape_total, 0, V,
                        h->d_Js, 3 * NBETA);
@@ -501,9 +634,10 @@ int rohm_guidance_skating_prepare(const rohm_smplx_t* h, const float* x0, const 
     float* feet = (float*)ws;
     prof::Scope ps("guidance_skating_fwd", 0.0, 4.0 * B * T * (C_TOTAL + 24), s);
     ROHM_HIP_CHECK(hipMemsetAsync(counts2, 0, 2 * sizeof(float), s));
-    const int nf = B * T;
-    hipLaunchKernelGGL(skating_fwd_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
-                       h->d_parents, feet, B, T);
+    GuideArgs ga{};
+    ga.x0 = x0; ga.mean = mean294; ga.stdv = std294; ga.Jt = h->d_Jt; ga.Js = h->d_Js;
+    fill_tree(h, ga); ga.B = B; ga.T = T; ga.feet = feet;
+    hipLaunchKernelGGL(guide_lanes_kernel<0>, dim3(B * ((T + GF - 1) / GF)), dim3(GF * 32), 0, s, ga);
     const int np = B * (T - 1) * 4;
     hipLaunchKernelGGL(skating_count_kernel, dim3((np + 255) / 256), dim3(256), 0, s, x0, mean294, std294, feet,
                        counts2, B, T);
@@ -519,9 +653,10 @@ int rohm_guidance_skating_apply(const rohm_smplx_t* h, const float* x0, const fl
     ROHM_ARG_CHECK(ws_bytes >= rohm_guidance_workspace_bytes(B, T), "guidance_skating: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     prof::Scope ps("guidance_skating_bwd", 0.0, 4.0 * B * T * (2 * C_TOTAL + 24), s);
-    const int nf = B * T;
-    hipLaunchKernelGGL(skating_bwd_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
-                       h->d_parents, (const float*)ws, counts2, grad_out, B, T);
+    GuideArgs ga{};
+    ga.x0 = x0; ga.mean = mean294; ga.stdv = std294; ga.Jt = h->d_Jt; ga.Js = h->d_Js;
+    fill_tree(h, ga); ga.B = B; ga.T = T; ga.feet = (float*)ws; ga.counts = counts2; ga.grad = grad_out;
+    hipLaunchKernelGGL(guide_lanes_kernel<1>, dim3(B * ((T + GF - 1) / GF)), dim3(GF * 32), 0, s, ga);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
@@ -544,12 +679,13 @@ int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const floa
     ROHM_ARG_CHECK(B > 0 && T > 0 && kp_frames >= T, "guidance_proj2d: keypoints must cover T frames");
     ROHM_ARG_CHECK(ws_bytes >= rohm_guidance_workspace_bytes(B, T), "guidance_proj2d: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    float* cam2 = (float*)ws + (size_t)B * T * 24;
     prof::Scope ps("guidance_proj2d", 0.0, 8.0 * B * T * C_TOTAL, s);
-    hipLaunchKernelGGL(proj_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, transf_matrix, cam_R, cam2, B);
-    const int nf = B * T;
-    hipLaunchKernelGGL(proj2d_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, x0, mean294, std294, h->d_Jt, h->d_Js,
-                       h->d_parents, cam2, cam_t, focal, center, kp2d, kp_frames, grad_out, B, T);
+    GuideArgs ga{};
+    ga.x0 = x0; ga.mean = mean294; ga.stdv = std294; ga.Jt = h->d_Jt; ga.Js = h->d_Js;
+    fill_tree(h, ga); ga.B = B; ga.T = T; ga.grad = grad_out;
+    ga.transf = transf_matrix; ga.camR = cam_R; ga.camT = cam_t; ga.focal = focal; ga.center = center; ga.kp2d = kp2d;
+    ga.kp_frames = kp_frames;
+    hipLaunchKernelGGL(guide_lanes_kernel<2>, dim3(B * ((T + GF - 1) / GF)), dim3(GF * 32), 0, s, ga);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }

@@ -20,6 +20,7 @@ struct rohm_smplx {
     float* d_Js;       // [J, 3, 10]    J_regressor . shapedirs[:, :, :10]
     int* d_parents;    // [J]
     int parents[64];
+    int max_depth22;   // depth of the 22-joint body tree (guidance kernels run it level by level)
     // ---- full linear blend skinning (lbs.hip; optional, set by rohm_smplx_set_skinning) ----
     int P, KP, NP;     // pose-blendshape rows (J-1)*9, padded to a multiple of 32; V*3 padded to a multiple of 384
     float* d_vt;       // [V, 3]          v_template
