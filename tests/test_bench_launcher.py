@@ -54,3 +54,20 @@ def test_more_ranks_than_gpus_is_refused():
         return
     r = _run(['--gpus', '2'])
     assert r.returncode != 0 and 'GPU(s) visible' in r.stderr
+
+
+def test_driver_style_launch_under_torch_distributed_run():
+    """The way the driver starts N > 1: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher, bench.py must not spawn again)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['ROHM_BENCH_SELFTEST'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), BENCH, '--gpus', '2', '--backend', 'gloo',
+                        '--steps', '1', '--warmup', '0', '--batch', '2'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json_line(r.stdout)
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == [0, 1] and rec['gathered_clips'] == 4
