@@ -98,6 +98,9 @@ struct GemmParams {
     int conv_off[5];
     const float* zero_page;      // >= 128 B of zeros (source of padded taps)
     int orow_mul_m1, orow_add;
+    // columns >= ncol_split land ncol_jump floats further (0 = off): the two stride phases of a transposed convolution
+    // computed as ONE GEMM with 2 C output columns, phase 1 going to the next output row (trajnet.hip upsample)
+    int ncol_split, ncol_jump;
     // ---- split-K (few-tile, long-K problems: TrajNet's deep levels): workgroup (tile, split) accumulates the K
     // chunks of its split and stores the raw partial tile to partial[split][m][n] (row stride ld_partial); a second
     // kernel sums the splits in a fixed order, adds the bias and writes C.  ksplit <= 1: off.  EPI_BIAS only.

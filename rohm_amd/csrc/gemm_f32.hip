@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 }
             }
             const size_t crow = CONV ? (size_t)m * (p.orow_mul_m1 + 1) + p.orow_add : (size_t)m;
-            float* cp = p.C + crow * p.ldc + nb;
+            float* cp = p.C + crow * p.ldc + nb + ((CONV && p.ncol_split && nb >= p.ncol_split) ? p.ncol_jump : 0);
             if (vec_ok) {
                 *reinterpret_cast<f32x4*>(cp) = v;
             } else {
@@ -632,7 +632,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 // (deterministic).  One thread per 4 columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N,
                                                             int ldp, const float* __restrict__ bias, float* __restrict__ C,
-                                                            int ldc, int orow_mul_m1, int orow_add) {
+                                                            int ldc, int orow_mul_m1, int orow_add, int ncol_split,
+                                                            int ncol_jump) {
     const int n4 = (N + 3) / 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)M * n4) return;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] += v[q];
     }
-    float* cp = C + ((size_t)m * (orow_mul_m1 + 1) + orow_add) * ldc + nb;
+    float* cp = C + ((size_t)m * (orow_mul_m1 + 1) + orow_add) * ldc + nb + ((ncol_split && nb >= ncol_split) ? ncol_jump : 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (nb + q < N) cp[q] = acc[q] + (bias ? bias[nb + q] : 0.f);
@@ -711,7 +712,8 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
         prof::Scope pr("splitk_reduce", 0.0, 4.0 * ((double)ksplit + 1.0) * p.M * p.N, s);
         const long n = (long)p.M * ((p.N + 3) / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.partial, ksplit, p.M,
-                           p.N, p.ld_partial, p.bias, p.C, p.ldc, CONV ? p.orow_mul_m1 : 0, CONV ? p.orow_add : 0);
+                           p.N, p.ld_partial, p.bias, p.C, p.ldc, CONV ? p.orow_mul_m1 : 0, CONV ? p.orow_add : 0,
+                           CONV ? p.ncol_split : 0, CONV ? p.ncol_jump : 0);
         ROHM_LAUNCH_CHECK();
     }
     return ROHM_OK;

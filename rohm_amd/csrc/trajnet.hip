@@ -26,14 +26,16 @@ struct ConvW {          // re-laid-out conv weight: [cout, taps * cin_pad] + bia
     float* b = nullptr;
     int cin = 0, cin_pad = 0, cout = 0, taps = 0;
 };
-struct UpW { ConvW even, odd; };          // ConvTranspose1d(k4, s2, p1) as two 2-tap phases
+struct UpW { ConvW even, odd, both; };    // ConvTranspose1d(k4, s2, p1) as two 2-tap phases; `both` = the two phases as ONE
+                                          // 3-tap GEMM with 2 C output columns (phase 1 stored to the next output row)
 struct BlockW {                           // Conv1dBlock: conv5 + GroupNorm(8)
     ConvW conv;
     float *g = nullptr, *be = nullptr;
 };
-struct ResW {                             // ResidualTemporalBlock
+struct ResW {                             // ResidualTemporalBlock (b0res: block-0 conv and the 1x1 residual conv as ONE GEMM)
     BlockW b0, b1;
     ConvW res;                            // 1x1 when cin != cout (taps == 0 -> absent)
+    ConvW b0res;                          // [2 cout, 5 cin_pad]: rows [0, cout) = b0.conv, rows [cout, 2 cout) = res at the centre tap
     bool has_res = false;
     int tb_off = -1;                      // offset of this block's time bias inside tb_all, -1 = no time input
     int cin = 0, cout = 0;
@@ -334,14 +336,15 @@ static void plan_split(GemmParams& g, float* buf = nullptr, SplitInfo* defer = n
 
 static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int tin, int tq,
                      int stride, const int* offs, float* out, int ldo, int orow_mul, int orow_add, hipStream_t s,
-                     SplitInfo* defer = nullptr) {
+                     SplitInfo* defer = nullptr, float* splitk_buf = nullptr, int ncol_split = 0, int ncol_jump = 0) {
     GemmParams g{};
     g.A = x; g.lda = ldx; g.W = w.w; g.ldw = w.taps * w.cin_pad; g.C = out; g.ldc = ldo;
     g.M = B * tq; g.N = w.cout; g.K = w.taps * w.cin_pad; g.bias = w.b;
     g.conv_taps = w.taps; g.conv_cin_pad = w.cin_pad; g.conv_tin = tin; g.conv_tq = tq; g.conv_stride = stride;
     for (int j = 0; j < w.taps; ++j) g.conv_off[j] = offs[j];
     g.zero_page = h->zero_page; g.orow_mul_m1 = orow_mul - 1; g.orow_add = orow_add;
-    plan_split(g, nullptr, defer);
+    g.ncol_split = ncol_split; g.ncol_jump = ncol_jump;
+    plan_split(g, splitk_buf, defer);
     return launch_gemm(g, EPI_BIAS, s);
 }
 static int conv5(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
@@ -364,11 +367,21 @@ static int down(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, 
 }
 static int upsample(const rohm_trajnet* h, const UpW& w, const float* x, int ldx, int B, int Tq, float* out, int ldo,
                     hipStream_t s) {   // ConvTranspose1d(k4, s2, p1): heads.py:81-87
-    static const int off_even[2] = {0, -1}, off_odd[2] = {1, 0};
-    int rc = conv_gemm(h, w.even, x, ldx, B, Tq, Tq, 1, off_even, out, ldo, 2, 0, s);
-    if (rc) return rc;
-    return conv_gemm(h, w.odd, x, ldx, B, Tq, Tq, 1, off_odd, out, ldo, 2, 1, s);
+    // out[2t] = W1 x[t] + W3 x[t-1],  out[2t+1] = W0 x[t+1] + W2 x[t]: one GEMM over the taps {-1, 0, +1} with the even
+    // phase in columns [0, C) and the odd phase in [C, 2C); row m = (b, t) starts at output row 2 m and the odd columns
+    // jump to row 2 m + 1 (ldo - C floats further)
+    static const int offs[3] = {-1, 0, 1};
+    const int Cc = w.even.cout;
+    return conv_gemm(h, w.both, x, ldx, B, Tq, Tq, 1, offs, out, ldo, 2, 0, s, nullptr, nullptr, Cc, ldo - Cc);
 }
+// Column views of a fused conv result (plain tensor, or un-reduced split-K slabs) for the GroupNorm kernel.
+struct GnFused {
+    SplitInfo si; const float* plain; int ldplain;
+    const float* y(int col) const { return si.S > 1 ? nullptr : plain + col; }
+    int ld() const { return ldplain; }
+    SplitInfo split(int col) const { SplitInfo o = si; if (o.S > 1) o.base = si.base + col; return o; }
+};
+
 static int gn(const BlockW& bw, const float* y, int ldy, const SplitInfo& sy, int B, int T, const float* tb, int ldtb,
               const float* res, int ldres, const SplitInfo& sr, const float* res_bias, const float* add2, int ldadd2,
               float* dst, int lddst, float* dst2, int lddst2, hipStream_t s) {
@@ -402,17 +415,25 @@ static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int l
     int rc;
     const int co = r.cout;
     SplitInfo s0, s1, sr, none;
-    if ((rc = conv5(h, r.b0.conv, x, ldx, B, T, sc.ya, co, s, &s0))) return rc;
-    const float* res = x;
-    int ldres = ldx;
-    if (r.has_res) {       // before the GroupNorm so that its slabs (own buffer) are the only thing kept alive
-        if ((rc = conv1(r.res, x, ldx, B * T, sc.rc, co, s, &sr))) return rc;
-        res = sc.rc; ldres = co;
-    }
     const float* tb = (r.tb_off >= 0) ? tb_all + r.tb_off : nullptr;
+    if (r.has_res) {
+        // block-0 conv and the 1x1 residual conv in one launch: C = [conv5(x) | res(x)], 2 co columns.  Its split-K slabs go
+        // to the residual buffer (they must outlive the second conv, which re-uses the other one).
+        SplitInfo sf;
+        static const int offs[5] = {-2, -1, 0, 1, 2};
+        if ((rc = conv_gemm(h, r.b0res, x, ldx, B, T, T, 1, offs, sc.ya, 2 * co, 1, 0, s, &sf, tl_splitk_res))) return rc;
+        GnFused f0{sf, sc.ya, 2 * co};
+        if ((rc = gn(r.b0, f0.y(0), f0.ld(), f0.split(0), B, T, tb, ldtb, nullptr, 0, none, nullptr, nullptr, 0, sc.hb, co,
+                     nullptr, 0, s)))
+            return rc;
+        if ((rc = conv5(h, r.b1.conv, sc.hb, co, B, T, sc.rc, co, s, &s1))) return rc;
+        return gn(r.b1, sc.rc, co, s1, B, T, nullptr, 0, f0.y(co), f0.ld(), f0.split(co), r.b0res.b + co, add2, ldadd2, dst,
+                  lddst, dst2, lddst2, s);
+    }
+    if ((rc = conv5(h, r.b0.conv, x, ldx, B, T, sc.ya, co, s, &s0))) return rc;
     if ((rc = gn(r.b0, sc.ya, co, s0, B, T, tb, ldtb, nullptr, 0, none, nullptr, nullptr, 0, sc.hb, co, nullptr, 0, s))) return rc;
     if ((rc = conv5(h, r.b1.conv, sc.hb, co, B, T, sc.ya, co, s, &s1))) return rc;
-    return gn(r.b1, sc.ya, co, s1, B, T, nullptr, 0, res, ldres, sr, r.res.b, add2, ldadd2, dst, lddst, dst2, lddst2, s);
+    return gn(r.b1, sc.ya, co, s1, B, T, nullptr, 0, x, ldx, sr, nullptr, add2, ldadd2, dst, lddst, dst2, lddst2, s);
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------
@@ -461,7 +482,7 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     w.fin = take(M * kPadC);
     w.tb_all = take((size_t)B * h->tb_total);
     w.tb_steps = take((size_t)kTbSteps * h->tb_total);
-    w.sc.ya = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
+    w.sc.ya = take(2 * (M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m));     // fused [conv | residual] result
     w.sc.hb = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
     w.sc.rc = take(M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m);
     w.x0 = take(M * h->ctraj);
@@ -757,7 +778,28 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
             tb_cout.push_back(cout);
         }
         r.has_res = (cin != cout);
-        if (r.has_res) conv_std(r.res, cout, cin, 1);
+        if (r.has_res) {
+            conv_std(r.res, cout, cin, 1);
+            // the residual conv reads the same input as the block's first conv: one GEMM with 2 cout output columns, the
+            // 1x1 weights sitting at the centre tap (the arena is zero-filled)
+            ConvW& f = r.b0res;
+            const ConvW& a0 = r.b0.conv;
+            f.cout = 2 * cout; f.cin = cin; f.cin_pad = a0.cin_pad; f.taps = 5;
+            const size_t K5 = (size_t)5 * a0.cin_pad;
+            f.w = arena_take((size_t)2 * cout * K5);
+            f.b = arena_take(2 * cout);
+            if (base && ok) {
+                if (hipDeviceSynchronize() != hipSuccess ||
+                    hipMemcpy(f.w, a0.w, (size_t)cout * K5 * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess ||
+                    hipMemcpy2D(f.w + (size_t)cout * K5 + 2 * a0.cin_pad, K5 * sizeof(float), r.res.w,
+                                (size_t)r.res.cin_pad * sizeof(float), (size_t)r.res.cin_pad * sizeof(float), cout,
+                                hipMemcpyDeviceToDevice) != hipSuccess ||
+                    hipMemcpy(f.b, a0.b, cout * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess ||
+                    hipMemcpy(f.b + cout, r.res.b, cout * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) {
+                    ok = false; err = "fused residual weights";
+                }
+            }
+        }
     };
     const float *w1 = nullptr, *b1 = nullptr, *w3 = nullptr, *b3 = nullptr;
     const float* upw[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -797,6 +839,27 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
             if (ok) {
                 load_conv(h->up[i].even, ch[i], ch[i], 4, 1, 2, 2, true, upw[i], upb[i]);   // taps j = 1, 3
                 load_conv(h->up[i].odd, ch[i], ch[i], 4, 0, 2, 2, true, upw[i], upb[i]);    // taps j = 0, 2
+            }
+            {   // even = [tap @0 | tap @-1], odd = [tap @+1 | tap @0]  ->  both = [@-1 | @0 | @+1] x {even rows, odd rows}
+                UpW& u = h->up[i];
+                const int Cc = ch[i], cp = u.even.cin_pad;
+                u.both.cout = 2 * Cc; u.both.cin = Cc; u.both.cin_pad = cp; u.both.taps = 3;
+                u.both.w = arena_take((size_t)2 * Cc * 3 * cp);
+                u.both.b = arena_take(2 * Cc);
+                if (base && ok) {
+                    const size_t sp = (size_t)2 * cp * sizeof(float), dp = (size_t)3 * cp * sizeof(float), wd = (size_t)cp * sizeof(float);
+                    float* de = u.both.w;
+                    float* dod = u.both.w + (size_t)Cc * 3 * cp;
+                    if (hipDeviceSynchronize() != hipSuccess ||
+                        hipMemcpy2D(de, dp, u.even.w + cp, sp, wd, Cc, hipMemcpyDeviceToDevice) != hipSuccess ||          // @-1
+                        hipMemcpy2D(de + cp, dp, u.even.w, sp, wd, Cc, hipMemcpyDeviceToDevice) != hipSuccess ||          // @0
+                        hipMemcpy2D(dod + cp, dp, u.odd.w + cp, sp, wd, Cc, hipMemcpyDeviceToDevice) != hipSuccess ||     // @0
+                        hipMemcpy2D(dod + 2 * cp, dp, u.odd.w, sp, wd, Cc, hipMemcpyDeviceToDevice) != hipSuccess ||      // @+1
+                        hipMemcpy(u.both.b, u.even.b, Cc * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess ||
+                        hipMemcpy(u.both.b + Cc, u.odd.b, Cc * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) {
+                        ok = false; err = "fused upsample weights";
+                    }
+                }
             }
             resblk(h->dec[i], 2 * ch[i], i == 0 ? 32 : ch[i - 1], true);
         }
