@@ -309,6 +309,7 @@ static inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
 // enough splits to give every CU a workgroup, at least 4 K chunks per split.  The partial-tile buffer is part of the
 // caller's workspace; forward() publishes it here for the launch helpers of this host thread.
 constexpr size_t kSplitKFloats = (size_t)256 * 144 * 128;
+constexpr size_t kFuseMaxWork = (size_t)64 * 144 * 64;   // rows x channels of a level up to which the fused conv forms pay (B <= 64)
 constexpr int kTbSteps = 128;             // loop steps whose time path is evaluated by one launch
 constexpr int kGraphMaxSteps = 1024;       // steps per sample-loop call that the captured-graph path accepts
 static thread_local float* tl_splitk = nullptr;       // partial slabs of the conv feeding the next kernel
@@ -372,7 +373,12 @@ static int upsample(const rohm_trajnet* h, const UpW& w, const float* x, int ldx
     // jump to row 2 m + 1 (ldo - C floats further)
     static const int offs[3] = {-1, 0, 1};
     const int Cc = w.even.cout;
-    return conv_gemm(h, w.both, x, ldx, B, Tq, Tq, 1, offs, out, ldo, 2, 0, s, nullptr, nullptr, Cc, ldo - Cc);
+    if ((size_t)B * Tq * Cc * 2 <= kFuseMaxWork)
+        return conv_gemm(h, w.both, x, ldx, B, Tq, Tq, 1, offs, out, ldo, 2, 0, s, nullptr, nullptr, Cc, ldo - Cc);
+    static const int off_even[2] = {0, -1}, off_odd[2] = {1, 0};      // compute-bound batches: the two 2-tap phases
+    int rc = conv_gemm(h, w.even, x, ldx, B, Tq, Tq, 1, off_even, out, ldo, 2, 0, s);
+    if (rc) return rc;
+    return conv_gemm(h, w.odd, x, ldx, B, Tq, Tq, 1, off_odd, out, ldo, 2, 1, s);
 }
 // Column views of a fused conv result (plain tensor, or un-reduced split-K slabs) for the GroupNorm kernel.
 struct GnFused {
@@ -416,7 +422,9 @@ static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int l
     const int co = r.cout;
     SplitInfo s0, s1, sr, none;
     const float* tb = (r.tb_off >= 0) ? tb_all + r.tb_off : nullptr;
-    if (r.has_res) {
+    // the fused forms trade flops (zero taps) for launches: only while the step is latency-bound (measured: B = 256 loses
+    // 10 % with them, B <= 32 gains 8-11 %); T * cout is the same at every level, so this is a bound on the batch
+    if (r.has_res && (size_t)B * T * co <= kFuseMaxWork) {
         // block-0 conv and the 1x1 residual conv in one launch: C = [conv5(x) | res(x)], 2 co columns.  Its split-K slabs go
         // to the residual buffer (they must outlive the second conv, which re-uses the other one).
         SplitInfo sf;
@@ -431,9 +439,15 @@ static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int l
                   lddst, dst2, lddst2, s);
     }
     if ((rc = conv5(h, r.b0.conv, x, ldx, B, T, sc.ya, co, s, &s0))) return rc;
+    const float* res = x;
+    int ldres = ldx;
+    if (r.has_res) {
+        if ((rc = conv1(r.res, x, ldx, B * T, sc.rc, co, s, &sr))) return rc;
+        res = sc.rc; ldres = co;
+    }
     if ((rc = gn(r.b0, sc.ya, co, s0, B, T, tb, ldtb, nullptr, 0, none, nullptr, nullptr, 0, sc.hb, co, nullptr, 0, s))) return rc;
     if ((rc = conv5(h, r.b1.conv, sc.hb, co, B, T, sc.ya, co, s, &s1))) return rc;
-    return gn(r.b1, sc.ya, co, s1, B, T, nullptr, 0, x, ldx, sr, nullptr, add2, ldadd2, dst, lddst, dst2, lddst2, s);
+    return gn(r.b1, sc.ya, co, s1, B, T, nullptr, 0, res, ldres, sr, r.res.b, add2, ldadd2, dst, lddst, dst2, lddst2, s);
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------
