@@ -91,6 +91,17 @@ def test_attention_general_shapes(n_seq, n_head, S, dh):
     assert max_abs(ops.attention(qkv2.to(_dev()), n_seq, n_head, S, dh).cpu(), ref) < 1e-4
 
 
+@pytest.mark.parametrize('n_seq', [64, 32, 7])
+def test_attention_is_bit_reproducible(n_seq):
+    """Race screen of the LDS-DMA / counted-vmcnt / raw-barrier pipeline (both launch shapes): the same launch repeated
+    100 times must return the same bits every time."""
+    from rohm_amd import ops
+    qkv = seeded(n_seq, n_seq * 144, 1536).to(_dev())
+    ref = ops.attention(qkv, n_seq, 4).clone()
+    for _ in range(100):
+        assert torch.equal(ops.attention(qkv, n_seq, 4), ref)
+
+
 def test_ddpm_step_kernels():
     from rohm_amd import ops
     from oracle import diffusion as odiff
