@@ -109,3 +109,36 @@ def test_recover_rel_traj_matches_reference():
     x0 = synth.plausible_motion(int(g['motion_seed']), 2, 143, mean, std)
     d = G.split_repr(x0[:, :, 0].permute(0, 2, 1) * torch.from_numpy(std) + torch.from_numpy(mean))
     assert float((G.joints_from_rel_traj(d) - torch.from_numpy(g['j_rel'])).abs().max()) == 0.0
+
+
+def _round_trip_inputs(T=60):
+    """A smooth synthetic clip: SMPL-X parameters -> canonical joints (oracle body model)."""
+    import numpy as np
+    from rohm_amd.utils import synth
+    g = np.random.Generator(np.random.PCG64(321))
+    tt = np.linspace(0, 1, T)[:, None]
+    params = {'transl': (np.concatenate([0.5 * np.sin(2 * tt), 0.4 * tt, 0.05 * np.cos(3 * tt)], 1)).astype(np.float32),
+              'global_orient': (np.array([[1.4, 0.1, -0.2]]) + 0.3 * np.sin(2 * np.pi * tt * g.uniform(0.5, 1.5, (1, 3)))).astype(np.float32),
+              'body_pose': (0.2 * np.sin(2 * np.pi * tt * g.uniform(0.3, 1.2, (1, 63)) + g.uniform(0, 6, (1, 63)))).astype(np.float32),
+              'betas': np.tile(g.standard_normal((1, 10)).astype(np.float32) * 0.5, (T, 1))}
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    with torch.no_grad():
+        joints = body(**{k: torch.from_numpy(v) for k, v in params.items()}, return_verts=False).joints[:, :22].numpy()
+    return params, joints, body
+
+
+def test_repr_round_trip_reproduces_the_canonical_joints():
+    """The author's own check (data_loaders/dataloader_amass.py:230-236, left as a debug note): the representation built
+    by `get_repr_smplx` from a clip's joints + SMPL-X parameters, recovered with `recover_from_repr_smpl(...,
+    'smplx_params')`, gives the clip's canonical joints back (T - 1 frames) -- and so does the 'joint_abs_traj' recovery
+    (root trajectory + rotated local joints)."""
+    from oracle import rederive as RD
+    params, joints, body = _round_trip_inputs()
+    d = RD.get_repr_smplx(joints, params)
+    full = torch.from_numpy(RD.full_repr(d)).float()[None]                      # [1, T-1, 294]
+    rep = G.split_repr(full)
+    j_smpl = G.joints_from_smplx(rep, body)[0].numpy()
+    j_abs = G.joints_from_abs_traj(rep)[0].numpy()
+    assert full.shape == (1, joints.shape[0] - 1, 294)
+    assert abs(j_smpl - joints[:-1]).max() < 2e-5
+    assert abs(j_abs - joints[:-1]).max() < 2e-5

@@ -171,3 +171,21 @@ def test_lbs_vertices_vs_oracle_with_face_and_hands():
     ref2 = body(betas=betas, global_orient=go, body_pose=bp, transl=tr, return_verts=True)
     out2 = layer(betas=g(betas), global_orient=g(go), body_pose=g(bp), transl=g(tr), return_verts=True)
     assert max_abs(out2.vertices.cpu(), ref2.vertices) < 2e-5
+
+
+def test_repr_round_trip_on_the_device():
+    """SURVEY §4 invariant (the author's debug note, dataloader_amass.py:230-236) through the HIP kernels: joints recovered
+    by `rohm_repr_joints` from the representation that `get_repr_smplx` builds give the canonical joints back, for both
+    recoveries; and re-deriving the trajectory from that representation (`rohm_traj_rederive`) reproduces its first 22
+    channels."""
+    from test_geometry_oracle import _round_trip_inputs
+    from oracle import rederive as RD
+    from rohm_amd.body_model import SMPLXLayer
+    from rohm_amd.data_loaders.motion_representation import joints_from_repr
+    params, joints, _ = _round_trip_inputs()
+    full = torch.from_numpy(RD.full_repr(RD.get_repr_smplx(joints, params))).float()[None].to(DEV)      # [1, T-1, 294]
+    layer = SMPLXLayer.from_tensors(synth.synthetic_smplx_tensors(0)).to(DEV)
+    j_smpl = joints_from_repr(full, 'smplx_params', layer)[0].cpu().numpy()
+    j_abs = joints_from_repr(full, 'joint_abs_traj')[0].cpu().numpy()
+    assert abs(j_smpl - joints[:-1]).max() < 2e-5
+    assert abs(j_abs - joints[:-1]).max() < 2e-5
