@@ -377,6 +377,23 @@ def golden_frames(ref):
     print('frames.npz', os.path.getsize(os.path.join(OUT, 'frames.npz')), np.asarray(smplx_world).dtype)
 
 
+def golden_control_loop(ref):
+    """TrajControl (TrajNet + ControlNet, randomised zero-convs) through the reference's own 100-step sampler: the stage
+    every inference iteration >= 1 runs (test_amass_full.py:252-266), B = 2 clips."""
+    sdt = synth.trajnet_state_dict(seed=23, trajcontrol=True)
+    tn = ref.trajnet.TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=True).eval()
+    tn.load_state_dict(sdt, strict=True)
+    d = ref.model_util.create_gaussian_diffusion(_Args, ref.gd_trajnet, ref.respace.SpacedDiffusionTrajNet, 100, '', device='cpu')
+    batch = {'cond': seeded(214, 2, 144, 13), 'control_cond': seeded(215, 2, 144, 272)}
+    torch.manual_seed(4322)
+    with torch.no_grad():
+        _, y = d.eval_losses(model=tn, batch=batch, shape=[2, 144, 13], progress=False, clip_denoised=False,
+                             timestep_respacing='', cond_fn_with_grad=True, compute_loss=False)
+    np.savez_compressed(os.path.join(OUT, 'trajnet_control_loop100.npz'), weight_seed=23, cond_seed=214, control_seed=215,
+                        torch_seed=4322, steps=100, y=y.numpy())
+    print('trajnet_control_loop100.npz', os.path.getsize(os.path.join(OUT, 'trajnet_control_loop100.npz')))
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -411,6 +428,9 @@ def main():
     if sys.argv[1:] == ['rel']:
         warnings.filterwarnings('ignore')
         return golden_rel(refload.load())
+    if sys.argv[1:] == ['control_loop']:
+        warnings.filterwarnings('ignore')
+        return golden_control_loop(refload.load())
     if sys.argv[1:] == ['frames']:
         warnings.filterwarnings('ignore')
         return golden_frames(refload.load())
@@ -515,6 +535,7 @@ def main():
     golden_guided_step(ref)
     golden_scheme(ref)
     golden_frames(ref)
+    golden_control_loop(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

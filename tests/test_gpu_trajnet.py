@@ -87,6 +87,21 @@ def test_loop100_vs_reference_golden():
         assert max_abs(y.cpu(), torch.from_numpy(g['y'])) < 1e-3, fused
 
 
+def test_control_loop100_vs_reference_golden():
+    """TrajControl (ControlNet residuals on) through the full 100-step loop against the REFERENCE's own sampler
+    (tests/golden/trajnet_control_loop100.npz): the stage every inference iteration >= 1 of configs 3-5 runs."""
+    g = golden('trajnet_control_loop100.npz')
+    net, _ = make_trajnet(int(g['weight_seed']), True)
+    cond, cc = seeded(int(g['cond_seed']), 2, 144, 13), seeded(int(g['control_seed']), 2, 144, 272)
+    x_T, noises = cpu_noise_sequence(int(g['torch_seed']), (2, 144, 13), 100, trajnet_layout=True)
+    diff = make_diffusion()
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    _, y = diff.eval_losses(model=net, batch={'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}, shape=[2, 144, 13],
+                            progress=False, clip_denoised=False, timestep_respacing='', cond_fn_with_grad=True,
+                            compute_loss=False)
+    assert max_abs(y.cpu(), torch.from_numpy(g['y'])) < 1e-3
+
+
 def test_control_loop_vs_oracle():
     net, sd = make_trajnet(61, True)
     B = 2
