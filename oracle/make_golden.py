@@ -394,6 +394,26 @@ def golden_control_loop(ref):
     print('trajnet_control_loop100.npz', os.path.getsize(os.path.join(OUT, 'trajnet_control_loop100.npz')))
 
 
+def golden_posenet_loop1000(ref):
+    """The headline configuration end to end through the REFERENCE's own code: full-size PoseNet, the 1000-step cosine
+    schedule, `eval_losses` (p_sample_loop, no guidance), one clip, CPU generator noise from a seed."""
+    sd = synth.posenet_state_dict(seed=17)
+    net = ref.posenet.PoseNet(_DS(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                              device='cpu').eval()
+    net.load_state_dict(sd, strict=True)
+    diff = ref.model_util.create_gaussian_diffusion(_Args, ref.gd_posenet, ref.respace.SpacedDiffusionPoseNet, 1000, '',
+                                                    device='cpu')
+    mean, std = synth.synthetic_stats(1)
+    cond = synth.plausible_motion(8, 1, 143, mean, std)
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        _, y = diff.eval_losses(model=net, batch={'cond': cond}, shape=[1, 294, 1, 143], progress=False, clip_denoised=False,
+                                timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+    np.savez_compressed(os.path.join(OUT, 'posenet_loop1000.npz'), weight_seed=17, stats_seed=1, cond_seed=8, torch_seed=2024,
+                        steps=1000, y=y.numpy())
+    print('posenet_loop1000.npz', os.path.getsize(os.path.join(OUT, 'posenet_loop1000.npz')), float(y.abs().max()))
+
+
 def golden_metrics():
     """Run the reference's own metric statements (eval_amass_full.py:67-148, read from its file) on synthetic
     results.  The script cannot be imported (argparse / smplx / open3d at module level), the block can be executed."""
@@ -431,6 +451,10 @@ def main():
     if sys.argv[1:] == ['control_loop']:
         warnings.filterwarnings('ignore')
         return golden_control_loop(refload.load())
+    if sys.argv[1:] == ['posenet_loop1000']:
+        warnings.filterwarnings('ignore')
+        torch.set_num_threads(8)
+        return golden_posenet_loop1000(refload.load())
     if sys.argv[1:] == ['frames']:
         warnings.filterwarnings('ignore')
         return golden_frames(refload.load())
@@ -536,6 +560,7 @@ def main():
     golden_scheme(ref)
     golden_frames(ref)
     golden_control_loop(ref)
+    golden_posenet_loop1000(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

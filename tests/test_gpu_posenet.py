@@ -240,3 +240,21 @@ def test_two_streams_get_distinct_workspaces_and_agree():
     assert len({k[2] for k in net.native()._ws}) >= 2
     for o in outs:
         assert torch.equal(o, ref)
+
+
+def test_full_1000_step_loop_vs_reference_golden():
+    """The headline configuration against the REFERENCE's own sampler, not only the oracle: 1000 ancestral steps of one clip
+    through `eval_losses` (fused HIP loop) vs tests/golden/posenet_loop1000.npz (reference PoseNet + SpacedDiffusionPoseNet
+    on CPU, generator noise replayed)."""
+    g = golden('posenet_loop1000.npz')
+    net, _ = make_posenet(int(g['weight_seed']))
+    mean, std = synth.synthetic_stats(int(g['stats_seed']))
+    cond = synth.plausible_motion(int(g['cond_seed']), 1, 143, mean, std)
+    x_T, noises = cpu_noise_sequence(int(g['torch_seed']), (1, 294, 1, 143), 1000)
+    diff = make_diffusion(1000)
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    _, y = diff.eval_losses(model=net, batch={'cond': cond.to(DEV)}, shape=[1, 294, 1, 143], progress=False,
+                            clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+    err = max_abs(y.cpu(), torch.from_numpy(g['y']))
+    print(f'1000-step loop vs the reference: max|HIP - reference| = {err:.3e}')
+    assert err < 1e-3, err
