@@ -105,6 +105,48 @@ def pmc_mfma():
         return None
 
 
+def accuracy_vs_reference(dev):
+    """The metric's second half ("MPJPE vs ref"): one clip through all 1000 DDPM steps of the drop-in API with the noise
+    stream the REFERENCE drew on CPU, compared with what the reference's own code produced from it
+    (tests/golden/posenet_loop1000.npz, generated by oracle/make_golden.py in the build container): max |diff| on the
+    294-channel output and MPJPE of the SMPL-X joints recovered from both (synthetic body model: no SMPL-X files here).
+    Outside the timed region."""
+    path = os.path.join(ROOT, 'tests', 'golden', 'posenet_loop1000.npz')
+    if not os.path.exists(path):
+        return None
+    from rohm_amd.body_model import SMPLXLayer
+    from rohm_amd.data_loaders.motion_representation import joints_from_repr
+    from rohm_amd.diffusion import gaussian_diffusion_posenet as gdp
+    from rohm_amd.diffusion.respace import SpacedDiffusionPoseNet
+    from rohm_amd.model.posenet import PoseNet
+    from rohm_amd.utils import synth
+    from rohm_amd.utils.model_util import create_gaussian_diffusion
+    g = np.load(path)
+    net = PoseNet(_Dataset(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                  body_model_path=torch.nn.Identity(), device=dev)
+    net.load_state_dict(synth.posenet_state_dict(int(g['weight_seed'])), strict=True)
+    net = net.to(dev).eval()
+    mean, std = synth.synthetic_stats(int(g['stats_seed']))
+    cond = synth.plausible_motion(int(g['cond_seed']), 1, 143, mean, std).to(dev)
+    state = torch.get_rng_state()
+    torch.manual_seed(int(g['torch_seed']))                 # the reference: one randn(*shape), then one randn_like per step
+    x_T = torch.randn(1, 294, 1, 143)
+    noises = [torch.randn(1, 294, 1, 143) for _ in range(1000)]     # separate calls: one big randn is a different stream
+    torch.set_rng_state(state)
+    diff = create_gaussian_diffusion(_Args, gdp, SpacedDiffusionPoseNet, 1000, '', device=dev)
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    _, y = diff.eval_losses(model=net, batch={'cond': cond}, shape=[1, 294, 1, 143], progress=False, clip_denoised=False,
+                            timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+    ref = torch.from_numpy(g['y']).to(dev)
+    layer = SMPLXLayer.from_tensors(synth.synthetic_smplx_tensors(0)).to(dev)
+    j_hip = joints_from_repr(y, 'smplx_params', layer, stats=(mean, std), layout='bc1t')
+    j_ref = joints_from_repr(ref, 'smplx_params', layer, stats=(mean, std), layout='bc1t')
+    return {'max_abs_vs_reference': float((y - ref).abs().max()),
+            'mpjpe_mm_vs_reference': float((j_hip - j_ref).norm(dim=-1).mean()) * 1000.0,
+            'sample': '1 clip, 1000 DDPM steps, reference CPU run of the same inputs / noise (tests/golden/posenet_loop1000.npz); '
+                      'joints through a synthetic SMPL-X model', 'tolerance': '1e-3 / 1 mm (BASELINE.json north_star)'}
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -524,6 +566,7 @@ def main(argv=None):
         }
         if world == 1 and not args.no_cpu_baseline and not prox:
             rec['cpu_baseline'] = cpu_baseline(batch=B)
+            rec['accuracy'] = accuracy_vs_reference(dev)
         print(json.dumps(rec), flush=True)
     finish(world, dist)
 
