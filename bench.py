@@ -558,6 +558,12 @@ def main(argv=None):
                 'traffic': pmc_traffic()[0] if not _PRODUCTS else None, 'traffic_unit': 'bytes per launch (HBM side, PMC)',
                 'traffic_source': pmc_traffic()[1],
                 'mfma_busy_pmc': pmc_mfma(),
+                # north_star: "... as fraction of the attention/GEMM roofline": the attention kernel by the same event timing
+                'attention': ({'achieved': prof['attention']['flops'] / (prof['attention']['total_ms'] * 1e-3) / 1e12,
+                               'frac': prof['attention']['flops'] / (prof['attention']['total_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                               'avg_launch_us': prof['attention']['total_ms'] / prof['attention']['launches'] * 1e3,
+                               'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS}
+                              if prof.get('attention', {}).get('total_ms') else None),
                 'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
                 'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,
                 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
