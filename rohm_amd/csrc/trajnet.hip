@@ -137,12 +137,14 @@ struct GnArgs {
     float* dst2; int lddst2;            // optional second destination (skip / concat copy)
 };
 
-// One block per (sample, group).  A group is (C/8 channels) x T <= 1280 values: each thread keeps its <= 5 values in
+// One block per (sample, group).  A group is (C/8 channels) x T values (1152 at every level of a 144-frame clip, up to
+// 4096 supported): each thread keeps its values in
 // registers (ONE pass over memory; round 1 made three, with two 8-step block reductions), the statistics are two
 // wave-shuffle reductions + one LDS exchange each.  With split-K the block sums the partial slabs itself -- the
 // separate reduction kernel (35 of the 98 launches of a denoising step) disappears for every conv that feeds a
 // GroupNorm, and so does the round trip of the reduced tensor through memory.
-constexpr int kGnMaxPerThread = 5;
+constexpr int kGnMaxPerThread = 16;      // scalar units per thread: groups of up to 4096 values (T <= 512 at 8 channels per group)
+constexpr int kGnVecPerThread = 4;       // 16-byte units per thread: the same 4096 values
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -158,7 +160,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void gn_mish_kernel(GnArgs a) {
     constexpr int W = VEC ? 4 : 1;                  // floats per unit
-    constexpr int NU = VEC ? 2 : kGnMaxPerThread;   // units per thread
+    constexpr int NU = VEC ? kGnVecPerThread : kGnMaxPerThread;   // units per thread (unused ones are predicated off)
     const int b = blockIdx.x, g = blockIdx.y;
     const int cg = a.C >> 3;                        // channels per group: a power of two (4 .. 64)
     const int ug = cg / W;                          // units per row of the group

@@ -43,7 +43,8 @@ def test_forward_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize('B,T,ctrl', [(1, 144, False), (3, 144, True), (2, 48, True), (5, 16, False), (32, 144, True),
-                                      (72, 144, True)])      # B > 64: the un-fused conv forms (compute-bound batches)
+                                      (72, 144, True),      # B > 64: the un-fused conv forms (compute-bound batches)
+                                      (2, 288, True), (1, 400, False)])   # long clips: GroupNorm groups of 2304 / 3200 values
 def test_forward_vs_oracle(B, T, ctrl):
     net, sd = make_trajnet(40 + B, ctrl)
     x, c, cc = seeded(1, B, T, 13), seeded(2, B, T, 13), seeded(3, B, T, 272)
