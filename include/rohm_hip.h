@@ -173,6 +173,11 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* w, int
                         int c_traj, int c_ctrl, int trajcontrol, int device);
 void rohm_trajnet_destroy(rohm_trajnet_t* h);
 size_t rohm_trajnet_workspace_bytes(const rohm_trajnet_t* h, int B, int T);
+/* Launch shape of TrajNet's latency-bound convolutions (process-wide; no counterpart in the reference, whose convs are
+ * torch's): conv_wg_per_cu = workgroups of a conv GEMM that may share a CU (1 or 2; a 144x64 tile needs 60 KB of the 160 KB
+ * LDS), split_min_chunks = fewest 32-wide K chunks a split-K slice may get.  Results do not depend on either beyond the
+ * fp32 summation order of split-K.  The defaults are the measured optimum on MI355X. */
+int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks);
 
 /* TrajNet.forward (model/trajnet.py:177-275): x_t, cond [B, T, c_traj], control_cond [B, T, c_ctrl] (NULL
  * without TrajControl), t int64[B] -> x0_out [B, T, c_traj].  T must be a multiple of 16. */

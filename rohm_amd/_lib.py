@@ -77,6 +77,7 @@ SIGNATURES = {
     'rohm_trajnet_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(TrajNetWeights), C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int]),
     'rohm_trajnet_destroy': (None, [C.c_void_p]),
+    'rohm_trajnet_tune': (C.c_int, [C.c_int, C.c_int]),
     'rohm_trajnet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'rohm_trajnet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -106,6 +106,7 @@ struct GemmParams {
     // kernel sums the splits in a fixed order, adds the bias and writes C.  ksplit <= 1: off.  EPI_BIAS only.
     int ksplit; float* partial; int ld_partial;
     int ksplit_defer;            // 1: leave the partial slabs un-reduced (the consumer sums them: trajnet.hip GroupNorm)
+    int wg_per_cu;               // 2: let two workgroups share a CU (narrow tiles of latency-bound launches); else one is pinned
     // ---- LayerNorm folded into the GEMMs around it (posenet.hip).  A producer (bias+residual epilogue) writes
     // per-row partial sums of its OUTPUT, one (sum, sum of squares) pair per column tile: out_stats[m][tile_n][2].
     // A consumer whose normalised operand is LN(x) = (x - mu) rstd gamma + beta runs on the RAW x with

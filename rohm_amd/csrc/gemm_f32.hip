@@ -689,13 +689,15 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     lds += 2048;                           // landing zone of the dummy DMA pieces
     lds += 4 * BM * 2 * sizeof(float);     // row-stat exchange of the LayerNorm-producing epilogue
     // the split-bf16 variants WANT two workgroups per CU: one wave's plane splitting (VALU) runs under the other's MFMAs
-    if (lds < 84 * 1024 && !occ2 && VAR != 8 && VAR != 9) lds = 84 * 1024;
+    const size_t lds_need = lds;
+    if (lds < 84 * 1024 && !occ2 && VAR != 8 && VAR != 9 && p.wg_per_cu < 2) lds = 84 * 1024;
     static bool attr_set[64] = {};
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
+        const size_t lds_max = lds_need > 84 * 1024 ? lds_need : 84 * 1024;     // either residency of later launches
         ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_set[dev] = true;
     }
     static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv", "gemm_embed",

@@ -62,9 +62,14 @@ struct rohm_trajnet {
 namespace rohm {
 
 __device__ __forceinline__ float mishf(float x) {
-    // x * tanh(softplus(x)), softplus with torch's threshold 20 (model/heads.py:104, nn.Mish)
-    const float sp = (x > 20.f) ? x : log1pf(expf(x));
-    return x * tanhf(sp);
+    // x * tanh(softplus(x)), softplus with torch's threshold 20 (model/heads.py:104, nn.Mish).  With e = exp(x):
+    // tanh(log(1 + e)) = ((1 + e)^2 - 1) / ((1 + e)^2 + 1) = n / (n + 2), n = e (e + 2) -- one exp and one division instead
+    // of expf + log1pf + tanhf (~150 VALU instructions per value in the library form, the bulk of the GroupNorm
+    // kernel's time with one wave per SIMD); within 1 ulp of the library form over [-100, 100] (checked on the host).
+    const float e = __expf(fminf(x, 20.f));
+    const float n = e * (e + 2.f);
+    const float r = x * __fdividef(n, n + 2.f);
+    return (x > 20.f) ? x : r;
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -157,109 +162,160 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 
 // VEC: 16-byte accesses (every leading dimension a multiple of 4 floats, 16-byte aligned bases -- the layouts this
 // file builds); the scalar variant is the fallback for foreign strides.
+//
+// The kernel is a latency chain (B x 8 blocks, a few values per thread), so its memory round trips are what it costs:
+// EVERY load the block needs -- the conv output or its split-K slabs (8 slabs in flight per unit, summed in slab order),
+// the residual or ITS slabs, gamma / beta / time bias / control residual -- is issued before the first reduction, and the
+// statistics are computed while the epilogue operands are still in flight.
 template <bool VEC>
 __global__ __launch_bounds__(256) void gn_mish_kernel(GnArgs a) {
     constexpr int W = VEC ? 4 : 1;                  // floats per unit
     constexpr int NU = VEC ? kGnVecPerThread : kGnMaxPerThread;   // units per thread (unused ones are predicated off)
+    constexpr int SB = VEC ? 8 : 2;                 // slabs in flight per unit
     const int b = blockIdx.x, g = blockIdx.y;
     const int cg = a.C >> 3;                        // channels per group: a power of two (4 .. 64)
     const int ug = cg / W;                          // units per row of the group
     const int sh_ug = 31 - __clz(ug);
     const int n = cg * a.T, nu = n / W;
     __shared__ float sh[4];
-    float v[NU][W];
-    float s = 0.f;
     auto ldv = [&](const float* p, float* o) {
         if constexpr (VEC) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
         else o[0] = *p;
     };
+    auto active = [&](int k) { return (int)threadIdx.x + k * 256 < nu; };
+    auto unit_col = [&](int k) { return g * cg + (((int)threadIdx.x + k * 256) & (ug - 1)) * W; };
+    auto unit_row = [&](int k) { return (size_t)b * a.T + (((int)threadIdx.x + k * 256) >> sh_ug); };
+
+    // ---- phase 1: all loads ------------------------------------------------------------------------------------------
+    float v[NU][W];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-        const int i = threadIdx.x + k * 256;
 #pragma unroll
         for (int e = 0; e < W; ++e) v[k][e] = 0.f;
-        if (i < nu) {
-            const int t = i >> sh_ug, c = g * cg + (i & (ug - 1)) * W;
-            const float* p = a.y + ((size_t)b * a.T + t) * a.ldy + c;
-            ldv(p, v[k]);
-            if (a.ksplit > 1) {                     // fixed summation order (deterministic); 4 slabs in flight
-                int sp = 1;
-                for (; sp + 3 < a.ksplit; sp += 4) {
-                    float t0[W], t1[W], t2[W], t3[W];
-                    ldv(p + (size_t)sp * a.slab, t0);
-                    ldv(p + (size_t)(sp + 1) * a.slab, t1);
-                    ldv(p + (size_t)(sp + 2) * a.slab, t2);
-                    ldv(p + (size_t)(sp + 3) * a.slab, t3);
+        if (active(k)) ldv(a.y + unit_row(k) * a.ldy + unit_col(k), v[k]);
+    }
+    if (a.ksplit > 1) {       // v = ((((slab 0 + slab 1) + slab 2) + ...) + bias: fixed order, deterministic
+        for (int sp = 1; sp < a.ksplit; sp += SB) {
+            float t[NU][SB][W];
 #pragma unroll
-                    for (int e = 0; e < W; ++e) v[k][e] = (((v[k][e] + t0[e]) + t1[e]) + t2[e]) + t3[e];
-                }
-                for (; sp < a.ksplit; ++sp) {
-                    float t0[W];
-                    ldv(p + (size_t)sp * a.slab, t0);
+            for (int k = 0; k < NU; ++k)
+                if (active(k)) {
+                    const float* p = a.y + unit_row(k) * a.ldy + unit_col(k);
 #pragma unroll
-                    for (int e = 0; e < W; ++e) v[k][e] += t0[e];
+                    for (int j = 0; j < SB; ++j) {     // past the last slab: re-read it (an L2 hit), weight 0
+                        const int sj = (sp + j < a.ksplit) ? sp + j : a.ksplit - 1;
+                        ldv(p + (size_t)sj * a.slab, t[k][j]);
+                    }
                 }
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+                if (active(k)) {
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) {
+                        const bool ok = sp + j < a.ksplit;
+#pragma unroll
+                        for (int e = 0; e < W; ++e) v[k][e] += ok ? t[k][j][e] : 0.f;
+                    }
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+            if (active(k)) {
                 float cb[W];
-                ldv(a.cbias + c, cb);
+                ldv(a.cbias + unit_col(k), cb);
 #pragma unroll
                 for (int e = 0; e < W; ++e) v[k][e] += cb[e];
             }
+    }
+    // epilogue operands: issued now, consumed after the two reductions
+    float ga[NU][W], be[NU][W], tbv[NU][W], rr[NU][W], a2[NU][W];
 #pragma unroll
-            for (int e = 0; e < W; ++e) s += v[k][e];
+    for (int k = 0; k < NU; ++k) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) { ga[k][e] = 0.f; be[k][e] = 0.f; tbv[k][e] = 0.f; rr[k][e] = 0.f; a2[k][e] = 0.f; }
+        if (active(k)) {
+            const int c = unit_col(k);
+            ldv(a.gamma + c, ga[k]);
+            ldv(a.beta + c, be[k]);
+            if (a.tb) ldv(a.tb + (size_t)(a.ldtb ? b : 0) * a.ldtb + c, tbv[k]);
+            if (a.res) ldv(a.res + unit_row(k) * a.ldres + c, rr[k]);
+            if (a.add2) ldv(a.add2 + unit_row(k) * a.ldadd2 + c, a2[k]);
         }
     }
+    if (a.res && a.res_ksplit > 1) {          // residual = 1x1 conv left as split-K slabs: same fixed-order sum + its bias
+        constexpr int SR = VEC ? 4 : 2;
+        for (int sp = 1; sp < a.res_ksplit; sp += SR) {
+            float t[NU][SR][W];
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+                if (active(k)) {
+                    const float* p = a.res + unit_row(k) * a.ldres + unit_col(k);
+#pragma unroll
+                    for (int j = 0; j < SR; ++j) {
+                        const int sj = (sp + j < a.res_ksplit) ? sp + j : a.res_ksplit - 1;
+                        ldv(p + (size_t)sj * a.res_slab, t[k][j]);
+                    }
+                }
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+                if (active(k)) {
+#pragma unroll
+                    for (int j = 0; j < SR; ++j) {
+                        const bool ok = sp + j < a.res_ksplit;
+#pragma unroll
+                        for (int e = 0; e < W; ++e) rr[k][e] += ok ? t[k][j][e] : 0.f;
+                    }
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+            if (active(k)) {
+                float x[W];
+                ldv(a.res_bias + unit_col(k), x);
+#pragma unroll
+                for (int e = 0; e < W; ++e) rr[k][e] += x[e];
+            }
+    }
+
+    // ---- phase 2: statistics (two-pass: mean, then the centred sum of squares; biased variance) ------------------------
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+        if (active(k))
+#pragma unroll
+            for (int e = 0; e < W; ++e) s += v[k][e];
     const float mean = block_sum_256(s, sh) / (float)n;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < NU; ++k)
-        if (threadIdx.x + k * 256 < nu)
+        if (active(k))
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 const float d = v[k][e] - mean;
                 q += d * d;
             }
     const float rstd = 1.0f / sqrtf(block_sum_256(q, sh) / (float)n + 1e-5f);
+
+    // ---- phase 3: normalise, Mish, (+ time bias) (+ residual) (+ control residual), store -------------------------------
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-        const int i = threadIdx.x + k * 256;
-        if (i >= nu) continue;
-        const int t = i >> sh_ug, c = g * cg + (i & (ug - 1)) * W;
-        const size_t row = (size_t)b * a.T + t;
-        float ga[W], be[W], o[W];
-        ldv(a.gamma + c, ga);
-        ldv(a.beta + c, be);
+        if (!active(k)) continue;
+        const int c = unit_col(k);
+        const size_t row = unit_row(k);
+        float o[W];
 #pragma unroll
-        for (int e = 0; e < W; ++e) o[e] = mishf((v[k][e] - mean) * rstd * ga[e] + be[e]);
+        for (int e = 0; e < W; ++e) o[e] = mishf((v[k][e] - mean) * rstd * ga[k][e] + be[k][e]);
         if (a.tb) {
-            float x[W];
-            ldv(a.tb + (size_t)(a.ldtb ? b : 0) * a.ldtb + c, x);
 #pragma unroll
-            for (int e = 0; e < W; ++e) o[e] += x[e];
+            for (int e = 0; e < W; ++e) o[e] += tbv[k][e];
         }
         if (a.res) {
-            float r[W];
-            const float* rp = a.res + row * a.ldres + c;
-            ldv(rp, r);
-            if (a.res_ksplit > 1) {
-                for (int sp = 1; sp < a.res_ksplit; ++sp) {
-                    float x[W];
-                    ldv(rp + (size_t)sp * a.res_slab, x);
 #pragma unroll
-                    for (int e = 0; e < W; ++e) r[e] += x[e];
-                }
-                float x[W];
-                ldv(a.res_bias + c, x);
-#pragma unroll
-                for (int e = 0; e < W; ++e) r[e] += x[e];
-            }
-#pragma unroll
-            for (int e = 0; e < W; ++e) o[e] += r[e];
+            for (int e = 0; e < W; ++e) o[e] += rr[k][e];
         }
         if (a.add2) {
-            float x[W];
-            ldv(a.add2 + row * a.ldadd2 + c, x);
 #pragma unroll
-            for (int e = 0; e < W; ++e) o[e] += x[e];
+            for (int e = 0; e < W; ++e) o[e] += a2[k][e];
         }
         if constexpr (VEC) {
             *reinterpret_cast<f32x4*>(a.dst + row * a.lddst + c) = f32x4{o[0], o[1], o[2], o[3]};
@@ -275,6 +331,56 @@ __global__ __launch_bounds__(256) void gn_mish_kernel(GnArgs a) {
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] += b[i];
+}
+
+// The last three launches of a sampling-loop step as ONE: the head's Conv1d(32, c_traj, 1) (trajnet.py:158-161), the
+// ancestral update x_{t-1} = c1 x0 + c2 x_t + sigma noise (gaussian_diffusion_trajnet.py:440-466) and the zero-padded copy
+// of x_{t-1} that the next step's first convolution reads.  One thread per (row, channel); the per-step values are either
+// immediates or -- for the replayed hipGraph -- entries of device tables selected by the step counter.
+struct TailArgs {
+    const float* fin; int ldfin;         // final block output [M, ldfin]
+    const float* w; int ldw; int cin;    // head weight [c_traj, ldw] (cin <= 64 used columns), bias [c_traj]
+    const float* bias; int ctraj;
+    float* x;                            // [M, c_traj]: x_t in, x_{t-1} out
+    float* xin; int ldxin;               // padded copy [M, ldxin] (columns >= c_traj stay zero)
+    float* x0_out;                       // nullable: the head's output itself
+    const float* noise;                  // immediates: this step's noise (nullable)
+    float c1, c2, sigma;
+    const float* noise_base; const float* coef_tab; const int* step_ctr;   // tables (coef_tab != nullptr selects them)
+    size_t M;
+};
+__global__ __launch_bounds__(256) void traj_tail_kernel(TailArgs a) {
+    __shared__ float ws[32 * 65];
+    for (int i = threadIdx.x; i < a.ctraj * a.cin; i += 256) ws[(i / a.cin) * 65 + i % a.cin] = a.w[(size_t)(i / a.cin) * a.ldw + i % a.cin];
+    __syncthreads();
+    float c1 = a.c1, c2 = a.c2, sigma = a.sigma;
+    const float* noise = a.noise;
+    const size_t n = a.M * a.ctraj;
+    if (a.coef_tab) {
+        const int k = *a.step_ctr;
+        c1 = a.coef_tab[3 * k]; c2 = a.coef_tab[3 * k + 1]; sigma = a.coef_tab[3 * k + 2];
+        noise = a.noise_base ? a.noise_base + (size_t)k * n : nullptr;
+    }
+    if (sigma == 0.f) noise = nullptr;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t m = i / a.ctraj;
+        const int c = (int)(i - m * a.ctraj);
+        const float* f = a.fin + m * a.ldfin;
+        const float* wc = ws + c * 65;
+        float acc = 0.f;
+        for (int k = 0; k < a.cin; k += 4) {
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(f + k);
+            acc = fmaf(fv[0], wc[k], acc); acc = fmaf(fv[1], wc[k + 1], acc);
+            acc = fmaf(fv[2], wc[k + 2], acc); acc = fmaf(fv[3], wc[k + 3], acc);
+        }
+        const float x0 = acc + a.bias[c];
+        if (a.x0_out) a.x0_out[i] = x0;
+        float v = c1 * x0 + c2 * a.x[i];
+        if (noise) v += sigma * noise[i];
+        a.x[i] = v;
+        a.xin[m * a.ldxin + c] = v;
+    }
 }
 
 // ---- weight re-layout (create time) --------------------------------------------------------------------
@@ -320,16 +426,24 @@ static thread_local float* tl_splitk_res = nullptr;   // partial slabs of a bloc
 // A conv whose consumer is the GroupNorm kernel leaves its split-K slabs un-reduced; this says where they are.
 struct SplitInfo { int S = 1; size_t slab = 0; int ldp = 0; const float* base = nullptr; };
 
+// Launch shape of the latency-bound convolutions (rohm_trajnet_tune): workgroups per CU the conv GEMMs may occupy (a
+// 144 x 64 tile needs 60 KB of LDS, so two fit a CU; one is pinned by padding the LDS request) and the fewest K chunks a
+// split-K slice may get.
+static int g_conv_wg_per_cu = 1;
+static int g_split_min_chunks = 4;
+
 static void plan_split(GemmParams& g, float* buf = nullptr, SplitInfo* defer = nullptr) {
-    if (!buf) buf = tl_splitk;
-    if (!buf) return;
     const int tm = (g.M + 143) / 144;
     const int bn = (tm * ((g.N + 127) / 128) >= 256 && g.N % 128 == 0) ? 128 : 64;
     const int tiles = tm * ((g.N + bn - 1) / bn);
+    const int slots = 256 * g_conv_wg_per_cu;
+    g.wg_per_cu = (tiles <= slots) ? g_conv_wg_per_cu : 1;      // multi-round grids keep one workgroup per CU (gemm_f32.hip)
+    if (!buf) buf = tl_splitk;
+    if (!buf) return;
     const int nk = g.K / 32;
-    const int S = std::min(256 / tiles, nk / 4);
+    const int S = std::min(slots / tiles, nk / g_split_min_chunks);
     const int ldp = (g.N + 3) / 4 * 4;
-    if (tiles > 128 || S < 2 || (size_t)S * g.M * ldp > kSplitKFloats) return;
+    if (tiles > slots / 2 || S < 2 || (size_t)S * g.M * ldp > kSplitKFloats) return;
     g.ksplit = S; g.partial = buf; g.ld_partial = ldp;
     if (defer) {
         g.ksplit_defer = 1;
@@ -604,7 +718,27 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
     if ((rc = conv5(h, h->final_blk.conv, w.d[0], kPadC, B, T, w.sc.ya, 32, s, &sf))) return rc;
     if ((rc = gn(h->final_blk, w.sc.ya, 32, sf, B, T, nullptr, 0, nullptr, 0, none, nullptr, nullptr, 0, w.fin, kPadC, nullptr, 0, s)))
         return rc;
+    if (!out) return ROHM_OK;           // sampling loop: the head's 1x1 conv is part of traj_tail_kernel
     return conv1(h->final_conv, w.fin, kPadC, B * T, out, h->ctraj, s);
+}
+
+// head conv + DDPM update + padded copy of the new x (one launch, see traj_tail_kernel)
+static int run_tail(const rohm_trajnet* h, const TWs& w, float* x, float* x0_out, const float* noise, float c1, float c2,
+                    float sigma, const float* noise_base, const float* coef_tab, const int* step_ctr, size_t M,
+                    hipStream_t s) {
+    TailArgs a{};
+    a.fin = w.fin; a.ldfin = kPadC; a.w = h->final_conv.w; a.ldw = h->final_conv.cin_pad; a.cin = h->final_conv.cin;
+    a.bias = h->final_conv.b; a.ctraj = h->ctraj; a.x = x; a.xin = w.xin; a.ldxin = kPadC; a.x0_out = x0_out;
+    a.noise = noise; a.c1 = c1; a.c2 = c2; a.sigma = sigma; a.noise_base = noise_base; a.coef_tab = coef_tab;
+    a.step_ctr = step_ctr; a.M = M;
+    if (a.cin > 64 || a.cin % 4 != 0 || a.ctraj > 32) { set_error("trajnet: unsupported head shape"); return ROHM_ERR_UNSUPPORTED; }
+    const size_t n = M * h->ctraj;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    prof::Scope ps("traj_tail", 2.0 * n * a.cin, 4.0 * (M * a.cin + 4.0 * n), s);
+    hipLaunchKernelGGL(traj_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
 }
 
 static int run_time_path(const rohm_trajnet* h, const TWs& w, const int64_t* t_dev, int64_t t_host, int B,
@@ -664,13 +798,13 @@ static int sample_loop_graph(const rohm_trajnet* h, const TWs& w, float* x, cons
     ROHM_HIP_CHECK(hipMemsetAsync(w.step_ctr, 0, sizeof(int), gs));
     auto one_step = [&](hipStream_t s) -> int {
         int rc;
-        if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;
         if ((rc = run_time_path(h, w, nullptr, 0, B, s, w.step_t, w.step_ctr))) return rc;
-        if ((rc = run_denoiser(h, w, B, T, 0, w.x0, s))) return rc;
-        if ((rc = launch_ddpm_step_indexed(x, w.x0, noise, w.step_coef, w.step_ctr, x, n, s))) return rc;
+        if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s))) return rc;
+        if ((rc = run_tail(h, w, x, w.x0, nullptr, 0.f, 0.f, 0.f, noise, w.step_coef, w.step_ctr, M, s))) return rc;
         return launch_advance_counter(w.step_ctr, s);
     };
-    int rc = one_step(gs);                     // step 0 directly (also sets every kernel's launch attributes)
+    int rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, gs);     // x_T; afterwards the tail kernel keeps the padded copy current
+    if (!rc) rc = one_step(gs);                // step 0 directly (also sets every kernel's launch attributes)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool captured = false;
@@ -942,6 +1076,14 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
     return ROHM_OK;
 }
 
+int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks) {
+    ROHM_ARG_CHECK(conv_wg_per_cu >= 1 && conv_wg_per_cu <= 2 && split_min_chunks >= 1 && split_min_chunks <= 64,
+                   "trajnet_tune: conv_wg_per_cu must be 1 or 2, split_min_chunks 1..64");
+    g_conv_wg_per_cu = conv_wg_per_cu;
+    g_split_min_chunks = split_min_chunks;
+    return ROHM_OK;
+}
+
 void rohm_trajnet_destroy(rohm_trajnet_t* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
@@ -1015,10 +1157,10 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         if (rc != ROHM_ERR_UNSUPPORTED) return rc;
         // capture not available on this stream / runtime: fall through to the plain loop
     }
+    if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;     // x_T; the tail kernel keeps the padded copy current
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
-        if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;
         if (i % kTbSteps == 0) {
             // the time path depends on t only (trajnet.py:120-125, heads.py:35-38): one launch covers the next run of
             // steps (37 us per step before)
@@ -1030,9 +1172,10 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
                                h->tb_total, w.tb_steps);
             ROHM_LAUNCH_CHECK();
         }
-        float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
-        if ((rc = run_denoiser(h, w, B, T, 0, x0, s, w.tb_steps + (size_t)(i % kTbSteps) * h->tb_total))) return rc;
-        if ((rc = launch_ddpm_step(x, x0, noise ? noise + (size_t)i * n : nullptr, nullptr, c1, c2, sigma, 0.f, x, n, s)))
+        if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s, w.tb_steps + (size_t)(i % kTbSteps) * h->tb_total))) return rc;
+        // head conv + ancestral update + padded copy for the next step: one launch (three before)
+        if ((rc = run_tail(h, w, x, (x0_last && i == n_steps - 1) ? x0_last : nullptr, noise ? noise + (size_t)i * n : nullptr,
+                           c1, c2, sigma, nullptr, nullptr, nullptr, M, s)))
             return rc;
     }
     return ROHM_OK;

@@ -22,7 +22,37 @@ class Args:
     noise_schedule, sigma_small = 'cosine', True
 
 
+def sweep():
+    """Wall time of the 100-step loop over the conv launch shapes of rohm_trajnet_tune (workgroups per CU x fewest K
+    chunks per split-K slice); usage: python scripts/bench_trajnet.py --sweep [B ...]"""
+    dev = torch.device('cuda', 0)
+    batches = tuple(int(a) for a in sys.argv[2:]) or (1, 32)
+    res = {}
+    for ctrl in (False, True):
+        net = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=ctrl, device=dev)
+        net.load_state_dict(synth.trajnet_state_dict(1, trajcontrol=ctrl), strict=True)
+        net = net.to(dev).eval()
+        diff = create_gaussian_diffusion(Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev)
+        for B in batches:
+            batch = {'cond': torch.randn(B, 144, 13, device=dev), 'control_cond': torch.randn(B, 144, 272, device=dev)}
+            run = lambda: diff.eval_losses(model=net, batch=batch, shape=[B, 144, 13], progress=False, clip_denoised=False,
+                                           timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+            for wg, mc in ((1, 4), (1, 3), (1, 2), (2, 4), (2, 3), (2, 2), (2, 1)):
+                _lib.check(_lib.lib().rohm_trajnet_tune(wg, mc), 'rohm_trajnet_tune')
+                run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    run()
+                torch.cuda.synchronize()
+                res[f'{"control" if ctrl else "vanilla"}_B{B}_wg{wg}_minchunks{mc}'] = round((time.perf_counter() - t0) / 4 * 1e3, 2)
+    _lib.check(_lib.lib().rohm_trajnet_tune(1, 4), 'rohm_trajnet_tune')
+    print(json.dumps(res, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--sweep':
+        return sweep()
     dev = torch.device('cuda', 0)
     res = {}
     for ctrl in (False, True):
