@@ -57,6 +57,9 @@ typedef struct {
 } rohm_profile_row;
 int rohm_profile_start(int step_stride);
 int rohm_profile_stop(rohm_profile_row* rows, int max_rows, int* n_rows);
+/* on != 0: GEMM / conv-GEMM / GroupNorm launches are recorded under a label that carries their shape ("conv_gemm/64 M576
+ * N512 K2560 S8"), one row per distinct shape -- per-launch-shape timing of the TrajNet step (scripts/bench_trajnet.py). */
+int rohm_profile_detail(int on);
 
 /* ------------------------------------------------------------------ building blocks
  * Exposed so that each kernel can be parity-tested and profiled on its own.        */
@@ -175,9 +178,10 @@ void rohm_trajnet_destroy(rohm_trajnet_t* h);
 size_t rohm_trajnet_workspace_bytes(const rohm_trajnet_t* h, int B, int T);
 /* Launch shape of TrajNet's latency-bound convolutions (process-wide; no counterpart in the reference, whose convs are
  * torch's): conv_wg_per_cu = workgroups of a conv GEMM that may share a CU (1 or 2; a 144x64 tile needs 60 KB of the 160 KB
- * LDS), split_min_chunks = fewest 32-wide K chunks a split-K slice may get.  Results do not depend on either beyond the
- * fp32 summation order of split-K.  The defaults are the measured optimum on MI355X. */
-int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks);
+ * LDS), split_min_chunks = fewest 32-wide K chunks a split-K slice may get, split_pow2 != 0 rounds split counts down to
+ * powers of two (workgroup b computes split b % S and runs on XCD b % 8: with S a power of two an XCD's L2 holds only its
+ * own K slices of the weights).  Results do not depend on them beyond the fp32 summation order of split-K.  The defaults are the measured optimum on MI355X. */
+int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks, int split_pow2);
 
 /* TrajNet.forward (model/trajnet.py:177-275): x_t, cond [B, T, c_traj], control_cond [B, T, c_ctrl] (NULL
  * without TrajControl), t int64[B] -> x0_out [B, T, c_traj].  T must be a multiple of 16. */

@@ -56,6 +56,7 @@ SIGNATURES = {
     'rohm_version': (C.c_int, []),
     'rohm_profile_start': (C.c_int, [C.c_int]),
     'rohm_profile_stop': (C.c_int, [C.POINTER(ProfileRow), C.c_int, C.POINTER(C.c_int)]),
+    'rohm_profile_detail': (C.c_int, [C.c_int]),
     'rohm_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'rohm_layernorm_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -77,7 +78,7 @@ SIGNATURES = {
     'rohm_trajnet_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(TrajNetWeights), C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int]),
     'rohm_trajnet_destroy': (None, [C.c_void_p]),
-    'rohm_trajnet_tune': (C.c_int, [C.c_int, C.c_int]),
+    'rohm_trajnet_tune': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'rohm_trajnet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'rohm_trajnet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -165,8 +166,8 @@ def profile_start(step_stride=1):
 
 def profile_stop():
     """-> {label: dict(launches, total_ms, flops, bytes)} measured with HIP events on the launch stream."""
-    rows = (ProfileRow * 64)()
+    rows = (ProfileRow * 256)()
     n = C.c_int(0)
-    check(lib().rohm_profile_stop(rows, 64, C.byref(n)), 'rohm_profile_stop')
+    check(lib().rohm_profile_stop(rows, 256, C.byref(n)), 'rohm_profile_stop')
     return {rows[i].name.decode(): dict(launches=int(rows[i].launches), total_ms=rows[i].total_ms,
                                         flops=rows[i].flops, bytes=rows[i].bytes) for i in range(n.value)}

@@ -43,6 +43,15 @@ Scope::~Scope() {
 }
 void set_step(int step) { g_active = g_enabled && (step % g_stride == 0); }
 bool enabled() { return g_enabled; }
+static bool g_detail = false;
+bool detail() { return g_detail && g_active; }
+const char* intern(const char* s) {        // stable storage for labels composed at launch time (detail mode only)
+    static std::vector<std::string*> pool;
+    for (std::string* q : pool)
+        if (*q == s) return q->c_str();
+    pool.push_back(new std::string(s));
+    return pool.back()->c_str();
+}
 }  // namespace prof
 }  // namespace rohm
 
@@ -54,6 +63,11 @@ int rohm_profile_start(int step_stride) {
     prof::g_enabled = true;
     prof::g_stride = step_stride > 0 ? step_stride : 1;
     prof::g_active = true;
+    return ROHM_OK;
+}
+
+int rohm_profile_detail(int on) {
+    prof::g_detail = on != 0;
     return ROHM_OK;
 }
 

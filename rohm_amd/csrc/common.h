@@ -51,6 +51,8 @@ struct Scope {
 };
 void set_step(int step);       // sample loops call this; activates every `stride`-th step
 bool enabled();                // between rohm_profile_start and rohm_profile_stop
+bool detail();                 // rohm_profile_detail(1): GEMM / GroupNorm launches are labelled with their shape
+const char* intern(const char* s);
 }  // namespace prof
 
 constexpr int kNumXCD = 8;

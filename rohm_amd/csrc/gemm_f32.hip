@@ -705,6 +705,11 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64",
                                            "gemm_embed/64", "gemm_out_t/64"};
     const char* label = CONV ? (BN == 64 ? "conv_gemm/64" : "conv_gemm") : (BN == 64 ? kNames64[EPI] : kNames[EPI]);
+    if (prof::detail()) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), "%s M%d N%d K%d S%d", label, p.M, p.N, p.K, ksplit);
+        label = prof::intern(buf);
+    }
     {
     prof::Scope ps(label, 2.0 * p.M * p.N * p.K, 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N), s);
     hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);

@@ -430,7 +430,8 @@ struct SplitInfo { int S = 1; size_t slab = 0; int ldp = 0; const float* base = 
 // 144 x 64 tile needs 60 KB of LDS, so two fit a CU; one is pinned by padding the LDS request) and the fewest K chunks a
 // split-K slice may get.
 static int g_conv_wg_per_cu = 1;
-static int g_split_min_chunks = 4;
+static int g_split_min_chunks = 2;      // measured: B = 32 loop 69.0 ms at 4, 66.7 at 2; B = 1 54.1 / 49.6
+static int g_split_pow2 = 0;      // 1: split counts are powers of two, so that split = block % S stays tied to XCD = block % 8
 
 static void plan_split(GemmParams& g, float* buf = nullptr, SplitInfo* defer = nullptr) {
     const int tm = (g.M + 143) / 144;
@@ -441,7 +442,8 @@ static void plan_split(GemmParams& g, float* buf = nullptr, SplitInfo* defer = n
     if (!buf) buf = tl_splitk;
     if (!buf) return;
     const int nk = g.K / 32;
-    const int S = std::min(slots / tiles, nk / g_split_min_chunks);
+    int S = std::min(slots / tiles, nk / g_split_min_chunks);
+    if (g_split_pow2 && S > 1) S = 1 << (31 - __builtin_clz((unsigned)S));
     const int ldp = (g.N + 3) / 4 * 4;
     if (tiles > slots / 2 || S < 2 || (size_t)S * g.M * ldp > kSplitKFloats) return;
     g.ksplit = S; g.partial = buf; g.ld_partial = ldp;
@@ -521,7 +523,13 @@ static int gn(const BlockW& bw, const float* y, int ldy, const SplitInfo& sy, in
     const bool vec = ok4(a.y, a.ldy) && ok4(a.y, (long)(a.slab % 4)) && ok4(a.res, a.ldres) && ok4(a.res, (long)(a.res_slab % 4)) &&
                      ok4(a.add2, a.ldadd2) && ok4(a.dst, a.lddst) && ok4(a.dst2, a.lddst2) && ok4(a.tb, a.ldtb) &&
                      ok4(a.gamma, 0) && ok4(a.beta, 0) && ok4(a.cbias, 0) && ok4(a.res_bias, 0) && (a.C >> 3) % 4 == 0;
-    prof::Scope ps("gn_mish", 0.0, 4.0 * B * T * bw.conv.cout * (2.0 + sy.S), s);
+    const char* label = "gn_mish";
+    if (prof::detail()) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), "gn_mish C%d T%d S%d R%d", bw.conv.cout, T, sy.S, res ? sr.S : 0);
+        label = prof::intern(buf);
+    }
+    prof::Scope ps(label, 0.0, 4.0 * B * T * bw.conv.cout * (2.0 + sy.S), s);
     if (vec) hipLaunchKernelGGL(gn_mish_kernel<true>, dim3(B, 8), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gn_mish_kernel<false>, dim3(B, 8), dim3(256), 0, s, a);
     ROHM_LAUNCH_CHECK();
@@ -1076,11 +1084,12 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
     return ROHM_OK;
 }
 
-int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks) {
+int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks, int split_pow2) {
     ROHM_ARG_CHECK(conv_wg_per_cu >= 1 && conv_wg_per_cu <= 2 && split_min_chunks >= 1 && split_min_chunks <= 64,
                    "trajnet_tune: conv_wg_per_cu must be 1 or 2, split_min_chunks 1..64");
     g_conv_wg_per_cu = conv_wg_per_cu;
     g_split_min_chunks = split_min_chunks;
+    g_split_pow2 = split_pow2 ? 1 : 0;
     return ROHM_OK;
 }
 

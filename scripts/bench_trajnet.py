@@ -22,6 +22,9 @@ class Args:
     noise_schedule, sigma_small = 'cosine', True
 
 
+DEFAULT_TUNE = (1, 2, 0)        # the library's defaults (rohm_trajnet_tune): workgroups per CU, min chunks per split, pow2 splits
+
+
 def sweep():
     """Wall time of the 100-step loop over the conv launch shapes of rohm_trajnet_tune (workgroups per CU x fewest K
     chunks per split-K slice); usage: python scripts/bench_trajnet.py --sweep [B ...]"""
@@ -37,22 +40,54 @@ def sweep():
             batch = {'cond': torch.randn(B, 144, 13, device=dev), 'control_cond': torch.randn(B, 144, 272, device=dev)}
             run = lambda: diff.eval_losses(model=net, batch=batch, shape=[B, 144, 13], progress=False, clip_denoised=False,
                                            timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
-            for wg, mc in ((1, 4), (1, 3), (1, 2), (2, 4), (2, 3), (2, 2), (2, 1)):
-                _lib.check(_lib.lib().rohm_trajnet_tune(wg, mc), 'rohm_trajnet_tune')
+            for wg, mc, p2 in ((1, 4, 0), (1, 2, 0), (1, 1, 0), (1, 4, 1), (1, 2, 1), (1, 1, 1), (2, 2, 1)):
+                _lib.check(_lib.lib().rohm_trajnet_tune(wg, mc, p2), 'rohm_trajnet_tune')
                 run()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(4):
                     run()
                 torch.cuda.synchronize()
-                res[f'{"control" if ctrl else "vanilla"}_B{B}_wg{wg}_minchunks{mc}'] = round((time.perf_counter() - t0) / 4 * 1e3, 2)
-    _lib.check(_lib.lib().rohm_trajnet_tune(1, 4), 'rohm_trajnet_tune')
+                res[f'{"control" if ctrl else "vanilla"}_B{B}_wg{wg}_minchunks{mc}_pow2{p2}'] = round((time.perf_counter() - t0) / 4 * 1e3, 2)
+    _lib.check(_lib.lib().rohm_trajnet_tune(*DEFAULT_TUNE), 'rohm_trajnet_tune')
     print(json.dumps(res, indent=1))
+
+
+def detail():
+    """Per-launch-shape event times of one vanilla 100-step loop (rohm_profile_detail): which convolutions / GroupNorms the
+    step's time sits in, and their fixed cost against their K-chunk count.  usage: bench_trajnet.py --detail B [wg mc pow2]"""
+    dev = torch.device('cuda', 0)
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    tune = tuple(int(a) for a in sys.argv[3:6]) if len(sys.argv) > 5 else DEFAULT_TUNE
+    net = TrajNet(time_dim=32, mid_dim=512, cond_dim=13, traj_feat_dim=13, trajcontrol=False, device=dev)
+    net.load_state_dict(synth.trajnet_state_dict(1, trajcontrol=False), strict=True)
+    net = net.to(dev).eval()
+    diff = create_gaussian_diffusion(Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev)
+    batch = {'cond': torch.randn(B, 144, 13, device=dev)}
+    run = lambda: diff.eval_losses(model=net, batch=batch, shape=[B, 144, 13], progress=False, clip_denoised=False,
+                                   timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+    _lib.check(_lib.lib().rohm_trajnet_tune(*tune), 'rohm_trajnet_tune')
+    run()
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().rohm_profile_detail(1), 'rohm_profile_detail')
+    _lib.profile_start(4)
+    run()
+    torch.cuda.synchronize()
+    prof = _lib.profile_stop()
+    _lib.check(_lib.lib().rohm_profile_detail(0), 'rohm_profile_detail')
+    _lib.check(_lib.lib().rohm_trajnet_tune(*DEFAULT_TUNE), 'rohm_trajnet_tune')
+    tot = sum(v['total_ms'] for v in prof.values())
+    print(f'# B={B} tune={tune}: per-shape HIP-event times (every 4th step), total {tot:.2f} ms of events')
+    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms']):
+        print(f"{k:48s} n={v['launches']:4d} avg_us={v['total_ms'] / v['launches'] * 1e3:7.2f} share={v['total_ms'] / tot:.3f} "
+              f"gflop={v['flops'] / max(v['launches'], 1) / 1e9:.3f}")
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--sweep':
         return sweep()
+    if len(sys.argv) > 1 and sys.argv[1] == '--detail':
+        return detail()
     dev = torch.device('cuda', 0)
     res = {}
     for ctrl in (False, True):
