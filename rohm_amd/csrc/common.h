@@ -97,7 +97,8 @@ struct GemmParams {
     // (zeros outside [0, conv_tin)); conv_taps == 0 means a plain GEMM.  The output row is
     // m*(orow_mul_m1 + 1) + orow_add (interleaved phases of a transposed convolution).
     int conv_taps, conv_cin_pad, conv_tin, conv_tq, conv_stride;
-    int conv_off[5];
+    int conv_off[5];             // tap offsets as the host states them; the kernel uses the progression below
+    int conv_off0, conv_dstep;   // conv_off[j] == conv_off0 + j * conv_dstep (launch_gemm checks)
     const float* zero_page;      // >= 128 B of zeros (source of padded taps)
     int orow_mul_m1, orow_add;
     // columns >= ncol_split land ncol_jump floats further (0 = off): the two stride phases of a transposed convolution

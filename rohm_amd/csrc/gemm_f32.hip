@@ -63,18 +63,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // compile-time repetition of sched_group_barrier triples (the builtin needs literal arguments)
-template <int I, int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID>
+// VAL > 0 (conv gather): the per-chunk address arithmetic of the gathered operand (VALU) is dealt out between the MFMA
+// groups as well -- left alone the scheduler hoists all of it in front of the half's first MFMA.
+template <int I, int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID, int VAL = 0>
 struct SchedGroups {
     static __device__ __forceinline__ void run() {
-        constexpr int kMfma = 0x008, kVmem = 0x010, kDsRead = 0x100;
+        constexpr int kValu = 0x002, kMfma = 0x008, kVmem = 0x010, kDsRead = 0x100;
         __builtin_amdgcn_sched_group_barrier(kMfma, MF, ID);
         __builtin_amdgcn_sched_group_barrier(kDsRead, DS_TOTAL / N + (I < DS_TOTAL % N ? 1 : 0), ID);
+        if constexpr (VAL > 0) __builtin_amdgcn_sched_group_barrier(kValu, VAL, ID);
         __builtin_amdgcn_sched_group_barrier(kVmem, VM_TOTAL / N + (I < VM_TOTAL % N ? 1 : 0), ID);
-        SchedGroups<I + 1, N, MF, DS_TOTAL, VM_TOTAL, ID>::run();
+        SchedGroups<I + 1, N, MF, DS_TOTAL, VM_TOTAL, ID, VAL>::run();
     }
 };
-template <int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID>
-struct SchedGroups<N, N, MF, DS_TOTAL, VM_TOTAL, ID> {
+template <int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID, int VAL>
+struct SchedGroups<N, N, MF, DS_TOTAL, VM_TOTAL, ID, VAL> {
     static __device__ __forceinline__ void run() {}
 };
 
@@ -163,7 +166,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     // ---- global -> LDS staging by LDS-DMA ---------------------------------------------------------------------
     const float* a_src[A_ITERS];
-    int a_b[A_ITERS], a_tq[A_ITERS], a_slot[A_ITERS];      // conv gather: clip, output frame, 16-B slot
+    // conv gather, per unit: the zero-page address of its 16-B slot, the distance from there to its row at tap offset 0,
+    // and tq * stride (for the in-clip test)
+    uintptr_t a_cdiff[A_ITERS], a_zero[A_ITERS];      // a_cdiff = (row address at tap offset 0) - (zero-page address)
+    int a_tqs[A_ITERS];
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
         const int u = tid + i * 256;
@@ -172,19 +178,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const int grow = (m0 + row < p.M) ? m0 + row : p.M - 1;
         a_src[i] = p.A + (size_t)grow * p.lda + slot * 4;
         if constexpr (CONV) {
-            a_b[i] = grow / p.conv_tq;
-            a_tq[i] = grow % p.conv_tq;
-            a_slot[i] = slot;
+            const int b = grow / p.conv_tq;
+            a_tqs[i] = (grow - b * p.conv_tq) * p.conv_stride;
+            a_zero[i] = (uintptr_t)(p.zero_page + slot * 4);
+            a_cdiff[i] = (uintptr_t)(p.A + ((size_t)b * p.conv_tin + a_tqs[i]) * p.lda + slot * 4) - a_zero[i];
         }
     }
     // conv gather: source pointer of unit i for the K chunk starting at k0 (a chunk never straddles taps because
-    // cin_pad is a multiple of 32); taps that fall outside the clip read a page of zeros.
+    // cin_pad is a multiple of 32); taps that fall outside the clip read a page of zeros.  Everything that depends on the
+    // chunk only (tap index, its row offset, the channel base) is wave-uniform scalar arithmetic (no table: an indexed
+    // kernel-argument load costs an s_waitcnt lgkmcnt(0) inside the loop), a unit adds that scalar byte offset to its
+    // precomputed distance, and the in-clip / zero-page choice is a masked blend of the two addresses: a branch here
+    // splits the loop body that sched_group_barrier interleaves (both happened: the gather's loop ran at ~1.5 us per
+    // chunk against 1.05 us of MFMA).
+    const int conv_cp = p.conv_cin_pad;
     auto conv_src = [&](int i, int k0) -> const float* {
-        const int j = k0 / p.conv_cin_pad, ci0 = k0 - j * p.conv_cin_pad;
-        const int tin = a_tq[i] * p.conv_stride + p.conv_off[j];
-        const bool ok = (tin >= 0) && (tin < p.conv_tin);
-        return ok ? p.A + ((size_t)a_b[i] * p.conv_tin + tin) * p.lda + ci0 + a_slot[i] * 4
-                  : p.zero_page + a_slot[i] * 4;
+        const int j = (k0 >= conv_cp) + (k0 >= 2 * conv_cp) + (k0 >= 3 * conv_cp) + (k0 >= 4 * conv_cp);
+        const int off = p.conv_off0 + j * p.conv_dstep;                       // tap offsets are an arithmetic progression
+        const long long d = ((long long)off * p.lda + (k0 - j * conv_cp)) * (long long)sizeof(float);
+        // blend through an opaque lane mask: written as a select, hipcc turns the choice back into an exec-masked branch
+        unsigned m32 = ((unsigned)(a_tqs[i] + off) < (unsigned)p.conv_tin) ? 0xffffffffu : 0u;
+        asm("" : "+v"(m32));
+        const uintptr_t m = ((uintptr_t)m32 << 32) | m32;
+        return reinterpret_cast<const float*>(a_zero[i] + ((a_cdiff[i] + (uintptr_t)d) & m));
     };
     const float* b_src[B_ITERS];
 #pragma unroll
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if constexpr (VAR != 5) {
             read_frags(f1, buf, 1);
             mma_half(f0);
-            SchedGroups<0, NG, MF, READS, 0, 0>::run();
+            SchedGroups<0, NG, MF, READS, 0, 0, CONV ? 6 : 0>::run();
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // chunk k+1 landed
             __syncthreads();
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             dma(buf, kn);
             read_frags(f0, buf ^ 1, 0);
             mma_half(f1);
-            SchedGroups<0, NG, MF, READS, PIECES, 1>::run();
+            SchedGroups<0, NG, MF, READS, PIECES, 1, CONV ? 6 : 0>::run();
             __builtin_amdgcn_sched_barrier(0);
         } else {
             mma_half(f0);
@@ -850,6 +866,8 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
                        "gemm: conv gather needs cin_pad %% 32 == 0 and K == taps * cin_pad");
         ROHM_ARG_CHECK(p.zero_page && p.conv_tq > 0 && p.conv_tin > 0 && p.M % p.conv_tq == 0,
                        "gemm: bad conv gather geometry");
+        for (int j = 0; j < p.conv_taps; ++j)
+            ROHM_ARG_CHECK(p.conv_off[j] == p.conv_off0 + j * p.conv_dstep, "gemm: conv tap offsets must be off0 + j * dstep");
     }
     switch (epi) {
         case EPI_BIAS: return launch_bn<EPI_BIAS>(p, s);

@@ -461,6 +461,7 @@ static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int 
     g.M = B * tq; g.N = w.cout; g.K = w.taps * w.cin_pad; g.bias = w.b;
     g.conv_taps = w.taps; g.conv_cin_pad = w.cin_pad; g.conv_tin = tin; g.conv_tq = tq; g.conv_stride = stride;
     for (int j = 0; j < w.taps; ++j) g.conv_off[j] = offs[j];
+    g.conv_off0 = offs[0]; g.conv_dstep = (w.taps > 1) ? offs[1] - offs[0] : 0;
     g.zero_page = h->zero_page; g.orow_mul_m1 = orow_mul - 1; g.orow_add = orow_add;
     g.ncol_split = ncol_split; g.ncol_jump = ncol_jump;
     plan_split(g, splitk_buf, defer);
