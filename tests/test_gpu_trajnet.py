@@ -151,3 +151,46 @@ def test_shape_errors_are_raised_before_the_c_abi():
         net({'x_t': x, 'cond': x, 'control_cond': torch.zeros(2, 143, 272, device=DEV)}, t)
     with pytest.raises(KeyError):
         net({'x_t': x, 'cond': x}, t)
+
+
+def test_launch_shape_knobs_change_nothing_but_the_summation_order():
+    """rohm_trajnet_tune (workgroups per CU, fewest K chunks per split-K slice, power-of-two split counts) only re-shapes
+    the conv launches: every setting must agree with the default to fp32 rounding of a differently ordered K sum."""
+    from rohm_amd import _lib
+    net, _ = make_trajnet(7, True)
+    batch = {'x_t': seeded(1, 3, 144, 13).to(DEV), 'cond': seeded(2, 3, 144, 13).to(DEV),
+             'control_cond': seeded(3, 3, 144, 272).to(DEV)}
+    t = torch.tensor([99, 42, 0], device=DEV)
+    ref = net(batch, t).clone()
+    try:
+        for cfg in ((1, 4, 0), (1, 1, 1), (2, 2, 0), (2, 3, 1)):
+            _lib.check(_lib.lib().rohm_trajnet_tune(*cfg), 'rohm_trajnet_tune')
+            assert max_abs(net(batch, t), ref) < 2e-5, cfg
+    finally:
+        _lib.check(_lib.lib().rohm_trajnet_tune(1, 2, 0), 'rohm_trajnet_tune')
+    assert torch.equal(net(batch, t), ref)          # back on the defaults: bit-identical again
+    assert _lib.lib().rohm_trajnet_tune(3, 2, 0) != 0 and _lib.lib().rohm_trajnet_tune(1, 0, 0) != 0
+
+
+def test_profile_detail_labels_carry_the_launch_shape():
+    from rohm_amd import _lib
+    net, _ = make_trajnet(7, False)
+    batch = {'x_t': seeded(1, 2, 144, 13).to(DEV), 'cond': seeded(2, 2, 144, 13).to(DEV)}
+    t = torch.tensor([5, 6], device=DEV)
+    net(batch, t)
+    _lib.check(_lib.lib().rohm_profile_detail(1), 'rohm_profile_detail')
+    try:
+        _lib.profile_start(1)
+        net(batch, t)
+        torch.cuda.synchronize()
+        rows = _lib.profile_stop()
+    finally:
+        _lib.check(_lib.lib().rohm_profile_detail(0), 'rohm_profile_detail')
+    convs = [k for k in rows if k.startswith('conv_gemm')]
+    assert convs and all(' M' in k and ' K' in k and ' S' in k for k in convs), rows.keys()
+    assert any(k.startswith('gn_mish C') for k in rows)
+    _lib.profile_start(1)
+    net(batch, t)
+    torch.cuda.synchronize()
+    plain = _lib.profile_stop()
+    assert 'conv_gemm/64' in plain and 'gn_mish' in plain          # detail off: one row per kernel again
