@@ -124,6 +124,27 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
+// split-bf16 GEMM of the opt-in precision ladder (gemm_planes.hip): fp32 products emulated with `nplane` = 3 (six bf16 MFMA
+// products, fp32-class accuracy) or 2 (three products, ~2^-16) bf16 planes per operand; whole 144 x 128 tiles only
+bool planes_gemm_applies(const GemmParams& p, int epi);
+int launch_gemm_planes(const GemmParams& p, int epi, int nplane, hipStream_t s);
+
+#ifdef __HIPCC__
+// erf-form GELU (activation="gelu", model/posenet.py:67; NOT the tanh approximation).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <=
+// 1.5e-7, i.e. at fp32 resolution of the 1 + erf term) -- branch-free, one rcp + one exp, ~3x cheaper than the
+// library erff in a 72-element-per-lane epilogue.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-z * z);      // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+#endif
 
 // ---- other kernels -----------------------------------------------------------------------
 int launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);

@@ -48,20 +48,6 @@ __device__ __forceinline__ int lds_off(int row, int slot) {   // float index ins
     return row * BK + ((slot ^ ((row >> 1) & 7)) << 2);
 }
 
-// erf-form GELU (activation="gelu", model/posenet.py:67; NOT the tanh approximation).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <=
-// 1.5e-7, i.e. at fp32 resolution of the 1 + erf term) -- branch-free, one rcp + one exp, ~3x cheaper than the
-// library erff in a 72-element-per-lane epilogue.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-z * z);      // erf(|x| / sqrt 2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
-
 // compile-time repetition of sched_group_barrier triples (the builtin needs literal arguments)
 // VAL > 0 (conv gather): the per-chunk address arithmetic of the gathered operand (VALU) is dealt out between the MFMA
 // groups as well -- left alone the scheduler hoists all of it in front of the half's first MFMA.
@@ -99,27 +85,6 @@ __device__ __forceinline__ void row_mu_rstd(const float* __restrict__ stats, int
     rstd = 1.0f / sqrtf(var + eps);
 }
 
-// ---- split-bf16 products (opt-in precision ladder) ----------------------------------------------------------
-// An fp32 value is cut into bf16 planes by repeated round-to-nearest: x = h + m + l (+ 2^-24 |x|), each remainder exact
-// in fp32.  Eight k-values of a lane (its two 16-byte fragments of a 32-wide K chunk) make one bf16x8 operand of
-// v_mfma_f32_16x16x32_bf16; both operands use the same lane -> k assignment, so the contraction is a permutation of the
-// chunk's 32 k-values.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <int NP>
-struct Planes { bf16x8 p[NP]; };
-template <int NP>
-__device__ __forceinline__ void split_planes(const f32x4& x0, const f32x4& x1, Planes<NP>& o) {
-    float r[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const __bf16 b = (__bf16)r[i];
-            o.p[pl][i] = b;
-            r[i] -= (float)b;
-        }
-}
-
 #ifndef ROHM_GEMM_MIXED
 #define ROHM_GEMM_MIXED 1
 #endif
@@ -128,10 +93,6 @@ template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int WN = BN / 4;             // columns per wave
     constexpr bool M32 = (WN >= 64) && (ROHM_GEMM_MIXED != 0);   // mixed 32x32x2 + 16x16x4 path
-    // VAR 8 / 9: split-bf16 products on v_mfma_f32_16x16x32_bf16 -- three planes and the six products of weight >= 2^-16
-    // (fp32-class accuracy), or two planes and three products (~2^-16).  Same staging, fragments and epilogues.
-    constexpr int NPLANE = (VAR == 8) ? 3 : (VAR == 9) ? 2 : 0;
-    static_assert(NPLANE == 0 || !M32, "the split-bf16 path uses the 16x16 fragment layout (BN <= 192)");
     constexpr int NCB = WN / 16;           // 16-wide column blocks per wave
     constexpr int NCB32 = WN / 32;         // 32-wide column blocks per wave (M32)
     constexpr int B_UNITS = BN * 8;
@@ -369,41 +330,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     read_frags(f0, 0, 0);
     constexpr int NG = READS;                       // one LDS read per scheduling group
     constexpr int MF = (MFMAS + NG - 1) / NG;       // MFMAs per group (the tail groups run dry, harmless)
-    if constexpr (NPLANE != 0) {
-        for (int kc = 0; kc < nk; ++kc) {
-            const int buf = kc & 1;
-            Frag g0, g1;
-            read_frags(g0, buf, 0);
-            read_frags(g1, buf, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __syncthreads();                                   // every wave has its fragments of `buf` in registers
-            if (kc + 2 < nk) dma(buf, kbase + (kc + 2) * BK);
-            Planes<NPLANE> pa[NRB], pb[NCB];
-#pragma unroll
-            for (int r = 0; r < NRB; ++r) split_planes<NPLANE>(g0.a[r], g1.a[r], pa[r]);
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) split_planes<NPLANE>(g0.b[c], g1.b[c], pb[c]);
-            // products by decreasing weight class: (h,h); (h,m), (m,h); [(m,m), (h,l), (l,h)]
-            constexpr int NPROD = (NPLANE == 3) ? 6 : 3;
-            constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};    // smallest terms first
-#pragma unroll
-            for (int r = 0; r < NRB; ++r)
-#pragma unroll
-                for (int c = 0; c < NCB; ++c)
-#pragma unroll
-                    for (int q = 6 - NPROD; q < 6; ++q) {
-                        if constexpr (SWAP)
-                            acc16[r * NCB + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb[c].p[ib[q]], pa[r].p[ia[q]],
-                                                                                         acc16[r * NCB + c], 0, 0, 0);
-                        else
-                            acc16[r * NCB + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[r].p[ia[q]], pb[c].p[ib[q]],
-                                                                                         acc16[r * NCB + c], 0, 0, 0);
-                    }
-            if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                   // chunk kc + 1 has landed for everyone
-        }
-    } else
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
         if constexpr (VAR != 5) {
@@ -704,9 +630,8 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + lds_pad;
     lds += 2048;                           // landing zone of the dummy DMA pieces
     lds += 4 * BM * 2 * sizeof(float);     // row-stat exchange of the LayerNorm-producing epilogue
-    // the split-bf16 variants WANT two workgroups per CU: one wave's plane splitting (VALU) runs under the other's MFMAs
     const size_t lds_need = lds;
-    if (lds < 84 * 1024 && !occ2 && VAR != 8 && VAR != 9 && p.wg_per_cu < 2) lds = 84 * 1024;
+    if (lds < 84 * 1024 && !occ2 && p.wg_per_cu < 2) lds = 84 * 1024;
     static bool attr_set[64] = {};
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
@@ -751,7 +676,7 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
     if (EPI == EPI_EMBED) full = full && (p.ldtab % 4 == 0) && (p.ldtab0 % 4 == 0) && al16(p.tab) && al16(p.tab0);
     if (EPI == EPI_QKV) full = full && (p.qcols % 4 == 0);
     full = full && al16(p.ln_c) && al16(p.r_gamma) && al16(p.r_beta);      // 16-byte loads of the LayerNorm vectors
-    if (EPI == EPI_OUT_T || (VAR != 0 && VAR != 7 && VAR != 8 && VAR != 9)) full = false;
+    if (EPI == EPI_OUT_T || (VAR != 0 && VAR != 7)) full = false;
     if (p.conv_taps > 0) {
         if constexpr (EPI == EPI_BIAS && VAR == 0 && BN <= 128) {
             return full ? launch_one<BN, EPI, 0, true, true>(p, s) : launch_one<BN, EPI, 0, false, true>(p, s);
@@ -761,7 +686,7 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
         }
     }
     if (full) {
-        if constexpr (EPI != EPI_OUT_T && (VAR == 0 || VAR >= 7)) return launch_one<BN, EPI, VAR, true>(p, s);
+        if constexpr (EPI != EPI_OUT_T && (VAR == 0 || VAR == 7)) return launch_one<BN, EPI, VAR, true>(p, s);
     }
     return launch_one<BN, EPI, VAR, false>(p, s);
 }
@@ -809,11 +734,9 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
         if (e && !strcmp(e, "bf16x3")) return 9;
         return 0;
     }();
-    if (prec && p.conv_taps == 0 && p.ksplit <= 1 && !p.out_stats && !p.ln_stats && !p.r_stats) {
-        const bool wide = (p.N % 128 == 0) && (tiles128 >= want);    // measured: 144x64 tiles lose more than co-residency gains
-        if (prec == 8) return wide ? launch_t<128, EPI, 8>(p, s) : launch_t<64, EPI, 8>(p, s);
-        return wide ? launch_t<128, EPI, 9>(p, s) : launch_t<64, EPI, 9>(p, s);
-    }
+    if (prec && EPI != EPI_OUT_T && p.conv_taps == 0 && p.ksplit <= 1 && !p.out_stats && !p.ln_stats && !p.r_stats &&
+        planes_gemm_applies(p, EPI))
+        return launch_gemm_planes(p, EPI, prec == 8 ? 3 : 2, s);
     // Tile width: minimise  rounds x (BN + per-tile overhead),  rounds = ceil(tiles / workgroup slots).  Wider
     // tiles move fewer LDS-DMA bytes and fragment reads per MFMA and amortise the per-chunk barrier, but only while
     // every CU still gets a tile.  B = 64: N = 1536 -> 144x384, 1024 -> x256, 512 -> x128 (256 tiles each);
