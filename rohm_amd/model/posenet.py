@@ -195,6 +195,8 @@ class PoseNet(nn.Module):
         c_c = cond.detach().to(torch.float32).contiguous()
         t_c = timesteps.to(torch.int64).contiguous()
         out = torch.empty_like(x_c)
+        if B == 0 or T == 0:            # an empty batch passes through like the reference's modules (nothing to launch)
+            return out
         ws = nat.workspace(B, T)
         check(lib().rohm_posenet_forward(nat.handle, ptr(x_c), ptr(c_c), ptr(t_c), ptr(out), B, T, ptr(ws),
                                          ws.numel(), stream_ptr(x_c.device)), 'rohm_posenet_forward')
@@ -224,6 +226,8 @@ class PoseNet(nn.Module):
                                       tuple(noise.shape[1:]) == tuple(x.shape)):
             raise ValueError(f'noise must be contiguous [>= {n}, {B}, {Cc}, 1, {T}], got {tuple(noise.shape)}')
         x0_last = torch.empty_like(x) if want_x0_last else None
+        if B == 0 or T == 0 or n == 0:
+            return x0_last
         ws = nat.workspace(B, T)
         check(lib().rohm_posenet_sample_loop(nat.handle, ptr(x), ptr(cond),
                                              t_arr.ctypes.data_as(_lib.c_int64_p),

@@ -221,6 +221,8 @@ class TrajNet(nn.Module):
         nat = self.native(x.device)
         t = time.to(torch.int64).contiguous()
         out = torch.empty_like(x)
+        if B == 0:                      # an empty batch passes through like the reference's modules (nothing to launch)
+            return out
         ws = nat.workspace(B, T)
         check(lib().rohm_trajnet_forward(nat.handle, ptr(x), ptr(c), ptr(ctrl), ptr(t), ptr(out), B, T, ptr(ws),
                                          ws.numel(), stream_ptr(x.device)), 'rohm_trajnet_forward')
@@ -243,6 +245,8 @@ class TrajNet(nn.Module):
         t_arr = np.ascontiguousarray(t_model, dtype=np.int64)
         c_arr = np.ascontiguousarray(coef, dtype=np.float32).reshape(-1)
         x0_last = torch.empty_like(x) if want_x0_last else None
+        if B == 0 or n == 0:
+            return x0_last
         ws = nat.workspace(B, T)
         check(lib().rohm_trajnet_sample_loop(nat.handle, ptr(x), ptr(cond), ptr(ctrl),
                                              t_arr.ctypes.data_as(_lib.c_int64_p),

@@ -291,3 +291,25 @@ def test_headline_batch_is_clip_independent_and_meets_the_reference_golden():
     assert err < 1e-3, err
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_empty_batch_passes_through():
+    """B = 0 (an empty shard of a ragged split): forward and the whole sampling run return empty tensors of the right shape,
+    as the reference's torch modules do, without touching the C ABI (which rejects B <= 0)."""
+    from test_gpu_trajnet import make_trajnet
+    from test_gpu_trajnet import make_diffusion as make_traj_diffusion
+    net, _ = make_posenet(3)
+    x = torch.zeros(0, 294, 1, 143, device=DEV)
+    y = net({'x_t': x, 'cond': x}, torch.zeros(0, dtype=torch.int64, device=DEV))
+    assert tuple(y.shape) == (0, 294, 1, 143)
+    diff = make_diffusion(1000)
+    _, y = diff.eval_losses(model=net, batch={'cond': x}, shape=[0, 294, 1, 143], progress=False, clip_denoised=False,
+                            timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
+    assert tuple(y.shape) == (0, 294, 1, 143)
+    tnet, _ = make_trajnet(3, False)
+    xt = torch.zeros(0, 144, 13, device=DEV)
+    assert tuple(tnet({'x_t': xt, 'cond': xt}, torch.zeros(0, dtype=torch.int64, device=DEV)).shape) == (0, 144, 13)
+    _, yt = make_traj_diffusion().eval_losses(model=tnet, batch={'cond': xt}, shape=[0, 144, 13], progress=False,
+                                             clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
+                                             compute_loss=False)
+    assert tuple(yt.shape) == (0, 144, 13)
