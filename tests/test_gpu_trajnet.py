@@ -194,3 +194,19 @@ def test_profile_detail_labels_carry_the_launch_shape():
     torch.cuda.synchronize()
     plain = _lib.profile_stop()
     assert 'conv_gemm/64' in plain and 'gn_mish' in plain          # detail off: one row per kernel again
+
+
+def test_large_batch_is_clip_independent():
+    """B = 512 reaches the launch shapes small batches never do (144 x 128 conv tiles, no split-K, the separate residual /
+    transposed-conv forms of compute-bound batches); clips are independent, so every 64-clip slice of the result must agree
+    with a 64-clip forward of the same inputs to fp32 rounding of a differently ordered K sum."""
+    net, _ = make_trajnet(9, True)
+    B = 512
+    x, c, cc = seeded(11, B, 144, 13).to(DEV), seeded(12, B, 144, 13).to(DEV), seeded(13, B, 144, 272).to(DEV)
+    t = torch.arange(B, device=DEV) % 100
+    y = net({'x_t': x, 'cond': c, 'control_cond': cc}, t)
+    assert torch.isfinite(y).all()
+    for lo in (0, 192, 448):
+        sl = slice(lo, lo + 64)
+        ys = net({'x_t': x[sl].contiguous(), 'cond': c[sl].contiguous(), 'control_cond': cc[sl].contiguous()}, t[sl].contiguous())
+        assert max_abs(y[sl], ys) < 2e-5, lo
