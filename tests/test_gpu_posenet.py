@@ -313,3 +313,19 @@ def test_empty_batch_passes_through():
                                              clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
                                              compute_loss=False)
     assert tuple(yt.shape) == (0, 144, 13)
+
+
+def test_large_batch_is_clip_independent():
+    """B = 256 picks GEMM tile widths the smaller batches never reach (e.g. 144 x 256 for the N = 512 GEMMs, several rounds of
+    144 x 384 for QKV); clips are independent, so every 64-clip slice must agree with a 64-clip forward of the same inputs
+    (the K order of the fp32 MFMA chains does not depend on the tile width: agreement to the last few ulps)."""
+    net, _ = make_posenet(5)
+    B = 256
+    x, c = seeded(21, B, 294, 1, 143).to(DEV), seeded(22, B, 294, 1, 143).to(DEV)
+    t = (torch.arange(B, device=DEV) * 7) % 1000
+    y = net({'x_t': x, 'cond': c}, t)
+    assert torch.isfinite(y).all()
+    for lo in (0, 64, 192):
+        sl = slice(lo, lo + 64)
+        ys = net({'x_t': x[sl].contiguous(), 'cond': c[sl].contiguous()}, t[sl].contiguous())
+        assert max_abs(y[sl], ys) < 2e-5, lo
