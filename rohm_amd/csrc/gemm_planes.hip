@@ -10,7 +10,8 @@
 //
 // Planes by TRUNCATION: h = the upper 16 bits of x, m = the upper 16 bits of x - h, l = x - h - m.  Every remainder is
 // exact in fp32, h and m carry 8 significant bits each and the last remainder has at most 8 left, so x = h + m + l holds
-// EXACTLY (two planes: x = h + m up to 2^-16 |x|).  Per value: and, sub, and, sub on the VALU plus half a v_perm_b32 per
+// EXACTLY for every |x| >= 2^-100 (below that the remainders are denormal; tests/test_precision_ladder_arith.py) (two
+// planes: x = h + m up to 2^-15 |x|).  Per value: and, sub, and, sub on the VALU plus half a v_perm_b32 per
 // plane to pack two bf16 into a dword.
 //
 // Design.  The operands arrive as fp32 (4 B per element for an MFMA that takes a quarter of the fp32 MFMA's time), so per

@@ -1,0 +1,56 @@
+"""CPU check of the arithmetic behind the opt-in split-bf16 GEMM (rohm_amd/csrc/gemm_planes.hip): the truncation planes
+h = upper 16 bits of x, m = upper 16 bits of (x - h), l = x - h - m reproduce x EXACTLY, every plane is a bf16 value, and
+the six (three) plane products kept by bf16x6 (bf16x3) leave an error of fp32-rounding size (~2^-16) on a dot product.
+The kernel's own results are held to the fp32 kernel's bars by tests/test_gpu_precision_ladder.py on the GPU."""
+import numpy as np
+
+
+def planes(x):
+    x = np.asarray(x, np.float32)
+    h = (x.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    r1 = (x - h).astype(np.float32)
+    m = (r1.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    l = (r1 - m).astype(np.float32)
+    return h, m, l
+
+
+def is_bf16(v):
+    return np.all((np.asarray(v, np.float32).view(np.uint32) & np.uint32(0xffff)) == 0)
+
+
+def test_three_truncation_planes_are_exact_and_bf16():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(200000), rng.standard_normal(1000) * 1e-25, rng.standard_normal(1000) * 1e30,
+                        [0.0, -0.0, 1.0, -1.0, 3.4e38]]).astype(np.float32)
+    h, m, l = planes(x)
+    assert is_bf16(h) and is_bf16(m) and is_bf16(l)
+    assert np.array_equal((h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64)).astype(np.float32), x)
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))
+    # (below ~2^-100 the remainders become denormal: the planes still sum to x, but l may need more than bf16's 8 bits --
+    # twenty orders of magnitude under anything the networks produce)
+    tiny = np.float32(4.6645464e-35)
+    th, tm, tl = planes(np.asarray([tiny]))
+    assert float(th[0]) + float(tm[0]) + float(tl[0]) == float(tiny)
+    # two planes: relative error of x - (h + m) below 2^-15 (8 + 8 significant bits kept, truncation)
+    nz = x != 0
+    assert np.max(np.abs(l[nz].astype(np.float64) / x[nz])) < 2.0 ** -15
+
+
+def test_six_products_are_fp32_class_three_are_2_pow_minus_16():
+    rng = np.random.default_rng(1)
+    K = 1024
+    a = rng.standard_normal((64, K)).astype(np.float32)
+    w = rng.standard_normal((64, K)).astype(np.float32)
+    exact = np.einsum('ik,jk->ij', a.astype(np.float64), w.astype(np.float64))
+    pa, pw = planes(a), planes(w)
+
+    def emu(pairs):        # every bf16 x bf16 product is exact in fp32; sums taken in float64 to isolate the truncation error
+        return sum(np.einsum('ik,jk->ij', pa[i].astype(np.float64), pw[j].astype(np.float64)) for i, j in pairs)
+    six = emu([(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)])
+    three = emu([(0, 0), (0, 1), (1, 0)])
+    scale = np.sqrt(K)     # size of a typical dot product of unit normals
+    fp32 = (a @ w.T).astype(np.float64)
+    e6, e3, e32 = np.abs(six - exact).max() / scale, np.abs(three - exact).max() / scale, np.abs(fp32 - exact).max() / scale
+    assert e6 < 2.0 ** -21, e6                 # dropped m.l + l.m + l.l ~ 2^-23 per product: below an fp32 GEMM's own rounding
+    assert e6 < 4 * max(e32, 2.0 ** -24)
+    assert 2.0 ** -22 < e3 < 2.0 ** -13, e3    # three products: ~2^-16 per product, summed over K
