@@ -86,6 +86,28 @@ int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, i
 int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, int n_tok, int head_dim,
                        rohm_stream_t stream);
 
+/* ---- opt-in precision ladder: split-bf16 GEMMs on bf16 PLANES of the fp32 operands ----
+ * The same Linears as rohm_gemm_f32 (model/posenet.py:63-69), each fp32 product a.w emulated by bf16 MFMA products of
+ * planes cut by TRUNCATION (x = h + m + l exactly; nplane = 3: six products, fp32-class accuracy; nplane = 2: three
+ * products, ~2^-16).  A plane tensor of X[rows][K] (rows % 16 == 0, K % 32 == 0) is rohm_planes_bytes(rows, K, nplane)
+ * bytes in the fragment-major layout of rohm_amd/csrc/planes.h; producers write it (LayerNorm, attention, the GELU GEMM)
+ * or rohm_planes_split cuts it from an fp32 matrix.  Never the default: rohm_posenet_create selects it only under
+ * ROHM_GEMM_PRECISION=bf16x6 | bf16x3. */
+size_t rohm_planes_bytes(int rows, int K, int nplane);
+int rohm_planes_split(const float* X, int ldx, int rows, int K, int nplane, void* planes, rohm_stream_t stream);
+/* C[M,N] = epi(A . W^T) from the planes of A [M][K] and W [N][K]; M % 144 == 0, N % 64 == 0, K % 32 == 0.
+ * epi: 0 = +bias, 1 = +bias, erf GELU, 2 = +bias +R, 3 = (+bias) * (n < qcols ? qscale : 1).  C (fp32, ldc) and / or
+ * Cp (planes of the result over [M][N]) receive the result.  flags bit 0: plane output through 8-byte stores. */
+int rohm_gemm_planes(const void* Ap, const void* Wp, float* C, int ldc, void* Cp, int M, int N, int K,
+                     const float* bias, const float* R, int ldr, int qcols, float qscale, int epi, int nplane,
+                     int flags, rohm_stream_t stream);
+/* rohm_layernorm_f32 that also writes the planes of its result (M % 16 == 0); the fp32 result is bit-identical. */
+int rohm_layernorm_planes_f32(float* x, const float* gamma, const float* beta, int M, int D, int nplane,
+                              void* planes, rohm_stream_t stream);
+/* rohm_attention_f32 (n_tok = 144, head_dim = 128 only) writing the planes of ctx instead of fp32 ctx. */
+int rohm_attention_planes_f32(const float* qkv, void* ctx_planes, int n_seq, int n_head, int nplane,
+                              rohm_stream_t stream);
+
 /* One DDPM ancestral update, elementwise over n floats:
  *   x_prev = c1*x0 + c2*x_t + guid_scale*guid_grad + sigma*noise
  * = q_posterior_mean_variance + p_sample[_with_grad]
@@ -136,6 +158,9 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
                         int d_ff, int n_layer, int c_in, int c_out, int traj_dim, int device);
 void rohm_posenet_destroy(rohm_posenet_t* h);
 size_t rohm_posenet_workspace_bytes(const rohm_posenet_t* h, int B, int T);
+/* 0: exact fp32 MFMA GEMMs (default); 3 / 2: the handle was created under ROHM_GEMM_PRECISION=bf16x6 / bf16x3 and runs
+ * the four Linears of every encoder layer (model/posenet.py:63-69) as split-bf16 GEMMs on planes. */
+int rohm_posenet_precision(const rohm_posenet_t* h);
 
 /* PoseNet.forward (model/posenet.py:75-96): x_t, cond [B, C_in, 1, T] contiguous, t int64[B]
  * -> x0_out [B, C_in, 1, T] (channels < traj_dim copied from cond, the C_out others predicted). */

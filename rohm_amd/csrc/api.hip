@@ -3,6 +3,7 @@
 #include <string.h>
 #include <vector>
 #include "common.h"
+#include "planes.h"
 
 namespace rohm {
 static thread_local std::string g_err;
@@ -124,6 +125,35 @@ int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, int 
                        rohm_stream_t stream) {
     ROHM_ARG_CHECK(qkv && ctx, "attention: null pointer");
     return launch_attention(qkv, ctx, n_seq, n_head, n_tok, head_dim, (hipStream_t)stream);
+}
+
+size_t rohm_planes_bytes(int rows, int K, int nplane) {
+    if (rows <= 0 || K <= 0 || nplane <= 0) return 0;
+    return plane_tensor_bytes(rows, K, nplane);
+}
+
+int rohm_planes_split(const float* X, int ldx, int rows, int K, int nplane, void* planes, rohm_stream_t stream) {
+    return launch_plane_split(X, ldx, rows, K, nplane, planes, (hipStream_t)stream);
+}
+
+int rohm_gemm_planes(const void* Ap, const void* Wp, float* C, int ldc, void* Cp, int M, int N, int K,
+                     const float* bias, const float* R, int ldr, int qcols, float qscale, int epi, int nplane,
+                     int flags, rohm_stream_t stream) {
+    PlaneGemmParams g{};
+    g.Ap = Ap; g.Wp = Wp; g.C = C; g.ldc = ldc; g.Cp = Cp; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.R = R; g.ldr = ldr; g.qcols = qcols; g.qscale = qscale; g.no_swap = flags & 1;
+    return launch_gemm_pp(g, epi, nplane, (hipStream_t)stream);
+}
+
+int rohm_layernorm_planes_f32(float* x, const float* gamma, const float* beta, int M, int D, int nplane,
+                              void* planes, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(x && gamma && beta && planes, "layernorm_planes: null pointer");
+    return launch_layernorm_planes(x, gamma, beta, M, D, nplane, planes, (hipStream_t)stream);
+}
+
+int rohm_attention_planes_f32(const float* qkv, void* ctx_planes, int n_seq, int n_head, int nplane,
+                              rohm_stream_t stream) {
+    return launch_attention_planes(qkv, ctx_planes, n_seq, n_head, nplane, (hipStream_t)stream);
 }
 
 int rohm_ddpm_step(const float* x_t, const float* x0, const float* noise, const float* guid_grad, float c1,

@@ -29,6 +29,7 @@
 //         with its own row maximum m_w and row sum l_w, computes O_w = P_w V over its keys, and the waves combine
 //         O = sum_w e^(m_w - M) O_w / sum_w e^(m_w - M) l_w through the (by then free) K buffer.
 #include "common.h"
+#include "planes.h"
 
 namespace rohm {
 
@@ -61,7 +62,11 @@ __device__ __forceinline__ void at_dma16(const float* src, float* lds_dst) {
 #define AT_STAMP(i)
 #endif
 
-template <int NW>
+// NPO = 0: ctx is the fp32 matrix [n_seq * 144][n_head * 128]; NPO = 2 / 3: ctx receives the bf16 PLANES of that matrix
+// instead (planes.h; the consumer is the out-projection of the split-bf16 path, gemm_pp.hip).  For plane output the P.V
+// MFMAs run with their operands exchanged (O^T = V^T P^T: the same products summed in the same order), which leaves a lane
+// with 16 CONSECUTIVE output columns of one query row -- two complete 16-byte units per plane, 256 contiguous bytes per 16 lanes.
+template <int NW, int NPO = 0>
 __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __restrict__ qkv,
                                                                 float* __restrict__ ctx, int n_head, int n_items,
                                                                 int split AT_TL_PARAM) {
@@ -308,6 +313,10 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
 
     // ---- P.V of the owned block ----------------------------------------------------------------------------------
     {
+        auto pv_mfma = [](float pval, float vval, const f32x4& c) {
+            if constexpr (NPO == 0) return __builtin_amdgcn_mfma_f32_16x16x4f32(pval, vval, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_16x16x4f32(vval, pval, c, 0, 0, 0);
+        };
         float* out = ctx + ((size_t)seq * AT_S + (q0 + wave) * 16) * D + head * AT_DH;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
 #pragma unroll
             for (int sp = 0; sp < 2 * AT_NB; ++sp) {
                 const int st = 2 * sp;
-                oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[st >> 2][st & 3], vf[sp & 1][0][0], oacc[0], 0, 0, 0);
+                oacc[0] = pv_mfma(sacc[st >> 2][st & 3], vf[sp & 1][0][0], oacc[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (sp + 1 < 2 * AT_NB) {
                     vf[(sp + 1) & 1][0] = vread(st + 2);
@@ -333,16 +342,27 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 1; m < 4; ++m)
-                    oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[st >> 2][st & 3], vf[sp & 1][0][m], oacc[m], 0, 0, 0);
+                    oacc[m] = pv_mfma(sacc[st >> 2][st & 3], vf[sp & 1][0][m], oacc[m]);
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    oacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(sacc[(st + 1) >> 2][(st + 1) & 3], vf[sp & 1][1][m], oacc[m], 0, 0, 0);
+                    oacc[m] = pv_mfma(sacc[(st + 1) >> 2][(st + 1) & 3], vf[sp & 1][1][m], oacc[m]);
             }
-            // oacc[m][r] = O[query 4g + r][d = 64 db + 4 li + m]
+            if constexpr (NPO == 0) {
+                // oacc[m][r] = O[query 4g + r][d = 64 db + 4 li + m]
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<f32x4*>(out + (size_t)(lg * 4 + r) * D + db * 64 + li * 4) =
-                    f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]};
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<f32x4*>(out + (size_t)(lg * 4 + r) * D + db * 64 + li * 4) =
+                        f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]};
+            } else {
+                // exchanged operands: oacc[m][r] = O[query li][d = 64 db + 16 g + 4 r + m]
+                const int row = seq * AT_S + (q0 + wave) * 16 + li;
+                const int kg0 = (head * AT_DH + db * 64 + lg * 16) >> 3;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    plane_store8<(NPO ? NPO : 2)>(reinterpret_cast<char*>(ctx), row, kg0 + h, D / 32,
+                                                  f32x4{oacc[0][2 * h], oacc[1][2 * h], oacc[2][2 * h], oacc[3][2 * h]},
+                                                  f32x4{oacc[0][2 * h + 1], oacc[1][2 * h + 1], oacc[2][2 * h + 1], oacc[3][2 * h + 1]});
+            }
         }
     }
     AT_STAMP(8);
@@ -375,7 +395,8 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
                 o[2] = fmaf(s, pv[2], o[2]);
                 o[3] = fmaf(s, pv[3], o[3]);
             }
-            *reinterpret_cast<f32x4*>(out + (size_t)q * D + c4 * 4) = o;
+            if constexpr (NPO == 0) *reinterpret_cast<f32x4*>(out + (size_t)q * D + c4 * 4) = o;
+            else plane_store4<(NPO ? NPO : 2)>(reinterpret_cast<char*>(ctx), seq * AT_S + (q0 + OWNED) * 16 + q, head * AT_DH + c4 * 4, D / 32, o);
         }
     }
     AT_STAMP(11);
@@ -498,15 +519,40 @@ static int launch_generic(const float* qkv, float* ctx, int n_seq, int n_head, i
     return ROHM_OK;
 }
 
-template <int NW>
+template <int NW, int NPO>
 static int set_lds_attr(int dev) {
     static bool attr_set[64] = {};
     if (dev < 64 && !attr_set[dev]) {
-        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel<NW>),
+        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel<NW, NPO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(AT_LDS_FLOATS * sizeof(float))));
         attr_set[dev] = true;
     }
+    return ROHM_OK;
+}
+
+// specialised shape (S = 144, d_h = 128); NPO = 0: fp32 ctx, 2 / 3: planes of ctx
+template <int NPO>
+static int launch_special(const float* qkv, float* ctx, int n_seq, int n_head, hipStream_t s) {
+    const size_t lds = AT_LDS_FLOATS * sizeof(float);
+    int dev = 0;
+    ROHM_HIP_CHECK(hipGetDevice(&dev));
+    const int items = n_seq * n_head;
+    // One 8-wave workgroup per item takes ~1.6x the time of a 4-wave half-item workgroup: split while the halves
+    // still fit the chip in fewer (weighted) rounds.
+    constexpr int kCUs = 256;
+    const int rounds_full = (items + kCUs - 1) / kCUs, rounds_split = (2 * items + kCUs - 1) / kCUs;
+    const bool split = 10 * rounds_split <= 16 * rounds_full;
+    prof::Scope ps("attention", 4.0 * AT_S * AT_S * AT_DH * (double)items, 4.0 * 4.0 * AT_S * AT_DH * (double)items, s);
+    if (split) {
+        if (int e = set_lds_attr<4, NPO>(dev)) return e;
+        const int grid = ((items + 7) / 8) * 16;
+        hipLaunchKernelGGL((attention_f32_kernel<4, NPO>), dim3(grid), dim3(256), lds, s, qkv, ctx, n_head, items, 1);
+    } else {
+        if (int e = set_lds_attr<8, NPO>(dev)) return e;
+        hipLaunchKernelGGL((attention_f32_kernel<8, NPO>), dim3(items), dim3(512), lds, s, qkv, ctx, n_head, items, 0);
+    }
+    ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
 
@@ -519,26 +565,15 @@ int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, int n_
         set_error("attention: head dim must be 64 or 128 (got %d)", head_dim);
         return ROHM_ERR_UNSUPPORTED;
     }
-    const size_t lds = AT_LDS_FLOATS * sizeof(float);
-    int dev = 0;
-    ROHM_HIP_CHECK(hipGetDevice(&dev));
-    const int items = n_seq * n_head;
-    // One 8-wave workgroup per item takes ~1.6x the time of a 4-wave half-item workgroup: split while the halves
-    // still fit the chip in fewer (weighted) rounds.
-    constexpr int kCUs = 256;
-    const int rounds_full = (items + kCUs - 1) / kCUs, rounds_split = (2 * items + kCUs - 1) / kCUs;
-    const bool split = 10 * rounds_split <= 16 * rounds_full;
-    prof::Scope ps("attention", 4.0 * AT_S * AT_S * AT_DH * (double)items, 4.0 * 4.0 * AT_S * AT_DH * (double)items, s);
-    if (split) {
-        if (int e = set_lds_attr<4>(dev)) return e;
-        const int grid = ((items + 7) / 8) * 16;
-        hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(grid), dim3(256), lds, s, qkv, ctx, n_head, items, 1);
-    } else {
-        if (int e = set_lds_attr<8>(dev)) return e;
-        hipLaunchKernelGGL(attention_f32_kernel<8>, dim3(items), dim3(512), lds, s, qkv, ctx, n_head, items, 0);
-    }
-    ROHM_LAUNCH_CHECK();
-    return ROHM_OK;
+    return launch_special<0>(qkv, ctx, n_seq, n_head, s);
+}
+
+int launch_attention_planes(const float* qkv, void* ctx_planes, int n_seq, int n_head, int nplane, hipStream_t s) {
+    ROHM_ARG_CHECK(n_seq > 0 && n_head > 0 && qkv && ctx_planes, "attention_planes: empty problem / null pointer");
+    ROHM_ARG_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx_planes % 16) == 0, "attention_planes: operands must be 16-byte aligned");
+    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "attention_planes: 2 or 3 planes");
+    return nplane == 3 ? launch_special<3>(qkv, (float*)ctx_planes, n_seq, n_head, s)
+                       : launch_special<2>(qkv, (float*)ctx_planes, n_seq, n_head, s);
 }
 #endif  // AT_TIMELINE
 

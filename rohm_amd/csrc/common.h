@@ -124,11 +124,6 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
-// split-bf16 GEMM of the opt-in precision ladder (gemm_planes.hip): fp32 products emulated with `nplane` = 3 (six bf16 MFMA
-// products, fp32-class accuracy) or 2 (three products, ~2^-16) bf16 planes per operand; whole 144 x 128 tiles only
-bool planes_gemm_applies(const GemmParams& p, int epi);
-int launch_gemm_planes(const GemmParams& p, int epi, int nplane, hipStream_t s);
-
 #ifdef __HIPCC__
 // erf-form GELU (activation="gelu", model/posenet.py:67; NOT the tanh approximation).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <=
 // 1.5e-7, i.e. at fp32 resolution of the 1 + erf term) -- branch-free, one rcp + one exp, ~3x cheaper than the

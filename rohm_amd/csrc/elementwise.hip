@@ -1,6 +1,7 @@
 // Bandwidth-bound helpers of the PoseNet step: LayerNorm, layout pack, timestep token, DDPM update.
 // All are vectorised to 16 B per lane and sized so that >> 256 workgroups are in flight.
 #include "common.h"
+#include "planes.h"
 
 namespace rohm {
 
@@ -55,6 +56,87 @@ int launch_layernorm(float* x, const float* g, const float* b, int M, int D, hip
     else if (D == 256) hipLaunchKernelGGL(layernorm_kernel<256>, grid, block, 0, s, x, g, b, M);
     else if (D == 1024) hipLaunchKernelGGL(layernorm_kernel<1024>, grid, block, 0, s, x, g, b, M);
     else { set_error("layernorm: unsupported D=%d", D); return ROHM_ERR_UNSUPPORTED; }
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+// LayerNorm that also hands the consuming GEMM the bf16 planes of its result (precision ladder, planes.h).  A workgroup is
+// one 16-row block: wave w normalises rows 4 w .. 4 w + 3 exactly as layernorm_kernel does (same arithmetic, same order ->
+// the fp32 result is bit-identical), writes them back and parks them in LDS; then every thread cuts 16-byte units
+// (8 consecutive k of one row) in fragment order, so each plane store instruction writes 1 KiB contiguous.
+template <int D, int NP>
+__global__ __launch_bounds__(256) void layernorm_planes_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                               const float* __restrict__ b, char* __restrict__ planes) {
+    constexpr int V = D / 256;        // float4 per lane
+    constexpr int LD = D + 4;         // LDS row stride (floats)
+    __shared__ __attribute__((aligned(16))) float tile[16 * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 gg[V], bb[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        gg[i] = *reinterpret_cast<const f32x4*>(g + (i * 64 + lane) * 4);
+        bb[i] = *reinterpret_cast<const f32x4*>(b + (i * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lr = wave * 4 + r;
+        float* xr = x + ((size_t)blockIdx.x * 16 + lr) * D;
+        f32x4 v[V];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * gg[i][j] + bb[i][j];
+            *reinterpret_cast<f32x4*>(xr + (i * 64 + lane) * 4) = o;
+            *reinterpret_cast<f32x4*>(tile + lr * LD + (i * 64 + lane) * 4) = o;
+        }
+    }
+    __syncthreads();
+    constexpr int UNITS = 16 * (D / 8);
+#pragma unroll
+    for (int u = threadIdx.x; u < UNITS; u += 256) {
+        const int i = u & 15, kg = u >> 4;
+        const float* src = tile + i * LD + kg * 8;
+        plane_store8<NP>(planes, blockIdx.x * 16 + i, kg, D / 32, *reinterpret_cast<const f32x4*>(src),
+                         *reinterpret_cast<const f32x4*>(src + 4));
+    }
+}
+
+int launch_layernorm_planes(float* x, const float* g, const float* b, int M, int D, int nplane, void* planes, hipStream_t s) {
+    ROHM_ARG_CHECK(M > 0 && M % 16 == 0 && planes, "layernorm_planes: M must be a positive multiple of 16");
+    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "layernorm_planes: 2 or 3 planes");
+    const dim3 grid(M / 16), block(256);
+    prof::Scope ps("layernorm", 0.0, (8.0 + 2.0 * nplane) * M * D, s);
+#define ROHM_LNP(DD)                                                                                                     \
+    do {                                                                                                                 \
+        if (nplane == 3) hipLaunchKernelGGL((layernorm_planes_kernel<DD, 3>), grid, block, 0, s, x, g, b, (char*)planes); \
+        else hipLaunchKernelGGL((layernorm_planes_kernel<DD, 2>), grid, block, 0, s, x, g, b, (char*)planes);            \
+    } while (0)
+    if (D == 512) ROHM_LNP(512);
+    else if (D == 256) ROHM_LNP(256);
+    else if (D == 1024) ROHM_LNP(1024);
+    else { set_error("layernorm_planes: unsupported D=%d", D); return ROHM_ERR_UNSUPPORTED; }
+#undef ROHM_LNP
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }

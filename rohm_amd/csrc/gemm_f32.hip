@@ -726,17 +726,6 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
     if (force_bn == 6) return launch_t<64, EPI>(p, s);
     if (force_bn == 12) return launch_t<128, EPI>(p, s);
 #endif
-    // Opt-in precision ladder (ROHM_GEMM_PRECISION=bf16x6 | bf16x3): split-bf16 products for the plain GEMMs (PoseNet);
-    // convolutions, split-K and the LayerNorm-folding epilogues stay on the exact fp32 MFMA path.
-    static const int prec = [] {
-        const char* e = getenv("ROHM_GEMM_PRECISION");
-        if (e && !strcmp(e, "bf16x6")) return 8;
-        if (e && !strcmp(e, "bf16x3")) return 9;
-        return 0;
-    }();
-    if (prec && EPI != EPI_OUT_T && p.conv_taps == 0 && p.ksplit <= 1 && !p.out_stats && !p.ln_stats && !p.r_stats &&
-        planes_gemm_applies(p, EPI))
-        return launch_gemm_planes(p, EPI, prec == 8 ? 3 : 2, s);
     // Tile width: minimise  rounds x (BN + per-tile overhead),  rounds = ceil(tiles / workgroup slots).  Wider
     // tiles move fewer LDS-DMA bytes and fragment reads per MFMA and amortise the per-chunk barrier, but only while
     // every CU still gets a tile.  B = 64: N = 1536 -> 144x384, 1024 -> x256, 512 -> x128 (256 tiles each);

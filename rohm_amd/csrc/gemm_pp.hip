@@ -1,0 +1,403 @@
+// Split-bf16 GEMM on READY-MADE planes for gfx950 (opt-in precision ladder):
+//   C[M,N] = epi(A[M,K] . W[N,K]^T),  every fp32 product a.w emulated by bf16 MFMA products of the bf16 PLANES of the
+//   operands (planes.h), fp32 accumulation.  Same Linears as gemm_f32.hip (model/posenet.py:63-69).
+//
+//   three planes (bf16x6): the six plane products of weight >= 2^-16 -- fp32-class accuracy
+//   two planes   (bf16x3): three products (~2^-16 per product)
+//
+// Round 2 cut the planes INSIDE the GEMM (fp32 tiles staged through LDS, cut by the VALU, written back to LDS as fragments):
+// 221 KB of LDS traffic per K chunk for 1.0 us of MFMA -- the LDS pipe, not the matrix core, set the pace (MFMA busy 0.36).
+// Here nobody cuts: the PRODUCERS (LayerNorm, attention, the GELU epilogue of this kernel) write planes of their outputs in
+// fragment-major layout, the weights are cut once at rohm_posenet_create, and
+//   * the A fragments of a chunk (9 row blocks x NP planes x 1 KiB) go HBM/L2 -> LDS by LDS-DMA, ONE instruction per
+//     fragment, contiguous source, linear image, read back with one conflict-free ds_read_b128 per (row block, plane);
+//   * the B fragments never touch LDS: a wave loads the planes of its own 32 (16) columns straight into registers
+//     (1 KiB contiguous per load), two chunks ahead;
+//   -> 27 KB of DMA + 108 KB of fragment reads per chunk at 144 x 128, no VALU work in the loop at all.
+//   * 8 waves = two per SIMD on a 144 x (64 | 128) tile, 2 x 4 wave grid: wave (wm, wn) owns row blocks 0-4 / 5-8 of the
+//     column group wn; waves w and w + 4 share a SIMD, so every SIMD carries nine row blocks and the partner issues MFMAs
+//     while a wave sits in a DMA issue, an LDS wait or the barrier;
+//   * three LDS stages, DMA two chunks ahead, ONE barrier per chunk; the barrier sits between two MFMA groups whose
+//     operands are already in registers (the first row block of chunk k is multiplied AFTER the barrier that publishes chunk
+//     k + 1), so no LDS latency is exposed behind it; waits are counted (vmcnt(ops of the youngest chunk)).
+// Operand order is swapped (weights on the MFMA "A" side): a lane ends with 4 consecutive output columns of one row.  Plane
+// output (the GELU GEMM feeding FF2): lanes 16 apart exchange half their packed planes (v_permlane16_swap) so that every lane
+// stores one complete 16-byte unit -- 1 KiB contiguous per store instruction.
+#include <type_traits>
+#include "planes.h"
+
+namespace rohm {
+namespace {
+
+constexpr int QM = 144, QRB = 9, QNT = 512, QSTAGE = 3;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// s_waitcnt vmcnt(n) lgkmcnt(0) (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4] = 7, lgkmcnt [11:8])
+#define PP_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (0 << 8) | (((n) >> 4) << 14))
+
+template <int NP>
+struct Frag { u32x4 p[NP]; };
+
+template <int EPI, int NP, int CB, bool POUT>
+__global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
+    constexpr int NPROD = (NP == 3) ? 6 : 3;
+    constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};    // plane pairs (activation, weight), smallest terms first
+    constexpr int BN = 4 * CB * 16;
+    constexpr int NF = QRB * NP;                  // A fragments (1 KiB) per chunk
+    constexpr int PIECES = (NF + 7) / 8;          // LDS-DMA instructions per wave per chunk
+    constexpr int VMOPS = PIECES + CB * NP;       // vector-memory operations per wave per chunk
+    constexpr int STAGE_B = NF * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_dummy = smem + QSTAGE * STAGE_B;    // 1 KiB landing zone of the unpopulated DMA pieces
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    const int li = lane & 15, lg = lane >> 4;
+    // Rows: wave (wm, wn) owns row blocks 4 wm .. 4 wm + 3 of its CB column blocks, and of row block 8 the column block(s)
+    // of half wm -- every wave multiplies 4 CB + CB / 2 blocks per chunk, every SIMD (waves w, w + 4) nine row blocks.
+    const int r0 = wm * 4;
+    const int tiles_n = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, (p.M / QM) * tiles_n);
+    const int mblk0 = (tile / tiles_n) * QRB;     // first 16-row block of the tile
+    const int n0 = (tile % tiles_n) * BN;
+    const int nkc = p.K / 32;
+    const size_t chunk_b = (size_t)NP * 1024;     // bytes of one (row block, chunk) in either operand
+
+    // ---- A: LDS-DMA, fragment f = wave + 8 j of the chunk (row block f / NP, plane f % NP) --------------------------------
+    const char* a_src[PIECES];
+    int a_dst[PIECES];                            // byte offset inside a stage, -1: landing zone
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int f = wave + 8 * j;
+        const bool ok = f < NF;
+        const int rb = ok ? f / NP : 0, pl = ok ? f % NP : 0;
+        a_src[j] = reinterpret_cast<const char*>(p.Ap) + ((size_t)(mblk0 + rb) * nkc * NP + pl) * 1024 + lane * 16;
+        a_dst[j] = ok ? f * 1024 : -1;
+    }
+    auto dma_piece = [&](int stage, int kc, int j) {
+        char* dst = (a_dst[j] >= 0) ? smem + stage * STAGE_B + a_dst[j] : lds_dummy;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + (size_t)kc * chunk_b),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto dma = [&](int stage, int kc) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) dma_piece(stage, kc, j);
+    };
+    // ---- B: straight into registers, the planes of this wave's CB column blocks ------------------------------------------
+    const char* b_src[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+        b_src[c] = reinterpret_cast<const char*>(p.Wp) + (size_t)((n0 >> 4) + wn * CB + c) * nkc * chunk_b + lane * 16;
+    Frag<NP> breg[QSTAGE][CB];
+    auto bload = [&](Frag<NP> (&dst)[CB], int kc) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                dst[c].p[pl] = *reinterpret_cast<const u32x4*>(b_src[c] + (size_t)kc * chunk_b + pl * 1024);
+    };
+    auto aread = [&](Frag<NP>& dst, int stage, int rb) {     // row block rb of the chunk in `stage`
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+            dst.p[pl] = *reinterpret_cast<const u32x4*>(smem + stage * STAGE_B + (rb * NP + pl) * 1024 + lane * 16);
+    };
+
+    f32x4 acc[4][CB], acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma = [](const u32x4& w, const u32x4& a, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    };
+    // MFMAs [lo, hi) of one row block, product-major (consecutive MFMAs hit different accumulators): t = product * CB + column
+    auto mm_range = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP> (&b)[CB], int lo, int hi) {
+#pragma unroll
+        for (int t = 0; t < NPROD * CB; ++t) {
+            if (t < lo || t >= hi) continue;
+            const int q = 6 - NPROD + t / CB, c = t % CB;
+            d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+        }
+    };
+    auto mm = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP> (&b)[CB]) { mm_range(d, a, b, 0, NPROD * CB); };
+    // the wave's share of row block 8: column block wm of its two (CB = 2), or the only one for wm = 0 (CB = 1)
+    auto b8 = [&](const Frag<NP> (&b)[CB]) {
+        Frag<NP> r;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r.p[pl][q] = wm ? b[CB - 1].p[pl][q] : b[0].p[pl][q];
+        return r;
+    };
+    // [last full row block | the share of row block 8], CB = 2: three accumulators round-robin, MFMAs [lo, hi) of 3 NPROD
+    auto mm_last = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP>& a8, const Frag<NP> (&b)[CB], const Frag<NP>& bh, int lo, int hi) {
+#pragma unroll
+        for (int t = 0; t < 3 * NPROD; ++t) {
+            if (t < lo || t >= hi) continue;
+            const int q = 6 - NPROD + t / 3, c = t % 3;
+            if (c < 2) d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+            else acc8 = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8);
+        }
+    };
+
+    // ---- prologue: chunks 0 and 1 in flight -----------------------------------------------------------------------------------
+    dma(0, 0);
+    bload(breg[0], 0);
+    const int k1 = (nkc > 1) ? 1 : 0;
+    dma(1, k1);
+    bload(breg[1], k1);
+    PP_WAIT_VM_LGKM0(VMOPS);                      // chunk 0 has landed (mine); the barrier publishes everybody's
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // One K chunk (stage S = kc % 3), entered right after the barrier that published it.  `a0` carries the wave's first row
+    // block of the PREVIOUS chunk (read before that barrier): its MFMAs run first, while the fragment reads of this chunk are
+    // in flight.  Every section opens with ONE MFMA of its row block, then issues the fragment reads of the next section,
+    // then the rest: hipcc waits lgkmcnt(0) at the first use of a fragment while LDS-DMA is pending, and placed like this
+    // that wait never has anything to wait for.  DMA pieces stay where the source puts them (side effects), so they are dealt
+    // out between MFMA groups by hand; the B loads are placed by sched_group_barrier.
+    constexpr int kMfma = 0x008, kVmem = 0x010;
+    constexpr int NM = CB * NPROD;                // MFMAs of one full row block
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+    Frag<NP> a0, a1, a2, a3;
+    auto step = [&](auto s_tag, auto first_tag, int kc) {
+        constexpr int S = decltype(s_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int SP = (S + 2) % 3;           // stage of chunk kc - 1 = target of chunk kc + 2
+        const int kn = (kc + 2 < nkc) ? kc + 2 : nkc - 1;     // the last two chunks re-fetch the last one (uniform counts)
+        // -- section 1: [previous chunk, first row block] + DMA of chunk kc + 2
+        if constexpr (FIRST) {
+            aread(a1, S, r0 + 1);
+            dma(SP, kn);
+        } else {
+            constexpr int G = (NM - 1) / PIECES;  // MFMAs between two DMA pieces
+            mm_range(acc[0], a0, breg[SP], 0, 1);
+            PP_SB();
+            aread(a1, S, r0 + 1);
+            PP_SB();
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                mm_range(acc[0], a0, breg[SP], 1 + i * G, 1 + (i + 1) * G);
+                PP_SB();
+                dma_piece(SP, kn, i);
+                PP_SB();
+            }
+            mm_range(acc[0], a0, breg[SP], 1 + PIECES * G, NM);
+        }
+        PP_SB();
+        // -- section 2: row block r0 + 1, B fragments of chunk kc + 2 (their registers were last read in section 1)
+        mm_range(acc[1], a1, breg[S], 0, 1);
+        PP_SB();
+        aread(a2, S, r0 + 2);
+        PP_SB();
+        bload(breg[SP], kn);
+        mm_range(acc[1], a1, breg[S], 1, NM);
+#pragma unroll
+        for (int i = 0; i < CB * NP; ++i) {
+            __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NP), 1);
+            __builtin_amdgcn_sched_group_barrier(kVmem, 1, 1);
+        }
+        PP_SB();
+        // -- section 3: row block r0 + 2
+        mm_range(acc[2], a2, breg[S], 0, 1);
+        PP_SB();
+        aread(a1, S, r0 + 3);
+        aread(a3, S, 8);
+        PP_SB();
+        mm_range(acc[2], a2, breg[S], 1, NM);
+        PP_SB();
+        // -- section 4: row block r0 + 3 and the share of row block 8; the first row block is read for the next step
+        if constexpr (CB == 2) {
+            const Frag<NP> bh = b8(breg[S]);
+            mm_last(acc[3], a1, a3, breg[S], bh, 0, 1);
+            PP_SB();
+            aread(a0, S, r0);
+            PP_SB();
+            mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
+        } else {
+            mm_range(acc[3], a1, breg[S], 0, 1);
+            PP_SB();
+            aread(a0, S, r0);
+            PP_SB();
+            mm_range(acc[3], a1, breg[S], 1, NM);
+            if (wm == 0) {          // wave-uniform
+#pragma unroll
+                for (int q = 6 - NPROD; q < 6; ++q) acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
+            }
+        }
+        PP_SB();
+        PP_WAIT_VM_LGKM0(VMOPS);                  // chunk kc + 1 has landed; every fragment read of chunk kc has returned
+        __builtin_amdgcn_s_barrier();
+        PP_SB();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    step(I0{}, std::true_type{}, 0);
+    int kc = 1;
+    for (; kc + 3 <= nkc; kc += 3) {
+        step(I1{}, std::false_type{}, kc);
+        step(I2{}, std::false_type{}, kc + 1);
+        step(I0{}, std::false_type{}, kc + 2);
+    }
+    // remainder: 0, 1 or 2 chunks, then the first row block of the last chunk
+    const int rem = nkc - kc;
+    if (rem >= 1) step(I1{}, std::false_type{}, kc);
+    if (rem == 2) step(I2{}, std::false_type{}, kc + 1);
+    if (rem == 0) mm(acc[0], a0, breg[0]);
+    else if (rem == 1) mm(acc[0], a0, breg[1]);
+    else mm(acc[0], a0, breg[2]);
+    PP_WAIT_VM_LGKM0(0);                          // the re-fetched tail chunks: nothing may land in LDS after the workgroup ends
+
+    // ---- epilogue: lane holds C[m][nb .. nb + 3] ------------------------------------------------------------------------------
+    const int nkc_out = p.N / 32;
+    char* const cp = reinterpret_cast<char*>(p.Cp);
+    auto finish = [&](f32x4 v, int m, int nb) {
+        if (p.bias) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += b4[q];
+        }
+        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+        }
+        if constexpr (EPI == EPI_BIAS_RES) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += rr[q];
+        }
+        if constexpr (EPI == EPI_QKV) {
+            if (nb < p.qcols) {      // qcols is a multiple of 4
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= p.qscale;
+            }
+        }
+        if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + nb) = v;
+        return v;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = (mblk0 + r0 + j) * 16 + li;
+        f32x4 v[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) v[c] = finish(acc[j][c], m, n0 + (wn * CB + c) * 16 + lg * 4);
+        if constexpr (POUT) {
+            if (CB == 2 && !p.no_swap) {
+                // lanes (li, lg) and (li, lg ^ 1) trade: the even one ends with columns 4 lg .. 4 lg + 7 of block 0, the odd
+                // one with columns 4 (lg - 1) .. + 7 of block 1 -- one complete 16-byte unit per lane and plane
+                u32x2 c0[NP], c1[NP];
+                plane_cut4<NP>(v[0], c0);
+                plane_cut4<NP>(v[CB - 1], c1);
+                const int col = n0 + wn * 32 + ((lg & 1) ? 16 + (lg - 1) * 4 : lg * 4);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(c0[pl][0], c1[pl][0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(c0[pl][1], c1[pl][1], false, false);
+                    *reinterpret_cast<u32x4*>(cp + plane_unit(m, col >> 3, nkc_out, NP, pl) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) plane_store4<NP>(cp, m, n0 + (wn * CB + c) * 16 + lg * 4, nkc_out, v[c]);
+            }
+        }
+    }
+    if (CB == 2 || wm == 0) {        // the share of row block 8
+        const int m = (mblk0 + 8) * 16 + li;
+        const int nb = n0 + (wn * CB + (CB == 2 ? wm : 0)) * 16 + lg * 4;
+        const f32x4 v = finish(acc8, m, nb);
+        if constexpr (POUT) plane_store4<NP>(cp, m, nb, nkc_out, v);
+    }
+}
+
+// X[rows][K] fp32 -> planes; one thread per 16-byte unit, consecutive threads = consecutive lanes of a fragment
+template <int NP>
+__global__ __launch_bounds__(256) void plane_split_kernel(const float* __restrict__ X, int ld, int rows, int K, char* __restrict__ out) {
+    const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int nkc = K / 32;
+    const size_t units = (size_t)(rows / 16) * nkc * 64;
+    if (u >= units) return;
+    const int lane = (int)(u & 63);
+    const size_t blk = u >> 6;
+    const int kc = (int)(blk % nkc), rb = (int)(blk / nkc);
+    const int row = rb * 16 + (lane & 15), kg = kc * 4 + (lane >> 4);
+    const float* src = X + (size_t)row * ld + kg * 8;
+    plane_store8<NP>(out, row, kg, nkc, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+}
+
+inline bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
+
+template <int EPI, int NP, int CB, bool POUT>
+int launch_pp(const PlaneGemmParams& p, hipStream_t s) {
+    constexpr int BN = 4 * CB * 16;
+    const int tiles = (p.M / QM) * (p.N / BN);
+    const size_t lds = (size_t)QSTAGE * QRB * NP * 1024 + 1024;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    ROHM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev]) {
+        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, NP, CB, POUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv"};
+    static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64"};
+    prof::Scope ps(CB == 1 ? kNames64[EPI] : kNames[EPI], 2.0 * p.M * p.N * p.K,
+                   2.0 * NP * ((double)p.M * p.K + (double)p.N * p.K) + (p.C ? 4.0 : 0.0) * p.M * p.N + (p.Cp ? 2.0 * NP : 0.0) * p.M * p.N, s);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, NP, CB, POUT>), dim3(tiles), dim3(QNT), lds, s, p);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+template <int EPI, int NP>
+int launch_pp_shape(const PlaneGemmParams& p, hipStream_t s) {
+    // 144 x 128 tiles while they give (nearly) every CU a tile, 144 x 64 below that (the per-GPU batch of 32 clips and less)
+    const bool wide = (p.N % 128 == 0) && (long)(p.M / QM) * (p.N / 128) >= 192;
+    if (p.Cp) return wide ? launch_pp<EPI, NP, 2, true>(p, s) : launch_pp<EPI, NP, 1, true>(p, s);
+    return wide ? launch_pp<EPI, NP, 2, false>(p, s) : launch_pp<EPI, NP, 1, false>(p, s);
+}
+
+template <int NP>
+int launch_pp_epi(const PlaneGemmParams& p, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BIAS: return launch_pp_shape<EPI_BIAS, NP>(p, s);
+        case EPI_BIAS_GELU: return launch_pp_shape<EPI_BIAS_GELU, NP>(p, s);
+        case EPI_BIAS_RES: return launch_pp_shape<EPI_BIAS_RES, NP>(p, s);
+        case EPI_QKV: return launch_pp_shape<EPI_QKV, NP>(p, s);
+    }
+    set_error("gemm_pp: unsupported epilogue %d", epi);
+    return ROHM_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+int launch_gemm_pp(const PlaneGemmParams& p, int epi, int nplane, hipStream_t s) {
+    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "gemm_pp: 2 or 3 planes (got %d)", nplane);
+    ROHM_ARG_CHECK(p.Ap && p.Wp && (p.C || p.Cp), "gemm_pp: null operand / no output");
+    ROHM_ARG_CHECK(p.M > 0 && p.M % QM == 0 && p.N > 0 && p.N % 64 == 0 && p.K > 0 && p.K % 32 == 0,
+                   "gemm_pp: %d x %d x %d is not made of whole 144 x 64 tiles / 32-wide K chunks", p.M, p.N, p.K);
+    ROHM_ARG_CHECK(al16(p.Ap) && al16(p.Wp) && al16(p.C) && al16(p.Cp) && al16(p.bias) && p.ldc % 4 == 0,
+                   "gemm_pp: operands must be 16-byte aligned");
+    if (epi == EPI_BIAS_RES) ROHM_ARG_CHECK(p.R && al16(p.R) && p.ldr % 4 == 0, "gemm_pp: bad residual");
+    if (epi == EPI_QKV) ROHM_ARG_CHECK(p.qcols % 4 == 0, "gemm_pp: qcols must be a multiple of 4");
+    return nplane == 3 ? launch_pp_epi<3>(p, epi, s) : launch_pp_epi<2>(p, epi, s);
+}
+
+int launch_plane_split(const float* X, int ld, int rows, int K, int nplane, void* out, hipStream_t s) {
+    ROHM_ARG_CHECK(X && out && rows > 0 && rows % 16 == 0 && K > 0 && K % 32 == 0 && ld % 4 == 0 && al16(X) && al16(out),
+                   "plane_split: rows %% 16, K %% 32, 16-byte aligned operands required (rows=%d, K=%d)", rows, K);
+    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "plane_split: 2 or 3 planes (got %d)", nplane);
+    const size_t units = (size_t)(rows / 16) * (K / 32) * 64;
+    prof::Scope ps("plane_split", 0.0, (4.0 + 2.0 * nplane) * rows * K, s);
+    const dim3 grid((unsigned)((units + 255) / 256));
+    if (nplane == 3) hipLaunchKernelGGL(plane_split_kernel<3>, grid, dim3(256), 0, s, X, ld, rows, K, (char*)out);
+    else hipLaunchKernelGGL(plane_split_kernel<2>, grid, dim3(256), 0, s, X, ld, rows, K, (char*)out);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+}  // namespace rohm

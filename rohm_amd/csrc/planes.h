@@ -1,0 +1,100 @@
+// bf16 PLANES of fp32 tensors (opt-in precision ladder): layout and the cut, shared by every kernel that
+// produces or consumes them (gemm_pp.hip, elementwise.hip LayerNorm, attention_f32.hip, posenet.hip).
+//
+// Cut (by truncation, exact):  h = upper 16 bits of x,  m = upper 16 bits of x - h,  l = x - h - m.  Every remainder is
+// exact in fp32 and each plane carries 8 significant bits, so x = h + m + l EXACTLY for |x| >= 2^-100
+// (tests/test_precision_ladder_arith.py).  Two planes: x = h + m up to 2^-15 |x|.
+//
+// Layout ("fragment-major"), for a matrix X[rows][K], rows % 16 == 0, K % 32 == 0, NP planes:
+//   16-byte unit (row block rb = row / 16, K chunk kc = k / 32, plane p, lane = ((k % 32) / 8) * 16 + row % 16)
+//   holds the 8 bf16 of k = 8 (k / 8) .. + 7;   unit index = ((rb * (K / 32) + kc) * NP + p) * 64 + lane.
+// A (row block, chunk, plane) is 1 KiB = exactly the operand fragment of v_mfma_f32_16x16x32_bf16 (lane (i, g) holds
+// row i, k-group g), so the consuming GEMM moves it with ONE LDS-DMA instruction (contiguous source, linear LDS image) and
+// reads it back with ONE conflict-free ds_read_b128 -- or, for the weights, loads it straight into registers; the row
+// strip of a row block is contiguous over K.
+#pragma once
+#include "common.h"
+
+namespace rohm {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+inline size_t plane_tensor_bytes(int rows, int K, int nplane) {
+    return (size_t)((rows + 15) / 16) * 16 * (size_t)K * 2 * (size_t)nplane;
+}
+
+#ifdef __HIPCC__
+// 16-byte unit index of (row, k-group kg = k / 8)
+__device__ __forceinline__ size_t plane_unit(int row, int kg, int nkc, int np, int pl) {
+    return ((size_t)((row >> 4) * nkc + (kg >> 2)) * np + pl) * 64 + (kg & 3) * 16 + (row & 15);
+}
+
+// four fp32 -> two packed dwords (4 bf16) per plane
+template <int NP>
+__device__ __forceinline__ void plane_cut4(const f32x4& x, u32x2 (&o)[NP]) {
+    unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hb[i] = __float_as_uint(x[i]) & 0xffff0000u;
+        const float r1 = x[i] - __uint_as_float(hb[i]);
+        if constexpr (NP == 3) {
+            mb[i] = __float_as_uint(r1) & 0xffff0000u;
+            lb[i] = __float_as_uint(r1 - __uint_as_float(mb[i]));
+        } else {
+            mb[i] = __float_as_uint(r1);
+            lb[i] = 0u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {        // (hi & 0xffff0000) | (lo >> 16): one v_perm_b32
+        o[0][j] = __builtin_amdgcn_perm(hb[2 * j + 1], hb[2 * j], 0x07060302u);
+        o[1][j] = __builtin_amdgcn_perm(mb[2 * j + 1], mb[2 * j], 0x07060302u);
+        if constexpr (NP == 3) o[2][j] = __builtin_amdgcn_perm(lb[2 * j + 1], lb[2 * j], 0x07060302u);
+    }
+}
+
+// eight consecutive fp32 of one row (k = 8 kg .. 8 kg + 7) -> the row's 16-byte unit of every plane
+template <int NP>
+__device__ __forceinline__ void plane_store8(char* planes, int row, int kg, int nkc, const f32x4& lo, const f32x4& hi) {
+    u32x2 a[NP], b[NP];
+    plane_cut4<NP>(lo, a);
+    plane_cut4<NP>(hi, b);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+        *reinterpret_cast<u32x4*>(planes + plane_unit(row, kg, nkc, NP, pl) * 16) = u32x4{a[pl][0], a[pl][1], b[pl][0], b[pl][1]};
+}
+
+// four consecutive fp32 (k = k0 .. k0 + 3, k0 % 4 == 0) -> half a unit of every plane
+template <int NP>
+__device__ __forceinline__ void plane_store4(char* planes, int row, int k0, int nkc, const f32x4& v) {
+    u32x2 a[NP];
+    plane_cut4<NP>(v, a);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+        *reinterpret_cast<u32x2*>(planes + plane_unit(row, k0 >> 3, nkc, NP, pl) * 16 + (k0 & 4) * 2) = a[pl];
+}
+#endif
+
+// ---- pre-planed split-bf16 GEMM (gemm_pp.hip):  C[M,N] = epi(A[M,K] . W[N,K]^T), both operands given as planes -------------
+struct PlaneGemmParams {
+    const void* Ap;          // planes of A over [M][K]
+    const void* Wp;          // planes of W over [N][K]
+    float* C; int ldc;       // fp32 result (nullptr: not stored)
+    void* Cp;                // planes of the result over [M][N] (nullptr: not stored)
+    int M, N, K;
+    const float* bias;
+    const float* R; int ldr; // EPI_BIAS_RES
+    int qcols; float qscale; // EPI_QKV
+    int no_swap;             // diagnostic: plane output through 8-byte stores instead of the lane-swapped 16-byte form
+};
+// epi: EPI_BIAS / EPI_BIAS_GELU / EPI_BIAS_RES / EPI_QKV.  M % 144 == 0, N % 64 == 0, K % 32 == 0.
+int launch_gemm_pp(const PlaneGemmParams& p, int epi, int nplane, hipStream_t s);
+// X[rows][K] fp32 (row stride ld floats) -> planes; rows % 16 == 0, K % 32 == 0
+int launch_plane_split(const float* X, int ld, int rows, int K, int nplane, void* out, hipStream_t s);
+// LayerNorm in place on x [M][D] (M % 16 == 0) that also writes the planes of its result
+int launch_layernorm_planes(float* x, const float* g, const float* b, int M, int D, int nplane, void* planes, hipStream_t s);
+// attention (S = 144, d_h = 128 only) writing the planes of ctx [n_seq * 144][n_head * 128] instead of fp32
+int launch_attention_planes(const float* qkv, void* ctx_planes, int n_seq, int n_head, int nplane, hipStream_t s);
+
+}  // namespace rohm

@@ -15,8 +15,11 @@
 //            output head as a transposed GEMM (rows = 272 channels, cols = tokens) that stores
 //            straight into the [B, C, 1, T] layout, then `finish` copies the trajectory channels
 //            from cond (posenet.py:94-95) and applies the DDPM update.
+#include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "common.h"
+#include "planes.h"
 
 namespace rohm {
 
@@ -28,6 +31,8 @@ struct LayerW {
     // LayerNorm folding (common.h GemmParams): with folding on, l1_w is gamma1-scaled, l1_b holds d, l1_c holds c;
     // for layers >= 1 in_w is scaled by the PREVIOUS layer's gamma2, in_b holds d and in_c holds c.
     float *in_c, *l1_c;
+    // bf16 planes of the four weight matrices (precision ladder, planes.h); null in the exact-fp32 mode
+    char *in_wp, *out_wp, *l1_wp, *l2_wp;
 };
 
 }  // namespace rohm
@@ -45,6 +50,8 @@ struct rohm_posenet {
     float *out_w, *out_b;                 // [Cout, D], [Cout]
     float *out_c;                         // LayerNorm folding of the last norm2 into the output head
     bool ln_fold;                         // LayerNorm folded into the surrounding GEMMs (default) or run as a kernel
+    int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2: split-bf16 GEMMs on planes (bf16x6 / bf16x3)
+    char* wplanes;                        // one allocation holding the weight planes of every layer
     std::vector<rohm::LayerW> layers;
 };
 
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(float* __restrict__ W, flo
 // ----------------------------------------------------------------------------- workspace
 struct Workspace {
     float *apack, *h, *y, *qkv, *ctx, *ff, *tab0, *x0, *tok_all;
+    char *hP, *yP, *ctxP, *ffP;   // planes of h / y / ctx / ff (split-bf16 mode; ctx and ff then exist as planes only)
     float *stats_a, *stats_b;     // row (sum, sum of squares) partials of y / h: [M][D/64][2]
     int64_t* t_all;
     size_t floats;
@@ -218,6 +226,13 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
     w.h = take(M * p->D);
     w.y = take(M * p->D);
     w.qkv = take(M * 3 * p->D);
+    if (p->nplane) {
+        // M is a multiple of 16 only for whole clips of 144 tokens; other shapes run the fp32 path and need ctx / ff
+        auto take_planes = [&](size_t cols) { return reinterpret_cast<char*>(take(plane_tensor_bytes((int)M, (int)cols, p->nplane) / 4)); };
+        w.hP = take_planes(p->D); w.yP = take_planes(p->D); w.ctxP = take_planes(p->D); w.ffP = take_planes(p->F);
+    } else {
+        w.hP = w.yP = w.ctxP = w.ffP = nullptr;
+    }
     w.ctx = take(M * p->D);
     w.ff = take(M * p->F);
     w.tab0 = take((size_t)B * p->D);
@@ -262,7 +277,35 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     }
     float* h = w.h;
     float* y = w.y;
-    const bool fold = p->ln_fold;
+    const bool planes = p->nplane && S == 144 && D / p->H == 128;
+    if (planes) {
+        // Split-bf16 mode: every producer hands its consumer bf16 planes (planes.h) -- LayerNorm writes fp32 (the residual)
+        // AND planes, attention and the GELU GEMM write planes only; the embed output is cut by a small kernel (once per step).
+        const int np = p->nplane;
+        if ((rc = launch_plane_split(h, D, M, D, np, w.hP, s))) return rc;
+        for (int l = 0; l < p->L; ++l) {
+            const LayerW& lw = p->layers[l];
+            PlaneGemmParams g{};
+            g.Ap = w.hP; g.Wp = lw.in_wp; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+            g.bias = lw.in_b; g.qcols = D; g.qscale = 1.0f / sqrtf((float)(D / p->H));
+            if ((rc = launch_gemm_pp(g, EPI_QKV, np, s))) return rc;
+            if ((rc = launch_attention_planes(w.qkv, w.ctxP, B, p->H, np, s))) return rc;
+            g = PlaneGemmParams{};
+            g.Ap = w.ctxP; g.Wp = lw.out_wp; g.C = y; g.ldc = D; g.M = M; g.N = D; g.K = D;
+            g.bias = lw.out_b; g.R = h; g.ldr = D;
+            if ((rc = launch_gemm_pp(g, EPI_BIAS_RES, np, s))) return rc;
+            if ((rc = launch_layernorm_planes(y, lw.n1_w, lw.n1_b, M, D, np, w.yP, s))) return rc;
+            g = PlaneGemmParams{};
+            g.Ap = w.yP; g.Wp = lw.l1_wp; g.Cp = w.ffP; g.M = M; g.N = p->F; g.K = D; g.bias = lw.l1_b;
+            if ((rc = launch_gemm_pp(g, EPI_BIAS_GELU, np, s))) return rc;
+            g = PlaneGemmParams{};
+            g.Ap = w.ffP; g.Wp = lw.l2_wp; g.C = h; g.ldc = D; g.M = M; g.N = D; g.K = p->F;
+            g.bias = lw.l2_b; g.R = y; g.ldr = D;
+            if ((rc = launch_gemm_pp(g, EPI_BIAS_RES, np, s))) return rc;
+            if ((rc = launch_layernorm_planes(h, lw.n2_w, lw.n2_b, M, D, np, w.hP, s))) return rc;
+        }
+    }
+    const bool fold = p->ln_fold && !planes;
     const int parts = D / 64;
     auto ln_operand = [&](GemmParams& g, const float* stats, const float* c) {
         g.ln_stats = stats; g.ln_parts = parts; g.ln_c = c; g.ln_dim = D; g.ln_eps = 1e-5f;
@@ -270,7 +313,7 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     auto ln_residual = [&](GemmParams& g, const float* stats, const float* gamma, const float* beta) {
         g.r_stats = stats; g.r_parts = parts; g.r_gamma = gamma; g.r_beta = beta; g.ln_dim = D; g.ln_eps = 1e-5f;
     };
-    for (int l = 0; l < p->L; ++l) {
+    for (int l = 0; l < (planes ? 0 : p->L); ++l) {
         const LayerW& lw = p->layers[l];
         // With folding, h holds the RAW (pre-norm2) output of the previous layer for l >= 1 and stats_b its row sums.
         GemmParams g{};
@@ -400,6 +443,21 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         // Opt-in for further tuning: ROHM_POSENET_LNFOLD=1.
         const char* e2 = getenv("ROHM_POSENET_LNFOLD");
         p->ln_fold = (e2 && atoi(e2) == 1) && d_model <= 512;       // 8 statistic slots of 64 columns
+        // Opt-in precision ladder: ROHM_GEMM_PRECISION=bf16x6 | bf16x3 runs the four Linears of every
+        // encoder layer as split-bf16 GEMMs on planes (gemm_pp.hip).  The default -- and every headline number -- is exact fp32.
+        const char* e3 = getenv("ROHM_GEMM_PRECISION");
+        p->nplane = 0;
+        if (e3 && !strcmp(e3, "bf16x6")) p->nplane = 3;
+        else if (e3 && !strcmp(e3, "bf16x3")) p->nplane = 2;
+        else if (e3 && *e3 && strcmp(e3, "fp32")) {
+            set_error("posenet_create: ROHM_GEMM_PRECISION must be fp32, bf16x6 or bf16x3 (got '%s')", e3);
+            (void)hipFree(p->arena);
+            delete p;
+            return ROHM_ERR_ARG;
+        }
+        if (d_model / n_head != 128 || d_model % 64 || d_ff % 64) p->nplane = 0;   // shapes the plane kernels do not cover
+        if (p->nplane) p->ln_fold = false;
+        p->wplanes = nullptr;
     }
     float* tmp = a + o_tmp;
     float* tmp2 = a + o_tmp2;
@@ -445,6 +503,35 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
     }
 #undef PUT
     ROHM_HIP_CHECK(hipDeviceSynchronize());
+    for (auto& d : p->layers) d.in_wp = d.out_wp = d.l1_wp = d.l2_wp = nullptr;
+    if (p->nplane) {
+        const size_t b_in = plane_tensor_bytes(3 * d_model, d_model, p->nplane), b_out = plane_tensor_bytes(d_model, d_model, p->nplane),
+                     b_l1 = plane_tensor_bytes(d_ff, d_model, p->nplane), b_l2 = plane_tensor_bytes(d_model, d_ff, p->nplane);
+        hipError_t e4 = hipMalloc(&p->wplanes, (b_in + b_out + b_l1 + b_l2) * n_layer);
+        if (e4 != hipSuccess) {
+            set_error("posenet_create: hipMalloc of the weight planes failed: %s", hipGetErrorString(e4));
+            (void)hipFree(p->arena);
+            delete p;
+            return ROHM_ERR_HIP;
+        }
+        char* wp = p->wplanes;
+        int rc4 = ROHM_OK;
+        for (int l = 0; l < n_layer && rc4 == ROHM_OK; ++l) {
+            LayerW& d = p->layers[l];
+            d.in_wp = wp; wp += b_in; d.out_wp = wp; wp += b_out; d.l1_wp = wp; wp += b_l1; d.l2_wp = wp; wp += b_l2;
+            rc4 = launch_plane_split(d.in_w, d_model, 3 * d_model, d_model, p->nplane, d.in_wp, 0);
+            if (!rc4) rc4 = launch_plane_split(d.out_w, d_model, d_model, d_model, p->nplane, d.out_wp, 0);
+            if (!rc4) rc4 = launch_plane_split(d.l1_w, d_model, d_ff, d_model, p->nplane, d.l1_wp, 0);
+            if (!rc4) rc4 = launch_plane_split(d.l2_w, d_ff, d_model, d_ff, p->nplane, d.l2_wp, 0);
+        }
+        if (rc4 != ROHM_OK || hipDeviceSynchronize() != hipSuccess) {
+            if (rc4 == ROHM_OK) set_error("posenet_create: cutting the weight planes failed");
+            (void)hipFree(p->wplanes);
+            (void)hipFree(p->arena);
+            delete p;
+            return rc4 != ROHM_OK ? rc4 : ROHM_ERR_HIP;
+        }
+    }
     if (p->ln_fold) {
         for (int l = 0; l < n_layer; ++l) {
             LayerW& d = p->layers[l];
@@ -467,8 +554,11 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
 void rohm_posenet_destroy(rohm_posenet_t* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
+    if (h->wplanes) (void)hipFree(h->wplanes);
     delete h;
 }
+
+int rohm_posenet_precision(const rohm_posenet_t* h) { return h ? h->nplane : 0; }
 
 size_t rohm_posenet_workspace_bytes(const rohm_posenet_t* h, int B, int T) {
     if (!h || B <= 0 || T <= 0) return 0;

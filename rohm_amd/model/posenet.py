@@ -82,6 +82,8 @@ class _NativePoseNet:
                   'rohm_posenet_create')
         del keep
         self._ws = {}
+        # 0: exact fp32 MFMA GEMMs (default); 3 / 2: created under ROHM_GEMM_PRECISION=bf16x6 / bf16x3 (labelled second line)
+        self.gemm_planes = int(lib().rohm_posenet_precision(self.handle))
 
     def workspace(self, B, T):
         """Caller-owned workspace of the C ABI, one per (shape, HIP stream): forwards issued on different streams get
@@ -157,9 +159,24 @@ class PoseNet(nn.Module):
         self._native_key = None
 
     # ------------------------------------------------------------------ native handle cache
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): parameters may be re-created
+        self._plist = None
+        return super()._apply(fn, *args, **kwargs)
+
     def _fingerprint(self, device):
-        vs = tuple((p.data_ptr(), p._version) for p in self.parameters(recurse=True))
-        return (str(device), hash(vs))
+        """(device, storage address and version counter of every parameter).  The parameter list is collected once (the
+        module-tree walk is the expensive part of a per-forward check on the guided, step-wise path); in-place updates
+        (load_state_dict, optimiser steps) move the version counters, re-allocation moves the addresses."""
+        pl = getattr(self, '_plist', None)
+        if pl is None:
+            pl = self._plist = list(self.parameters(recurse=True))
+        return (str(device), hash(tuple([(p.data_ptr(), p._version) for p in pl])))
+
+    @property
+    def gemm_precision(self):
+        """'fp32' (default) or the opt-in 'bf16x6' / 'bf16x3' the native handle was created under (ROHM_GEMM_PRECISION)."""
+        n = self._native.gemm_planes if self._native is not None else 0
+        return {0: 'fp32', 3: 'bf16x6', 2: 'bf16x3'}[n]
 
     def native(self, device=None):
         """The `rohm_posenet_t` for the current weights on `device` (rebuilt if they changed)."""

@@ -46,6 +46,58 @@ def attention(qkv, n_seq, n_head, n_tok=144, head_dim=128):
     return ctx
 
 
+# ---- opt-in precision ladder: bf16 planes of fp32 matrices and the split-bf16 GEMM on them (rohm_hip.h) ----
+EPI_QKV = 3
+
+
+def planes_empty(rows, k, nplane, device):
+    """Uninitialised plane tensor of an fp32 matrix [rows, k] (fragment-major layout of csrc/planes.h), as int16."""
+    n = lib().rohm_planes_bytes(rows, k, nplane)
+    return torch.empty(n // 2, dtype=torch.int16, device=device)
+
+
+def planes_split(x, nplane=3):
+    """fp32 [rows, K] (rows % 16 == 0, K % 32 == 0) -> its bf16 planes."""
+    _lib.require_hip(x)
+    rows, k = x.shape
+    out = planes_empty(rows, k, nplane, x.device)
+    check(lib().rohm_planes_split(ptr(x), x.stride(0), rows, k, nplane, ptr(out), stream_ptr(x.device)), 'rohm_planes_split')
+    return out
+
+
+def gemm_planes(a_planes, w_planes, m, n, k, nplane=3, bias=None, residual=None, epi=EPI_BIAS, qcols=0, qscale=1.0,
+                out_f32=True, out_planes=False, flags=0):
+    """epi(A @ W^T) from the planes of A [m, k] and W [n, k] -> (fp32 [m, n] or None, planes of it or None)."""
+    _lib.require_hip(a_planes, w_planes)
+    c = torch.empty(m, n, device=a_planes.device, dtype=torch.float32) if out_f32 else None
+    cp = planes_empty(m, n, nplane, a_planes.device) if out_planes else None
+    check(lib().rohm_gemm_planes(ptr(a_planes), ptr(w_planes), ptr(c), n, ptr(cp), m, n, k, ptr(bias), ptr(residual),
+                                 residual.stride(0) if residual is not None else 0, qcols, qscale, epi, nplane, flags,
+                                 stream_ptr(a_planes.device)), 'rohm_gemm_planes')
+    return c, cp
+
+
+def layernorm_planes_(x, gamma, beta, nplane=3):
+    """In-place LayerNorm that also returns the planes of its result."""
+    _lib.require_hip(x)
+    m, d = x.shape
+    out = planes_empty(m, d, nplane, x.device)
+    check(lib().rohm_layernorm_planes_f32(ptr(x), ptr(gamma), ptr(beta), m, d, nplane, ptr(out), stream_ptr(x.device)),
+          'rohm_layernorm_planes_f32')
+    return out
+
+
+def attention_planes(qkv, n_seq, n_head, nplane=3):
+    """attention() for n_tok = 144, head_dim = 128 returning the PLANES of ctx [n_seq * 144, n_head * 128]."""
+    _lib.require_hip(qkv)
+    if qkv.shape != (n_seq * 144, 3 * n_head * 128):
+        raise ValueError(f'qkv must be [{n_seq * 144}, {3 * n_head * 128}], got {tuple(qkv.shape)}')
+    out = planes_empty(n_seq * 144, n_head * 128, nplane, qkv.device)
+    check(lib().rohm_attention_planes_f32(ptr(qkv), ptr(out), n_seq, n_head, nplane, stream_ptr(qkv.device)),
+          'rohm_attention_planes_f32')
+    return out
+
+
 def ddpm_step(x_t, x0, noise, c1, c2, sigma, grad=None, grad_scale=0.0, out=None):
     _lib.require_hip(x_t, x0)
     if out is None:

@@ -1,0 +1,140 @@
+"""GPU: the opt-in split-bf16 path kernel by kernel, through the C ABI.
+
+Producers of bf16 planes (rohm_planes_split, the LayerNorm / attention / GELU-GEMM plane outputs) are held BIT-EXACTLY to
+"cut of the fp32 result" (oracle/planes.py restates cut and layout); the GEMM on planes is held to a float64 evaluation
+at the exact-fp32 kernel's own bar (tests/test_gpu_kernels.py::test_gemm) for three planes, and to the north-star class
+for two.  The whole-network proofs (reference goldens, 1000 steps, 64 clips) are in tests/test_gpu_precision_ladder.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_abs, seeded
+from oracle import nets
+from oracle import planes as oplanes
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda', 0)
+
+
+@pytest.mark.parametrize('nplane', [3, 2])
+def test_planes_split_is_the_cut_in_fragment_major_layout(nplane):
+    from rohm_amd import ops
+    x = seeded(11, 144 * 2, 96) * 3.0
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-20, 3e20, 0.333333343, -7.0])
+    got = ops.planes_split(x.to(_dev()), nplane).cpu().numpy()
+    assert np.array_equal(got, oplanes.encode(x.numpy(), nplane))
+    if nplane == 3:
+        assert np.array_equal(oplanes.decode(got, 288, 96, 3).astype(np.float64).sum(0), x.numpy().astype(np.float64))
+
+
+# shapes: one tile / several; K chunk counts 1, 2, 3, 4, 16, 17, 18, 32 (every remainder of the 3-stage ring);
+# 144 x 128 tiles (>= 192 of them) and 144 x 64 tiles (fewer)
+SHAPES = [(144, 64, 32), (144, 128, 64), (288, 192, 96), (144, 512, 128), (144 * 3, 512, 512), (144 * 2, 512, 544),
+          (144 * 2, 256, 576), (144 * 3, 512, 1024), (144 * 64, 512, 512), (144 * 64, 1536, 512), (144 * 64, 1024, 512),
+          (144 * 64, 512, 1024), (144 * 32, 512, 512), (144 * 32, 1536, 512)]
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+@pytest.mark.parametrize('epi', [0, 1, 2, 3])
+def test_gemm_planes_bf16x6_meets_the_fp32_bar(M, N, K, epi):
+    from rohm_amd import ops
+    if M * N > 144 * 64 * 512 and epi in (0, 3) and K > 512:
+        pytest.skip('covered by the other epilogues at this size')
+    a, w = seeded(M + N, M, K), seeded(K + 7, N, K) / math.sqrt(K)
+    bias, res = seeded(3, N), seeded(4, M, N)
+    ref = a.double() @ w.double().T + bias.double()
+    if epi == 1:
+        ref = nets.gelu_erf(ref)
+    if epi == 2:
+        ref = ref + res.double()
+    if epi == 3:
+        ref[:, :N // 2] *= 0.25
+    d = _dev()
+    ap, wp = ops.planes_split(a.to(d), 3), ops.planes_split(w.to(d), 3)
+    out, _ = ops.gemm_planes(ap, wp, M, N, K, 3, bias.to(d), res.to(d) if epi == 2 else None, epi, qcols=N // 2, qscale=0.25)
+    assert max_abs(out.cpu(), ref) < 2e-5 * math.sqrt(K / 32)       # the exact-fp32 kernel's bar
+
+
+@pytest.mark.parametrize('M,N,K', [(144 * 3, 512, 512), (144 * 64, 512, 512), (144 * 2, 192, 1024)])
+def test_gemm_planes_bf16x3_is_2_pow_minus_16_class(M, N, K):
+    from rohm_amd import ops
+    a, w = seeded(M + N, M, K), seeded(K + 7, N, K) / math.sqrt(K)
+    ref = a.double() @ w.double().T
+    d = _dev()
+    out, _ = ops.gemm_planes(ops.planes_split(a.to(d), 2), ops.planes_split(w.to(d), 2), M, N, K, 2)
+    err = max_abs(out.cpu(), ref)
+    assert err < 3e-4 * math.sqrt(K / 512), err
+
+
+def test_gemm_planes_identity_asymmetric():
+    """A = I against an asymmetric W: catches transposed or permuted output tiles and a wrong k order inside a fragment."""
+    from rohm_amd import ops
+    d = _dev()
+    a = torch.eye(144, 192).contiguous()
+    w = (torch.arange(128 * 192, dtype=torch.float32).reshape(128, 192) / 128.0).contiguous()      # exact in 3 planes
+    out, _ = ops.gemm_planes(ops.planes_split(a.to(d)), ops.planes_split(w.to(d)), 144, 128, 192)
+    assert torch.equal(out.cpu(), w[:, :144].T.contiguous())
+
+
+@pytest.mark.parametrize('M,N,K', [(144 * 64, 1024, 512), (144 * 2, 1024, 512), (144 * 64, 512, 64)])
+@pytest.mark.parametrize('nplane', [3, 2])
+@pytest.mark.parametrize('flags', [0, 1])
+def test_gemm_plane_output_is_the_cut_of_the_fp32_output(M, N, K, nplane, flags):
+    """The GELU GEMM that feeds FF2 writes planes only; both store forms (lane-swapped 16-byte units / 8-byte halves) and
+    both tile widths must give exactly cut(fp32 result)."""
+    from rohm_amd import ops
+    a, w, bias = seeded(M + N, M, K), seeded(K + 7, N, K) / math.sqrt(K), seeded(3, N)
+    d = _dev()
+    ap, wp = ops.planes_split(a.to(d), nplane), ops.planes_split(w.to(d), nplane)
+    out, cp = ops.gemm_planes(ap, wp, M, N, K, nplane, bias.to(d), None, 1, out_planes=True, flags=flags)
+    only, cp2 = ops.gemm_planes(ap, wp, M, N, K, nplane, bias.to(d), None, 1, out_f32=False, out_planes=True, flags=flags)
+    assert only is None and torch.equal(cp, cp2)
+    assert np.array_equal(cp.cpu().numpy(), oplanes.encode(out.cpu().numpy(), nplane))
+
+
+@pytest.mark.parametrize('M', [16, 144, 144 * 7])
+@pytest.mark.parametrize('nplane', [3, 2])
+def test_layernorm_planes(M, nplane):
+    from rohm_amd import ops
+    x, g, b = seeded(M, M, 512) * 3 + 0.5, seeded(1, 512), seeded(2, 512)
+    d = _dev()
+    plain = ops.layernorm_(x.to(d), g.to(d), b.to(d))
+    xx = x.to(d)
+    pl = ops.layernorm_planes_(xx, g.to(d), b.to(d), nplane)
+    assert torch.equal(xx, plain)                      # same arithmetic, same order
+    assert np.array_equal(pl.cpu().numpy(), oplanes.encode(plain.cpu().numpy(), nplane))
+    assert max_abs(plain.cpu(), nets.layer_norm(x.double(), g.double(), b.double())) < 5e-6
+
+
+@pytest.mark.parametrize('n_seq,n_head', [(1, 4), (3, 4), (32, 4), (33, 4), (64, 4)])      # split / full launch shapes
+@pytest.mark.parametrize('nplane', [3, 2])
+def test_attention_planes(n_seq, n_head, nplane):
+    """Plane output runs the P.V MFMAs with exchanged operands (the same products in the same order): the planes must be the
+    cut of what the fp32 kernel stores."""
+    from rohm_amd import ops
+    D = n_head * 128
+    qkv = seeded(n_seq * 10 + n_head, n_seq * 144, 3 * D).to(_dev())
+    ctx = ops.attention(qkv, n_seq, n_head)
+    pl = ops.attention_planes(qkv, n_seq, n_head, nplane).cpu().numpy()
+    dec = oplanes.decode(pl, n_seq * 144, D, nplane)
+    want = np.stack(oplanes.cut(ctx.cpu().numpy(), nplane))
+    if not np.array_equal(dec, want):                  # tolerate a different rounding of the exchanged MFMA, nothing more
+        assert nplane == 3
+        assert np.abs(dec.astype(np.float64).sum(0) - ctx.cpu().numpy()).max() < 2e-6
+
+
+def test_shape_errors_are_raised_before_any_launch():
+    from rohm_amd import _lib, ops
+    d = _dev()
+    with pytest.raises(_lib.RohmHipError):
+        ops.planes_split(torch.zeros(10, 32, device=d))                 # rows % 16
+    ap, wp = ops.planes_split(torch.zeros(144, 32, device=d)), ops.planes_split(torch.zeros(64, 32, device=d))
+    with pytest.raises(_lib.RohmHipError):
+        ops.gemm_planes(ap, wp, 100, 64, 32)                            # M % 144
+    with pytest.raises(_lib.RohmHipError):
+        ops.gemm_planes(ap, wp, 144, 64, 32, nplane=4)

@@ -1,4 +1,4 @@
-"""CPU check of the arithmetic behind the opt-in split-bf16 GEMM (rohm_amd/csrc/gemm_planes.hip): the truncation planes
+"""CPU check of the arithmetic behind the opt-in split-bf16 GEMM (rohm_amd/csrc/gemm_pp.hip, planes.h): the truncation planes
 h = upper 16 bits of x, m = upper 16 bits of (x - h), l = x - h - m reproduce x EXACTLY, every plane is a bf16 value, and
 the six (three) plane products kept by bf16x6 (bf16x3) leave an error of fp32-rounding size (~2^-16) on a dot product.
 The kernel's own results are held to the fp32 kernel's bars by tests/test_gpu_precision_ladder.py on the GPU."""
@@ -54,3 +54,26 @@ def test_six_products_are_fp32_class_three_are_2_pow_minus_16():
     assert e6 < 2.0 ** -21, e6                 # dropped m.l + l.m + l.l ~ 2^-23 per product: below an fp32 GEMM's own rounding
     assert e6 < 4 * max(e32, 2.0 ** -24)
     assert 2.0 ** -22 < e3 < 2.0 ** -13, e3    # three products: ~2^-16 per product, summed over K
+
+
+def test_plane_layout_restatement_round_trips():
+    """oracle/planes.py (the checker of the GPU plane producers): encode -> decode gives the cut back, the cut sums to x,
+    and the unit index is the one planes.h states."""
+    from oracle import planes as op
+    rng = np.random.default_rng(2)
+    for nplane in (3, 2):
+        x = rng.standard_normal((48, 96)).astype(np.float32)
+        buf = op.encode(x, nplane)
+        assert buf.size * 2 == 48 * 96 * 2 * nplane
+        dec = op.decode(buf, 48, 96, nplane)
+        for got, want in zip(dec, op.cut(x, nplane)):
+            assert np.array_equal(got, want)
+        if nplane == 3:
+            assert np.array_equal(dec.astype(np.float64).sum(0), x.astype(np.float64))
+        # spot-check the address arithmetic: element (row 37, k 70) of plane 1
+        row, k, p = 37, 70, 1
+        unit = (((row // 16) * (96 // 32) + k // 32) * nplane + p) * 64 + ((k % 32) // 8) * 16 + row % 16
+        got = (np.uint32(buf.view(np.uint16)[unit * 8 + k % 8]) << np.uint32(16)).view(np.float32)
+        assert got == op.cut(x, nplane)[p][row, k]
+    h, m = op.cut(np.float32([1.2345678]), 2)
+    assert is_bf16(h) and is_bf16(m) and abs(float(h[0]) + float(m[0]) - 1.2345678) < 1.2345678 * 2.0 ** -15
