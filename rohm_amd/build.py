@@ -41,8 +41,13 @@ def find_hipcc():
     return None
 
 
-def build(force=False, verbose=True):
-    if not force and not is_stale():
+def build(force=False, verbose=True, out=None, diag=None):
+    """Build the library; `out` / `diag` build a second copy (scripts/gemm_timeline.py uses a ROHM_GEMM_DIAGNOSTICS build
+    under ROHM_HIP_LIB without touching the shipped librohm_hip.so)."""
+    target = out or LIB
+    if diag is None:
+        diag = os.environ.get('ROHM_DIAG') == '1'
+    if not force and out is None and not is_stale():
         return LIB
     hipcc = find_hipcc()
     if hipcc is None:
@@ -51,7 +56,7 @@ def build(force=False, verbose=True):
     import concurrent.futures
     import tempfile
     flags = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
-    if os.environ.get('ROHM_DIAG') == '1':      # diagnostic GEMM variants / knobs for scripts/gemm_*.py (never shipped)
+    if diag:      # diagnostic GEMM variants / knobs for scripts/gemm_*.py (never shipped)
         flags.append('-DROHM_GEMM_DIAGNOSTICS')
     with tempfile.TemporaryDirectory(prefix='rohm_build_') as tmp:
         objs = [os.path.join(tmp, os.path.basename(f) + '.o') for f in sources()]
@@ -64,14 +69,17 @@ def build(force=False, verbose=True):
             subprocess.run(cmd, check=True, cwd=CSRC)
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(compile_one, zip(sources(), objs)))
-        link = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB + '.tmp'] + objs
+        link = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', target + '.tmp'] + objs
         if verbose:
             print('[rohm_amd.build]', ' '.join(link), flush=True)
         subprocess.run(link, check=True, cwd=CSRC)
-    os.replace(LIB + '.tmp', LIB)
-    return LIB
+    os.replace(target + '.tmp', target)
+    return target
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(LIB)
+    if '--diag' in sys.argv:      # second copy with the diagnostic GEMM variants, next to the shipped library
+        print(build(force=True, out=os.path.join(HERE, 'librohm_hip_diag.so'), diag=True))
+    else:
+        build(force='--force' in sys.argv)
+        print(LIB)
