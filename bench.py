@@ -17,8 +17,17 @@ given.  A world size that disagrees with --gpus, or fewer visible GPUs than rank
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the fp32-MFMA GEMM
 family: algorithmic flops / HIP-event-measured launch time, sampled every 16th denoising step of the
-timed region on the launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle port of the same
-p_sample step timed on the host cores).
+timed region on the launch stream) and, at N = 1, `cpu_baseline` (the reference's own p_sample on its own PoseNet where
+/root/reference exists -- the build container -- else the CPU oracle port of the same step, timed on the host cores).
+
+At N = 1 the default run then adds, each measured by a child process AFTER the headline leg (thermal history: the headline
+always runs first on a cold chip) and none of them ever replacing `value` / `dtype` / `roofline`, which stay exact fp32:
+  `second_line`  the same workload under ROHM_GEMM_PRECISION=bf16x6 (split-bf16 GEMMs on planes) with its
+                 own dtype, roofline (bf16 MFMA peak / 6) and 1000-step accuracy against the reference's own run;
+  `configs`      one short pass each of the other BASELINE.json configurations on this GPU: `b32` (PoseNet at the per-GPU
+                 batch of configs[2..4]), `scheme_b32` (configs[2]), `prox_b32` (configs[3]), `egobody_b32` (configs[4]).
+`--no-extras` skips both (the children run with it).  `--force-dist` initialises the RCCL process group even at world size
+1 and runs the barrier / MAX all-reduce / result all-gather of the multi-GPU path through it.
 """
 from __future__ import annotations
 
@@ -84,12 +93,16 @@ def pmc_traffic():
         return None, None
 
 
-def pmc_mfma():
-    """MFMA-pipe utilisation of the GEMM family as rocprofv3 counts it (profiles/*pmc_sq.json from scripts/gpu_r2_profile.sh
-    + scripts/sq_summary.py: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel time x 2.4 GHz), launch-weighted),
-    plus the attention kernel's.  A separate, serialised and slower-clocked run of the same workload (never the timed one)."""
+def pmc_mfma(batch):
+    """ARCHIVED counter figures, not part of this run: MFMA-pipe utilisation of the GEMM family as rocprofv3 counted it in the
+    most recent committed PMC pass of THIS batch size (profiles/*pmc_sq[_b<B>].json from scripts/gpu_r2_profile.sh +
+    scripts/sq_summary.py: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel time x 2.4 GHz), launch-weighted).  PMC
+    collection serialises and slows the kernels, so it is always a separate run of an earlier build; None when no pass of
+    this batch size is committed."""
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*pmc_sq.json')))
+    want = '' if batch == 64 else f'_b{batch}'
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*pmc_sq*.json'))
+                   if os.path.basename(f).split('pmc_sq')[1] == want + '.json')
     if not files:
         return None
     try:
@@ -99,7 +112,8 @@ def pmc_mfma():
         busy = sum(v['mfma_busy_frac_at_2p4GHz'] * v['avg_us_under_pmc'] * v['launches'] for v in gem.values()) / t
         att = [v for n, v in k.items() if 'attention_f32_kernel' in n]
         conf = max(v['lds_bank_conflict_frac'] for v in k.values())
-        return {'gemm_family_mfma_busy': busy, 'attention_mfma_busy': att[0]['mfma_busy_frac_at_2p4GHz'] if att else None,
+        return {'archived': True, 'note': 'separate rocprofv3 PMC pass of an earlier build at this batch size, not this run',
+                'gemm_family_mfma_busy': busy, 'attention_mfma_busy': att[0]['mfma_busy_frac_at_2p4GHz'] if att else None,
                 'max_lds_bank_conflict_frac': conf, 'source': os.path.basename(files[-1])}
     except (OSError, ValueError, KeyError, ZeroDivisionError):
         return None
@@ -159,23 +173,58 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(batch=8, budget_s=12.0):
-    """Oracle port of one PoseNet p_sample step on the host cores, extrapolated to 1000 steps."""
-    from oracle import diffusion as odiff
-    from oracle import nets
+    """One PoseNet p_sample step on the host cores, extrapolated to 1000 steps: the REFERENCE's own
+    SpacedDiffusionPoseNet.p_sample on its own model.posenet.PoseNet (diffusion/gaussian_diffusion_posenet.py:388-434) where
+    the reference tree exists (kind "reference": the build container), otherwise the oracle port of the same step (kind
+    "port": the GPU boxes, where /root/reference does not exist).  Same synthetic weights, same batch."""
+    from oracle import refload
     from rohm_amd.utils import synth
     cores = min(usable_cores(), 64)      # torch intra-op scaling flattens (and then degrades) past ~64 threads
     torch.set_num_threads(cores)
     sd = synth.posenet_state_dict(0)
-    tab = odiff.tables(odiff.cosine_betas(1000))
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 294, 1, 143, generator=g)
     cond = torch.randn(batch, 294, 1, 143, generator=g)
-    fn = lambda xx, i: nets.posenet_forward(sd, xx, cond, torch.full((batch,), i, dtype=torch.int64))
+    kind = 'port'
+    if refload.available():
+        try:
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # the reference prints while it builds its modules
+                ref = refload.load()
+                net = ref.posenet.PoseNet(_Dataset(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4,
+                                          traj_feat_dim=22, device='cpu').eval()
+            net.load_state_dict(sd, strict=True)
+            diff = ref.model_util.create_gaussian_diffusion(_Args, ref.gd_posenet, ref.respace.SpacedDiffusionPoseNet, 1000, '',
+                                                            device='cpu')
 
-    def one(i):
-        nz = [torch.randn(batch, 294, 1, 143, generator=g)]
-        return odiff.p_sample_loop(fn, x, nz, tab, [i])
+            def one(i):
+                t = torch.full((batch,), i, dtype=torch.int64)
+                return diff.p_sample(net, {'cond': cond}, x, t, clip_denoised=False)['sample']
+            with torch.no_grad():
+                one(999)
+            kind = 'reference'
+        except Exception as e:      # a reference tree that does not import here: say so and time the port
+            print(f'bench.py: reference CPU baseline unavailable ({type(e).__name__}: {e}); timing the oracle port', file=sys.stderr)
+    if kind == 'port':
+        from oracle import diffusion as odiff
+        from oracle import nets
+        tab = odiff.tables(odiff.cosine_betas(1000))
+        fn = lambda xx, i: nets.posenet_forward(sd, xx, cond, torch.full((batch,), i, dtype=torch.int64))
+
+        def one(i):
+            nz = [torch.randn(batch, 294, 1, 143, generator=g)]
+            return odiff.p_sample_loop(fn, x, nz, tab, [i])
     with torch.no_grad():
         one(999)
         n, t0 = 0, time.perf_counter()
@@ -186,10 +235,11 @@ def cpu_baseline(batch=8, budget_s=12.0):
             if el > budget_s or n >= 200:
                 break
     sec_per_step = el / n
+    what = ("the reference's own SpacedDiffusionPoseNet.p_sample on model.posenet.PoseNet (torch CPU fp32)" if kind == 'reference'
+            else 'oracle (torch-CPU fp32 restatement) PoseNet p_sample')
     return {'value': batch / (sec_per_step * 1000.0), 'unit': 'clips/s', 'cores': cores,
-            'host_cpus': os.cpu_count(), 'kind': 'port',
-            'sample': f'oracle (torch-CPU fp32 restatement) PoseNet p_sample, B={batch}, {n} timed steps '
-                      f'({el:.1f} s, {sec_per_step * 1e3:.1f} ms/step) extrapolated to 1000 steps',
+            'host_cpus': os.cpu_count(), 'cpu_model': cpu_model(), 'kind': kind,
+            'sample': f'{what}, B={batch}, {n} timed steps ({el:.1f} s, {sec_per_step * 1e3:.1f} ms/step) extrapolated to 1000 steps',
             'torch_threads': torch.get_num_threads()}
 
 
@@ -282,8 +332,8 @@ def scheme_bench(args, world, rank, dev, dist):
         bt, bp = batches()
         run = run_prox_iterations if ego else run_amass_iterations
         pose, _, _ = run(sargs, nets, diffs, bt, bp, tds, pds, layer)
-        if world > 1:
-            sharding.gather_clips(pose, world * B)
+        if dist is not None:
+            sharding.gather_clips(pose, world * B, force=True)
         return pose
 
     elapsed, out, prof = timed_region(one_pass, args, world, dev, dist)
@@ -322,6 +372,67 @@ def scheme_bench(args, world, rank, dev, dist):
                             'kernels': kernels}}
         print(json.dumps(rec), flush=True)
     finish(world, dist)
+
+
+def run_child(argv, env_extra=None, timeout=600):
+    """One more measurement as a child process of this script (own process: own handles, own failure domain); returns its
+    JSON record, or {'error': ...} -- a failing extra never costs the headline line."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'ROHM_GEMM_PRECISION'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-extras', '--no-cpu-baseline'] + list(argv)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {'error': f'timeout after {timeout} s', 'argv': list(argv)}
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'error': f'rc={r.returncode}', 'stderr_tail': r.stderr[-400:], 'argv': list(argv)}
+    try:
+        d = json.loads(lines[-1])
+    except ValueError as e:
+        return {'error': f'bad JSON: {e}', 'argv': list(argv)}
+    d['child_wall_s'] = round(time.perf_counter() - t0, 1)
+    return d
+
+
+def brief(d):
+    """The fields of a child's record that the parent line carries."""
+    if 'error' in d:
+        return d
+    rf = d.get('roofline') or {}
+    out = {'value': d['value'], 'unit': d['unit'], 'ms_per_pass': d['ms_per_step'], 'passes': d['steps'], 'warmup': d['warmup'],
+           'dtype': d['dtype'], 'metric': d['metric'], 'workload': d['config']['workload'],
+           'finite_output': d['config'].get('finite_output', True),
+           'gemm_roofline': {'achieved': rf.get('achieved'), 'peak': rf.get('peak'), 'frac': rf.get('frac'), 'unit': rf.get('unit'),
+                             'time_share_of_kernels': rf.get('gemm_time_share_of_kernels')},
+           'child_wall_s': d.get('child_wall_s')}
+    if rf.get('attention'):
+        out['attention_roofline'] = {k: rf['attention'][k] for k in ('achieved', 'frac', 'avg_launch_us')}
+    return out
+
+
+def extras(args):
+    """`second_line` and `configs` of the N = 1 record (see the module docstring); headline first, these afterwards."""
+    S = str(args.ddpm_steps)
+    sl = run_child(['--workload', 'posenet', '--batch', str(args.batch), '--ddpm-steps', S, '--steps', '2', '--warmup', '1',
+                    '--with-accuracy'], {'ROHM_GEMM_PRECISION': 'bf16x6'})
+    second = brief(sl)
+    if 'error' not in sl:
+        second['roofline'] = {k: sl['roofline'].get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'peak_note',
+                                                                  'launches_timed', 'avg_launch_us')}
+        second['accuracy'] = sl.get('accuracy')
+        second['label'] = ('opt-in ROHM_GEMM_PRECISION=bf16x6: every fp32 product of the four encoder Linears emulated by six bf16 MFMA '
+                           'products of exact truncation planes, fp32 accumulation; held to the fp32 parity bars by '
+                           'tests/test_gpu_precision_ladder.py; NEVER the headline (narrower arithmetic than the reference)')
+    cfg = {}
+    for key, argv in (('b32', ['--workload', 'posenet', '--batch', '32']), ('scheme_b32', ['--workload', 'scheme', '--batch', '32']),
+                      ('prox_b32', ['--workload', 'prox', '--batch', '32']), ('egobody_b32', ['--workload', 'egobody', '--batch', '32'])):
+        cfg[key] = brief(run_child(argv + ['--ddpm-steps', S, '--steps', '1', '--warmup', '1']))
+    return second, cfg
 
 
 def free_port():
@@ -365,9 +476,14 @@ def init_ranks(args):
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:        # bare `--force-dist` start without a launcher
+            os.environ['MASTER_PORT'] = str(free_port())
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if selftest:
             dist.init_process_group('gloo')
         else:
@@ -379,7 +495,7 @@ def timed_region(one_pass, args, world, dev, dist, profile=True):
     """W untimed warm-up passes, then EXACTLY K passes bracketed by barrier + device synchronize on both sides; the
     elapsed time is the MAX over ranks.  Returns (elapsed_s, last_output, profiler_dict)."""
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         if dev.type == 'cuda':
             torch.cuda.synchronize(dev)
@@ -398,7 +514,7 @@ def timed_region(one_pass, args, world, dev, dist, profile=True):
     elapsed = time.perf_counter() - t0
     if profile and dev.type == 'cuda':
         prof = _lib.profile_stop()
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -406,7 +522,7 @@ def timed_region(one_pass, args, world, dev, dist, profile=True):
 
 
 def finish(world, dist):
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -451,6 +567,11 @@ def main(argv=None):
                          "configs[4]: the PROX/EgoBody driver loop (run_prox_iterations) with sample_iter=3, a random 80 % "
                          "visibility mask and PROX guidance; all but 'posenet' are extra measurements, not the headline")
     ap.add_argument('--profile-stride', type=int, default=16)
+    ap.add_argument('--no-extras', action='store_true', help='N = 1 only: skip the second_line / configs child measurements')
+    ap.add_argument('--with-accuracy', action='store_true', help='attach the 1000-step accuracy record even without the CPU leg')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise the RCCL process group even at world size 1 and run barrier / all-reduce / all-gather '
+                         'through it (the multi-GPU plumbing on a 1-GPU box)')
     argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -505,8 +626,8 @@ def main(argv=None):
             _, x0 = diffusion.eval_losses(model=net, batch=batch, shape=[B, 294, 1, 143], progress=False,
                                           clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
                                           compute_loss=False)
-        if world > 1:
-            sharding.gather_clips(x0, world * B)      # the path's only exchange: finished clips, RCCL all-gather
+        if dist is not None:
+            sharding.gather_clips(x0, world * B, force=True)      # the path's only exchange: finished clips, RCCL all-gather
         return x0
 
     elapsed, out, prof = timed_region(one_pass, args, world, dev, dist)
@@ -557,7 +678,7 @@ def main(argv=None):
                 'peak_note': 'fp32 MFMA' if not _PRODUCTS else f'bf16 MFMA peak / {_PRODUCTS} products (fp32-equivalent flops)',
                 'traffic': pmc_traffic()[0] if not _PRODUCTS else None, 'traffic_unit': 'bytes per launch (HBM side, PMC)',
                 'traffic_source': pmc_traffic()[1],
-                'mfma_busy_pmc': pmc_mfma(),
+                'mfma_busy_pmc': pmc_mfma(B),
                 # north_star: "... as fraction of the attention/GEMM roofline": the attention kernel by the same event timing
                 'attention': ({'achieved': prof['attention']['flops'] / (prof['attention']['total_ms'] * 1e-3) / 1e12,
                                'frac': prof['attention']['flops'] / (prof['attention']['total_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
@@ -570,9 +691,15 @@ def main(argv=None):
                 'kernels': kernels,
             },
         }
+        if dist is not None:
+            rec['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'forced': bool(args.force_dist)}
         if world == 1 and not args.no_cpu_baseline and not prox:
             rec['cpu_baseline'] = cpu_baseline(batch=B)
+        if world == 1 and not prox and (args.with_accuracy or not args.no_cpu_baseline):
             rec['accuracy'] = accuracy_vs_reference(dev)
+        if world == 1 and not args.no_extras and not prox and not _PRODUCTS:
+            torch.cuda.synchronize(dev)
+            rec['second_line'], rec['configs'] = extras(args)
         print(json.dumps(rec), flush=True)
     finish(world, dist)
 

@@ -43,10 +43,12 @@ def shard_batch(batch, world=None, rank=None, batch_dim_keys=None):
     return out
 
 
-def gather_clips(local, n_total, group=None):
-    """All-gather the per-rank results (possibly ragged along dim 0) back into the global batch order."""
+def gather_clips(local, n_total, group=None, force=False):
+    """All-gather the per-rank results (possibly ragged along dim 0) back into the global batch order.  A single-rank group
+    returns its input untouched unless `force` asks for the collective anyway (bench.py --force-dist: the RCCL path on a
+    one-GPU box)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local
     counts = [slice_bounds(n_total, world, r)[1] - slice_bounds(n_total, world, r)[0] for r in range(world)]
     width = max(counts)

@@ -23,8 +23,9 @@ def main():
     lib = _lib.lib()
     stream = torch.cuda.current_stream().cuda_stream
     for name, M, N, K in SHAPES:
-        a = torch.randn(M, K, device=dev)
-        w = torch.randn(N, K, device=dev) / K ** 0.5
+        zero = os.environ.get('ROHM_TL_ZERO') == '1'      # constant operands: the same instruction stream at lower switching power
+        a = torch.zeros(M, K, device=dev) if zero else torch.randn(M, K, device=dev)
+        w = torch.zeros(N, K, device=dev) if zero else torch.randn(N, K, device=dev) / K ** 0.5
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev)
         ts = torch.zeros(8192, 8, dtype=torch.int64, device=dev)

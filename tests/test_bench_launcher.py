@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, 'bench.py')
 
@@ -71,3 +73,44 @@ def test_driver_style_launch_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = _json_line(r.stdout)
     assert rec['n_gpus'] == 2 and rec['ranks_seen'] == [0, 1] and rec['gathered_clips'] == 4
+
+
+@pytest.mark.gpu
+def test_force_dist_runs_the_rccl_plumbing_on_one_gpu():
+    """the multi-GPU path's process-group code (nccl = RCCL init with device_id, barrier, MAX all-reduce of
+    the timing, all-gather of the results, one JSON line from rank 0) executed on real hardware at world size 1, launched the
+    way the driver launches N > 1 (torch.distributed.run, 127.0.0.1 rendezvous)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '1', '--warmup', '1',
+           '--batch', '8', '--ddpm-steps', '20', '--no-cpu-baseline', '--no-extras']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['process_group'] == {'backend': 'nccl', 'world_size': 1, 'forced': True}
+    assert d['value'] > 0 and d['roofline']['frac'] > 0
+    # and started bare (no launcher): the script provides its own rendezvous
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--steps', '1', '--warmup', '0', '--batch', '4',
+                        '--ddpm-steps', '10', '--no-cpu-baseline', '--no-extras'], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])['process_group']['backend'] == 'nccl'
+
+
+def test_force_dist_at_world_size_1_goes_through_the_process_group():
+    """CPU twin of the GPU test above: with --force-dist a single rank still initialises the group and runs the barrier, the MAX
+    all-reduce and the result all-gather through it (gloo here, RCCL on the GPU)."""
+    r = _run(['--gpus', '1', '--backend', 'gloo', '--force-dist', '--steps', '2', '--warmup', '1', '--batch', '3'],
+             {'ROHM_BENCH_SELFTEST': '1'}, drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json_line(r.stdout)
+    assert rec['n_gpus'] == 1 and rec['gathered_clips'] == 3 and rec['ranks_seen'] == [0]
