@@ -23,6 +23,7 @@
 // Operand order is swapped (weights on the MFMA "A" side): a lane ends with 4 consecutive output columns of one row.  Plane
 // output (the GELU GEMM feeding FF2): lanes 16 apart exchange half their packed planes (v_permlane16_swap) so that every lane
 // stores one complete 16-byte unit -- 1 KiB contiguous per store instruction.
+#include <stdlib.h>
 #include <type_traits>
 #include "planes.h"
 
@@ -30,6 +31,7 @@ namespace rohm {
 namespace {
 
 constexpr int QM = 144, QRB = 9, QNT = 512, QSTAGE = 3;
+constexpr int kStreamCUs = 256;      // MI355X: persistent workgroups of the stream kernel
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -314,6 +316,387 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
     }
 }
 
+// ---- the same GEMM as ONE STREAM OF CHUNKS per workgroup ---------------------------------------------------------------------
+// gemm_pp_kernel pays, per tile, a prologue (first chunk from L2 / HBM with nothing to multiply) and an epilogue in which all
+// 256 CUs store at once while no matrix core runs: measured 18-30 us of a 43-81 us launch at B = 64 (the K loop itself runs
+// at ~1.04 us per chunk).  Here a workgroup is persistent (grid = min(tiles, CUs)): it walks its tiles t = b, b + G, ... as one
+// flat sequence of K chunks.  The prefetch cursor (DMA + B loads two chunks ahead) simply runs on into the next tile, so only
+// the first tile of a workgroup has a prologue; and when a tile's last chunk has been multiplied its accumulators are handed to
+// a second register set (`pend`) and the next tile starts at once -- the stores of the finished tile are DRIPPED out one unit
+// (one 16-row block of the wave) per chunk of the next tile, between its MFMAs.  Only the last tile of a workgroup has an
+// exposed epilogue.
+// Counted waits with stores in the stream: on gfx9 stores share vmcnt with loads; loads return in order among loads, so
+// `vmcnt(n)` with n <= (loads issued since the data we need) can never be satisfied while an older load is outstanding,
+// whatever order the stores complete in.  Every step waits vmcnt(VMOPS) = the DMA pieces + B loads of that step.
+template <int EPI, int NP, int CB, bool POUT>
+__global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) {
+    constexpr int NPROD = (NP == 3) ? 6 : 3;
+    constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int BN = 4 * CB * 16;
+    constexpr int NF = QRB * NP;
+    constexpr int PIECES = (NF + 7) / 8;
+    constexpr int VMOPS = PIECES + CB * NP;
+    constexpr int STAGE_B = NF * 1024;
+    constexpr int NM = CB * NPROD;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_dummy = smem + QSTAGE * STAGE_B;
+    // the bias vector lives in LDS for the whole launch: an ordinary global load inside the dripped epilogue would make hipcc
+    // wait vmcnt(0) at its use and drain the prefetch pipeline in the middle of a step
+    float* bias_s = reinterpret_cast<float*>(smem + QSTAGE * STAGE_B + 1024);
+    for (int i = threadIdx.x; i < p.N; i += QNT) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    const int li = lane & 15, lg = lane >> 4;
+    const int r0 = wm * 4;
+    const int tiles_n = p.N / BN;
+    const int ntiles = (p.M / QM) * tiles_n;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;      // >= 1 (grid <= tiles)
+    const int nkc = p.K / 32;
+    const int total = my_tiles * nkc;                                 // chunks of this workgroup
+    const size_t chunk_b = (size_t)NP * 1024;
+
+    // tile seq -> (first row block, first column); linear ids of one workgroup keep their XCD (G is a multiple of 8 or == tiles)
+    auto tile_coords = [&](int seq, int& mblk0, int& n0) {
+        const int t = xcd_remap((int)blockIdx.x + seq * G, ntiles);
+        mblk0 = (t / tiles_n) * QRB;
+        n0 = (t % tiles_n) * BN;
+    };
+
+    // ---- operand addresses: tile-independent per-lane bases + a scalar offset for (tile, chunk) ------------------------------
+    const char* a_base[PIECES];
+    int a_dst[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int f = wave + 8 * j;
+        const bool ok = f < NF;
+        const int rb = ok ? f / NP : 0, pl = ok ? f % NP : 0;
+        a_base[j] = reinterpret_cast<const char*>(p.Ap) + ((size_t)rb * nkc * NP + pl) * 1024 + lane * 16;
+        a_dst[j] = ok ? f * 1024 : -1;
+    }
+    const char* b_base[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+        b_base[c] = reinterpret_cast<const char*>(p.Wp) + (size_t)(wn * CB + c) * nkc * chunk_b + lane * 16;
+    // prefetch cursor: chunk pf_kc of tile pf_seq; offsets of that chunk in A / W
+    int pf_seq = 0, pf_kc = 0;
+    size_t pf_a = 0, pf_b = 0;
+    {
+        int mb, n0;
+        tile_coords(0, mb, n0);
+        pf_a = (size_t)mb * nkc * chunk_b;
+        pf_b = (size_t)(n0 >> 4) * nkc * chunk_b;
+    }
+    auto pf_advance = [&]() {                     // to the next chunk of the stream; past the end it stays on the last chunk
+        if (pf_kc + 1 < nkc) {
+            ++pf_kc; pf_a += chunk_b; pf_b += chunk_b;
+        } else if (pf_seq + 1 < my_tiles) {
+            ++pf_seq; pf_kc = 0;
+            int mb, n0;
+            tile_coords(pf_seq, mb, n0);
+            pf_a = (size_t)mb * nkc * chunk_b;
+            pf_b = (size_t)(n0 >> 4) * nkc * chunk_b;
+        }
+    };
+    auto dma_piece = [&](int stage, int j) {
+        char* dst = (a_dst[j] >= 0) ? smem + stage * STAGE_B + a_dst[j] : lds_dummy;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base[j] + pf_a),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto dma = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) dma_piece(stage, j);
+    };
+    Frag<NP> breg[QSTAGE][CB];
+    auto bload = [&](Frag<NP> (&dst)[CB]) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                dst[c].p[pl] = *reinterpret_cast<const u32x4*>(b_base[c] + pf_b + pl * 1024);
+    };
+    auto aread = [&](Frag<NP>& dst, int stage, int rb) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+            dst.p[pl] = *reinterpret_cast<const u32x4*>(smem + stage * STAGE_B + (rb * NP + pl) * 1024 + lane * 16);
+    };
+
+    f32x4 acc[4][CB], acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma = [](const u32x4& w, const u32x4& a, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    };
+    auto mm_range = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP> (&b)[CB], int lo, int hi) {
+#pragma unroll
+        for (int t = 0; t < NPROD * CB; ++t) {
+            if (t < lo || t >= hi) continue;
+            const int q = 6 - NPROD + t / CB, c = t % CB;
+            d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+        }
+    };
+    auto b8 = [&](const Frag<NP> (&b)[CB]) {
+        Frag<NP> r;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r.p[pl][q] = wm ? b[CB - 1].p[pl][q] : b[0].p[pl][q];
+        return r;
+    };
+    auto mm_last = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP>& a8, const Frag<NP> (&b)[CB], const Frag<NP>& bh, int lo, int hi) {
+#pragma unroll
+        for (int t = 0; t < 3 * NPROD; ++t) {
+            if (t < lo || t >= hi) continue;
+            const int q = 6 - NPROD + t / 3, c = t % 3;
+            if (c < 2) d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+            else acc8 = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8);
+        }
+    };
+
+    // ---- epilogue of the PENDING tile (pm0 / pn0), one unit per step.  Units queue in the order they complete: row blocks
+    // r0 + 1, r0 + 2, r0 + 3, the share of row block 8, row block r0 (its last MFMAs run one step later).  `pendq[0]` is always the
+    // unit that goes out next; after a store the queue moves up by one (register moves: the arms of a switch over five statically
+    // named units would put five copies of the epilogue code into every step).
+    int pm0 = 0, pn0 = 0;                 // pending tile: first row block, first column
+    int drip = 5;                         // units stored so far of the pending tile (5 = nothing pending)
+    const int nkc_out = p.N / 32;
+    char* const cp = reinterpret_cast<char*>(p.Cp);
+    f32x4 pendq[5][CB];
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) pendq[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 rpre[CB];                       // residual of the unit about to be stored (EPI_BIAS_RES), loaded at the top of the step
+#pragma unroll
+    for (int c = 0; c < CB; ++c) rpre[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // position d in the queue order -> (row of this lane, first column of column block c, is the unit's block c real?)
+    auto unit_geom = [&](int d, int c, int& m, int& nb, bool& real) __attribute__((always_inline)) {
+        const bool blk8 = (d == 3);
+        const int rb = blk8 ? 8 : r0 + (d == 4 ? 0 : d + 1);
+        m = (pm0 + rb) * 16 + li;
+        const int cb = blk8 ? (CB == 2 ? wm : 0) : c;
+        nb = pn0 + (wn * CB + cb) * 16 + lg * 4;
+        real = !blk8 || (c == 0 && (CB == 2 || wm == 0));
+    };
+    auto load_residual = [&](int d) __attribute__((always_inline)) {
+        if constexpr (EPI == EPI_BIAS_RES) {
+            if (d < 5) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    int m, nb;
+                    bool real;
+                    unit_geom(d, c, m, nb, real);
+                    if (real) rpre[c] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nb);
+                }
+            }
+        }
+    };
+    auto finish = [&](f32x4 v, int m, int nb, const f32x4& rr) __attribute__((always_inline)) {
+        {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += b4[q];
+        }
+        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+        }
+        if constexpr (EPI == EPI_BIAS_RES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += rr[q];
+        }
+        if constexpr (EPI == EPI_QKV) {
+            if (nb < p.qcols) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= p.qscale;
+            }
+        }
+        return v;
+    };
+    // store the front unit (queue position d = drip) and move the queue up
+    auto store_front = [&](int d) __attribute__((always_inline)) {
+        f32x4 v[CB];
+        int m = 0, nb0 = 0;
+        bool real0 = false;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            int mm_, nb;
+            bool real;
+            unit_geom(d, c, mm_, nb, real);
+            if (c == 0) { m = mm_; nb0 = nb; real0 = real; }
+            v[c] = finish(pendq[0][c], mm_, nb, rpre[c]);
+            if (real && p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)mm_ * p.ldc + nb) = v[c];
+        }
+        if constexpr (POUT) {
+            if (d != 3 && CB == 2 && !p.no_swap) {
+                u32x2 c0[NP], c1[NP];
+                plane_cut4<NP>(v[0], c0);
+                plane_cut4<NP>(v[CB - 1], c1);
+                const int col = pn0 + wn * 32 + ((lg & 1) ? 16 + (lg - 1) * 4 : lg * 4);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(c0[pl][0], c1[pl][0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(c0[pl][1], c1[pl][1], false, false);
+                    *reinterpret_cast<u32x4*>(cp + plane_unit(m, col >> 3, nkc_out, NP, pl) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            } else if (d != 3) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) plane_store4<NP>(cp, m, nb0 + c * 16, nkc_out, v[c]);
+            } else if (real0) {
+                plane_store4<NP>(cp, m, nb0, nkc_out, v[0]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) pendq[u][c] = pendq[u + 1][c];
+    };
+
+    // ---- prologue of the stream: chunks 0 and 1 in flight ---------------------------------------------------------------------------
+    dma(0);
+    bload(breg[0]);
+    pf_advance();
+    dma(1);
+    bload(breg[1]);
+    pf_advance();
+    PP_WAIT_VM_LGKM0(VMOPS);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    constexpr int kMfma = 0x008, kVmem = 0x010;
+    Frag<NP> a0, a1, a2, a3;
+    int kc = 0;                           // chunk of the current tile being multiplied
+    int cm0 = 0, cn0 = 0, cseq = 0;       // current tile
+    tile_coords(0, cm0, cn0);
+    auto step = [&](auto s_tag, auto first_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int SP = (S + 2) % 3;
+        const bool tile_first = (kc == 0), tile_last = (kc + 1 == nkc);
+        if constexpr (!FIRST) load_residual(drip);
+        // -- section 1: [previous chunk, first row block] + DMA of chunk g + 2
+        if constexpr (FIRST) {
+            aread(a1, S, r0 + 1);
+            dma(SP);
+        } else {
+            constexpr int GQ = (NM - 1) / PIECES;
+            mm_range(acc[0], a0, breg[SP], 0, 1);
+            PP_SB();
+            aread(a1, S, r0 + 1);
+            PP_SB();
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                mm_range(acc[0], a0, breg[SP], 1 + i * GQ, 1 + (i + 1) * GQ);
+                PP_SB();
+                dma_piece(SP, i);
+                PP_SB();
+            }
+            mm_range(acc[0], a0, breg[SP], 1 + PIECES * GQ, NM);
+            if (tile_first) {             // that was the last chunk of the previous tile: its first row block is complete now
+#pragma unroll                        // (no unit of that tile has gone out yet: the queue's last slot is still position 4)
+                for (int c = 0; c < CB; ++c) { pendq[4][c] = acc[0][c]; acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+        }
+        PP_SB();
+        // -- section 2: row block r0 + 1, B fragments of chunk g + 2
+        mm_range(acc[1], a1, breg[S], 0, 1);
+        PP_SB();
+        aread(a2, S, r0 + 2);
+        PP_SB();
+        bload(breg[SP]);
+        mm_range(acc[1], a1, breg[S], 1, NM);
+#pragma unroll
+        for (int i = 0; i < CB * NP; ++i) {
+            __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NP), 1);
+            __builtin_amdgcn_sched_group_barrier(kVmem, 1, 1);
+        }
+        PP_SB();
+        pf_advance();
+        // -- section 3: row block r0 + 2
+        mm_range(acc[2], a2, breg[S], 0, 1);
+        PP_SB();
+        aread(a1, S, r0 + 3);
+        aread(a3, S, 8);
+        PP_SB();
+        mm_range(acc[2], a2, breg[S], 1, NM);
+        PP_SB();
+        // -- section 4: row block r0 + 3 and the share of row block 8; the first row block is read for the next step
+        if constexpr (CB == 2) {
+            const Frag<NP> bh = b8(breg[S]);
+            mm_last(acc[3], a1, a3, breg[S], bh, 0, 1);
+            PP_SB();
+            aread(a0, S, r0);
+            PP_SB();
+            mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
+        } else {
+            mm_range(acc[3], a1, breg[S], 0, 1);
+            PP_SB();
+            aread(a0, S, r0);
+            PP_SB();
+            mm_range(acc[3], a1, breg[S], 1, NM);
+            if (wm == 0) {
+#pragma unroll
+                for (int q = 6 - NPROD; q < 6; ++q) acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
+            }
+        }
+        PP_SB();
+        // -- one unit of the pending tile goes out
+        if constexpr (!FIRST) {
+            if (drip < 5) {
+                // the residual of this unit was requested at the top of the step, before the step's VMOPS prefetch operations
+                if constexpr (EPI == EPI_BIAS_RES) PP_WAIT_VM_LGKM0(VMOPS);
+                store_front(drip);
+                ++drip;
+            }
+        }
+        if (tile_last) {
+            // hand the finished blocks over (the first row block follows after section 1 of the next step).  The launcher
+            // guarantees nkc >= 6, so the five units of the tile before have gone out by now.
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) { pendq[j - 1][c] = acc[j][c]; acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            pendq[3][0] = acc8; acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
+            pm0 = cm0; pn0 = cn0; drip = 0;
+            kc = 0;
+            if (cseq + 1 < my_tiles) { ++cseq; tile_coords(cseq, cm0, cn0); }
+        } else {
+            ++kc;
+        }
+        PP_SB();
+        PP_WAIT_VM_LGKM0(VMOPS);
+        __builtin_amdgcn_s_barrier();
+        PP_SB();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    step(I0{}, std::true_type{});
+    int g = 1;
+    for (; g + 3 <= total; g += 3) {              // straight-line body: with steps under conditions inside the loop hipcc's wait
+        step(I1{}, std::false_type{});            // bookkeeping merges the paths and drains vmcnt(0) at the loop header
+        step(I2{}, std::false_type{});
+        step(I0{}, std::false_type{});
+    }
+    if (total - g >= 1) step(I1{}, std::false_type{});
+    if (total - g == 2) step(I2{}, std::false_type{});
+    const int last = (total - 1) % 3;             // stage of the last chunk: its first row block is still to be multiplied
+    if (last == 0) mm_range(acc[0], a0, breg[0], 0, NM);
+    else if (last == 1) mm_range(acc[0], a0, breg[1], 0, NM);
+    else mm_range(acc[0], a0, breg[2], 0, NM);
+    PP_WAIT_VM_LGKM0(0);                          // the re-fetched tail chunks: nothing may land in LDS after the workgroup ends
+    // the last tile was handed to the queue by its last step, except for the first row block
+#pragma unroll
+    for (int c = 0; c < CB; ++c) pendq[4][c] = acc[0][c];      // drip == 0 here: the tile ended with the last step
+    for (; drip < 5; ++drip) { load_residual(drip); store_front(drip); }
+}
+
 // X[rows][K] fp32 -> planes; one thread per 16-byte unit, consecutive threads = consecutive lanes of a fragment
 template <int NP>
 __global__ __launch_bounds__(256) void plane_split_kernel(const float* __restrict__ X, int ld, int rows, int K, char* __restrict__ out) {
@@ -331,24 +714,42 @@ __global__ __launch_bounds__(256) void plane_split_kernel(const float* __restric
 
 inline bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 
+static bool pp_stream_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("ROHM_PP_STREAM");      // diagnostic A/B switch: 0 = one workgroup per tile (gemm_pp_kernel)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <int EPI, int NP, int CB, bool POUT>
 int launch_pp(const PlaneGemmParams& p, hipStream_t s) {
     constexpr int BN = 4 * CB * 16;
     const int tiles = (p.M / QM) * (p.N / BN);
-    const size_t lds = (size_t)QSTAGE * QRB * NP * 1024 + 1024;
+    const size_t lds = (size_t)QSTAGE * QRB * NP * 1024 + 1024 + (size_t)p.N * sizeof(float);
+    const bool stream = pp_stream_enabled() && p.K / 32 >= 6;     // the dripped epilogue needs five steps of the next tile
     static bool attr_set[64] = {};
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
+        const int lds_max = QSTAGE * QRB * NP * 1024 + 1024 + 16384;      // + the bias vector (N <= 4096, checked at entry)
         ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, NP, CB, POUT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_stream_kernel<EPI, NP, CB, POUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr_set[dev] = true;
     }
     static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv"};
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64"};
     prof::Scope ps(CB == 1 ? kNames64[EPI] : kNames[EPI], 2.0 * p.M * p.N * p.K,
                    2.0 * NP * ((double)p.M * p.K + (double)p.N * p.K) + (p.C ? 4.0 : 0.0) * p.M * p.N + (p.Cp ? 2.0 * NP : 0.0) * p.M * p.N, s);
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, NP, CB, POUT>), dim3(tiles), dim3(QNT), lds, s, p);
+    if (stream) {
+        // persistent workgroups: one per CU (a multiple of 8, so a workgroup's tiles stay on its XCD), or one per tile if fewer
+        const int grid = tiles < kStreamCUs ? tiles : kStreamCUs;
+        hipLaunchKernelGGL((gemm_pp_stream_kernel<EPI, NP, CB, POUT>), dim3(grid), dim3(QNT), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((gemm_pp_kernel<EPI, NP, CB, POUT>), dim3(tiles), dim3(QNT), lds, s, p);
+    }
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
@@ -378,6 +779,7 @@ int launch_pp_epi(const PlaneGemmParams& p, int epi, hipStream_t s) {
 int launch_gemm_pp(const PlaneGemmParams& p, int epi, int nplane, hipStream_t s) {
     ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "gemm_pp: 2 or 3 planes (got %d)", nplane);
     ROHM_ARG_CHECK(p.Ap && p.Wp && (p.C || p.Cp), "gemm_pp: null operand / no output");
+    ROHM_ARG_CHECK(p.N <= 4096, "gemm_pp: N = %d exceeds the 4096 columns the kernel keeps a bias copy for", p.N);
     ROHM_ARG_CHECK(p.M > 0 && p.M % QM == 0 && p.N > 0 && p.N % 64 == 0 && p.K > 0 && p.K % 32 == 0,
                    "gemm_pp: %d x %d x %d is not made of whole 144 x 64 tiles / 32-wide K chunks", p.M, p.N, p.K);
     ROHM_ARG_CHECK(al16(p.Ap) && al16(p.Wp) && al16(p.C) && al16(p.Cp) && al16(p.bias) && p.ldc % 4 == 0,

@@ -34,9 +34,12 @@ def test_planes_split_is_the_cut_in_fragment_major_layout(nplane):
 
 # shapes: one tile / several; K chunk counts 1, 2, 3, 4, 16, 17, 18, 32 (every remainder of the 3-stage ring);
 # 144 x 128 tiles (>= 192 of them) and 144 x 64 tiles (fewer)
+# -- and for the persistent stream kernel (K >= 192): one, two and three tiles per workgroup, uneven tile counts (260, 320, 528
+# tiles on 256 workgroups), tiles of five to seven chunks
 SHAPES = [(144, 64, 32), (144, 128, 64), (288, 192, 96), (144, 512, 128), (144 * 3, 512, 512), (144 * 2, 512, 544),
           (144 * 2, 256, 576), (144 * 3, 512, 1024), (144 * 64, 512, 512), (144 * 64, 1536, 512), (144 * 64, 1024, 512),
-          (144 * 64, 512, 1024), (144 * 32, 512, 512), (144 * 32, 1536, 512)]
+          (144 * 64, 512, 1024), (144 * 32, 512, 512), (144 * 32, 1536, 512), (144 * 65, 512, 192), (144 * 40, 512, 224),
+          (144 * 66, 1024, 160), (144 * 66, 1024, 512)]
 
 
 @pytest.mark.parametrize('M,N,K', SHAPES)
@@ -81,7 +84,8 @@ def test_gemm_planes_identity_asymmetric():
     assert torch.equal(out.cpu(), w[:, :144].T.contiguous())
 
 
-@pytest.mark.parametrize('M,N,K', [(144 * 64, 1024, 512), (144 * 2, 1024, 512), (144 * 64, 512, 64)])
+@pytest.mark.parametrize('M,N,K', [(144 * 64, 1024, 512), (144 * 2, 1024, 512), (144 * 64, 512, 64), (144 * 65, 1024, 192),
+                                   (144 * 40, 1024, 224)])
 @pytest.mark.parametrize('nplane', [3, 2])
 @pytest.mark.parametrize('flags', [0, 1])
 def test_gemm_plane_output_is_the_cut_of_the_fp32_output(M, N, K, nplane, flags):
@@ -138,3 +142,17 @@ def test_shape_errors_are_raised_before_any_launch():
         ops.gemm_planes(ap, wp, 100, 64, 32)                            # M % 144
     with pytest.raises(_lib.RohmHipError):
         ops.gemm_planes(ap, wp, 144, 64, 32, nplane=4)
+
+
+def test_the_one_tile_per_workgroup_kernel_too():
+    """ROHM_PP_STREAM=0 (read at the first launch -> a child process) selects gemm_pp_kernel, which the default path only uses
+    for K < 192: the GEMM tests of this file must hold for it as well."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('ROHM_PP_STREAM') == '0':
+        pytest.skip('already the child')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_gpu_planes.py',
+                        '-k', 'gemm'], cwd=root, env=dict(os.environ, ROHM_PP_STREAM='0'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
