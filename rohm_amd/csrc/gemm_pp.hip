@@ -558,143 +558,187 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
             for (int c = 0; c < CB; ++c) pendq[u][c] = pendq[u + 1][c];
     };
 
-    // ---- prologue of the stream: chunks 0 and 1 in flight ---------------------------------------------------------------------------
-    dma(0);
-    bload(breg[0]);
-    pf_advance();
-    dma(1);
-    bload(breg[1]);
-    pf_advance();
-    PP_WAIT_VM_LGKM0(VMOPS);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-
-    constexpr int kMfma = 0x008, kVmem = 0x010;
-    Frag<NP> a0, a1, a2, a3;
-    int kc = 0;                           // chunk of the current tile being multiplied
-    int cm0 = 0, cn0 = 0, cseq = 0;       // current tile
-    tile_coords(0, cm0, cn0);
-    auto step = [&](auto s_tag, auto first_tag) {
-        constexpr int S = decltype(s_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr int SP = (S + 2) % 3;
-        const bool tile_first = (kc == 0), tile_last = (kc + 1 == nkc);
-        if constexpr (!FIRST) load_residual(drip);
-        // -- section 1: [previous chunk, first row block] + DMA of chunk g + 2
-        if constexpr (FIRST) {
-            aread(a1, S, r0 + 1);
-            dma(SP);
-        } else {
-            constexpr int GQ = (NM - 1) / PIECES;
-            mm_range(acc[0], a0, breg[SP], 0, 1);
-            PP_SB();
-            aread(a1, S, r0 + 1);
-            PP_SB();
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                mm_range(acc[0], a0, breg[SP], 1 + i * GQ, 1 + (i + 1) * GQ);
-                PP_SB();
-                dma_piece(SP, i);
-                PP_SB();
-            }
-            mm_range(acc[0], a0, breg[SP], 1 + PIECES * GQ, NM);
-            if (tile_first) {             // that was the last chunk of the previous tile: its first row block is complete now
-#pragma unroll                        // (no unit of that tile has gone out yet: the queue's last slot is still position 4)
-                for (int c = 0; c < CB; ++c) { pendq[4][c] = acc[0][c]; acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            }
-        }
-        PP_SB();
-        // -- section 2: row block r0 + 1, B fragments of chunk g + 2
-        mm_range(acc[1], a1, breg[S], 0, 1);
-        PP_SB();
-        aread(a2, S, r0 + 2);
-        PP_SB();
-        bload(breg[SP]);
-        mm_range(acc[1], a1, breg[S], 1, NM);
-#pragma unroll
-        for (int i = 0; i < CB * NP; ++i) {
-            __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NP), 1);
-            __builtin_amdgcn_sched_group_barrier(kVmem, 1, 1);
-        }
-        PP_SB();
+    // The two row halves run two instances of the whole stream (EARLY = true / false), chosen once per wave: inside the steps
+    // nothing depends on wm any more, so every step stays straight-line code (a run-time test there makes hipcc merge the
+    // wait-count state of the two paths and drain vmcnt(0) in the loop).  Both instances execute the same barriers.
+    auto run = [&](auto early_tag) {
+        constexpr bool EARLY = decltype(early_tag)::value;
+        // ---- prologue of the stream: chunks 0 and 1 in flight ---------------------------------------------------------------------------
+        dma(0);
+        bload(breg[0]);
         pf_advance();
-        // -- section 3: row block r0 + 2
-        mm_range(acc[2], a2, breg[S], 0, 1);
-        PP_SB();
-        aread(a1, S, r0 + 3);
-        aread(a3, S, 8);
-        PP_SB();
-        mm_range(acc[2], a2, breg[S], 1, NM);
-        PP_SB();
-        // -- section 4: row block r0 + 3 and the share of row block 8; the first row block is read for the next step
-        if constexpr (CB == 2) {
-            const Frag<NP> bh = b8(breg[S]);
-            mm_last(acc[3], a1, a3, breg[S], bh, 0, 1);
-            PP_SB();
-            aread(a0, S, r0);
-            PP_SB();
-            mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
-        } else {
-            mm_range(acc[3], a1, breg[S], 0, 1);
-            PP_SB();
-            aread(a0, S, r0);
-            PP_SB();
-            mm_range(acc[3], a1, breg[S], 1, NM);
-            if (wm == 0) {
-#pragma unroll
-                for (int q = 6 - NPROD; q < 6; ++q) acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
-            }
-        }
-        PP_SB();
-        // -- one unit of the pending tile goes out
-        if constexpr (!FIRST) {
-            if (drip < 5) {
-                // the residual of this unit was requested at the top of the step, before the step's VMOPS prefetch operations
-                if constexpr (EPI == EPI_BIAS_RES) PP_WAIT_VM_LGKM0(VMOPS);
-                store_front(drip);
-                ++drip;
-            }
-        }
-        if (tile_last) {
-            // hand the finished blocks over (the first row block follows after section 1 of the next step).  The launcher
-            // guarantees nkc >= 6, so the five units of the tile before have gone out by now.
-#pragma unroll
-            for (int j = 1; j < 4; ++j)
-#pragma unroll
-                for (int c = 0; c < CB; ++c) { pendq[j - 1][c] = acc[j][c]; acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            pendq[3][0] = acc8; acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
-            pm0 = cm0; pn0 = cn0; drip = 0;
-            kc = 0;
-            if (cseq + 1 < my_tiles) { ++cseq; tile_coords(cseq, cm0, cn0); }
-        } else {
-            ++kc;
-        }
-        PP_SB();
+        dma(1);
+        bload(breg[1]);
+        pf_advance();
         PP_WAIT_VM_LGKM0(VMOPS);
         __builtin_amdgcn_s_barrier();
-        PP_SB();
+        __builtin_amdgcn_sched_barrier(0);
+
+        constexpr int kMfma = 0x008, kVmem = 0x010;
+        Frag<NP> a0, a1, a2, a3;
+        int kc = 0;                           // chunk of the current tile being multiplied
+        int cm0 = 0, cn0 = 0, cseq = 0;       // current tile
+        tile_coords(0, cm0, cn0);
+        auto step = [&](auto s_tag, auto first_tag) {
+            constexpr int S = decltype(s_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr int SP = (S + 2) % 3;
+            const bool tile_first = (kc == 0), tile_last = (kc + 1 == nkc);
+            if constexpr (!FIRST) load_residual(drip);
+            // The two waves of a SIMD (row halves wm = 0 / 1) leave every barrier together and run the same code: without help they
+            // would issue their DMA pieces and B loads at the same moment and the matrix core would idle behind both.  So the
+            // halves are shifted against each other: wm = 0 issues its DMA in section 1 and its B loads in section 2, wm = 1 in
+            // sections 3 and 4 -- while one wave of the SIMD feeds the memory pipeline the other one feeds the matrix core.
+            // -- section 1: [previous chunk, first row block] (+ DMA of chunk g + 2)
+            if constexpr (FIRST) {
+                aread(a1, S, r0 + 1);
+                dma(SP);
+            } else {
+                constexpr int GQ = (NM - 1) / PIECES;
+                mm_range(acc[0], a0, breg[SP], 0, 1);
+                PP_SB();
+                aread(a1, S, r0 + 1);
+                PP_SB();
+                if constexpr (EARLY) {
+    #pragma unroll
+                    for (int i = 0; i < PIECES; ++i) {
+                        mm_range(acc[0], a0, breg[SP], 1 + i * GQ, 1 + (i + 1) * GQ);
+                        PP_SB();
+                        dma_piece(SP, i);
+                        PP_SB();
+                    }
+                    mm_range(acc[0], a0, breg[SP], 1 + PIECES * GQ, NM);
+                } else {
+                    mm_range(acc[0], a0, breg[SP], 1, NM);
+                }
+                if (tile_first) {             // that was the last chunk of the previous tile: its first row block is complete now
+    #pragma unroll                        // (no unit of that tile has gone out yet: the queue's last slot is still position 4)
+                    for (int c = 0; c < CB; ++c) { pendq[4][c] = acc[0][c]; acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                }
+            }
+            PP_SB();
+            // -- section 2: row block r0 + 1 (+ B fragments of chunk g + 2: their registers were last read in section 1)
+            mm_range(acc[1], a1, breg[S], 0, 1);
+            PP_SB();
+            aread(a2, S, r0 + 2);
+            PP_SB();
+            if constexpr (FIRST || EARLY) {
+                bload(breg[SP]);
+                mm_range(acc[1], a1, breg[S], 1, NM);
+    #pragma unroll
+                for (int i = 0; i < CB * NP; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NP), 1);
+                    __builtin_amdgcn_sched_group_barrier(kVmem, 1, 1);
+                }
+            } else {
+                mm_range(acc[1], a1, breg[S], 1, NM);
+            }
+            PP_SB();
+            // -- section 3: row block r0 + 2 (+ DMA, second row half)
+            mm_range(acc[2], a2, breg[S], 0, 1);
+            PP_SB();
+            aread(a1, S, r0 + 3);
+            aread(a3, S, 8);
+            PP_SB();
+            if constexpr (!FIRST && !EARLY) {
+                constexpr int GQ = (NM - 1) / PIECES;
+    #pragma unroll
+                for (int i = 0; i < PIECES; ++i) {
+                    mm_range(acc[2], a2, breg[S], 1 + i * GQ, 1 + (i + 1) * GQ);
+                    PP_SB();
+                    dma_piece(SP, i);
+                    PP_SB();
+                }
+                mm_range(acc[2], a2, breg[S], 1 + PIECES * GQ, NM);
+            } else {
+                mm_range(acc[2], a2, breg[S], 1, NM);
+            }
+            PP_SB();
+            // -- section 4: row block r0 + 3 and the share of row block 8 (+ B loads, second row half); the first row block is read
+            //    for the next step
+            if constexpr (CB == 2) {
+                const Frag<NP> bh = b8(breg[S]);
+                mm_last(acc[3], a1, a3, breg[S], bh, 0, 1);
+                PP_SB();
+                aread(a0, S, r0);
+                PP_SB();
+                if constexpr (!FIRST && !EARLY) {
+                    bload(breg[SP]);
+                    mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
+    #pragma unroll
+                    for (int i = 0; i < CB * NP; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(kMfma, (3 * NPROD - 1) / (CB * NP), 3);
+                        __builtin_amdgcn_sched_group_barrier(kVmem, 1, 3);
+                    }
+                } else {
+                    mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
+                }
+            } else {
+                mm_range(acc[3], a1, breg[S], 0, 1);
+                PP_SB();
+                aread(a0, S, r0);
+                PP_SB();
+                if constexpr (!FIRST && !EARLY) bload(breg[SP]);
+                mm_range(acc[3], a1, breg[S], 1, NM);
+                if (wm == 0) {
+    #pragma unroll
+                    for (int q = 6 - NPROD; q < 6; ++q) acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
+                }
+            }
+            PP_SB();
+            pf_advance();
+            // -- one unit of the pending tile goes out
+            if constexpr (!FIRST) {
+                if (drip < 5) {
+                    // the residual of this unit was requested at the top of the step, before the step's VMOPS prefetch operations
+                    if constexpr (EPI == EPI_BIAS_RES) PP_WAIT_VM_LGKM0(VMOPS);
+                    store_front(drip);
+                    ++drip;
+                }
+            }
+            if (tile_last) {
+                // hand the finished blocks over (the first row block follows after section 1 of the next step).  The launcher
+                // guarantees nkc >= 6, so the five units of the tile before have gone out by now.
+    #pragma unroll
+                for (int j = 1; j < 4; ++j)
+    #pragma unroll
+                    for (int c = 0; c < CB; ++c) { pendq[j - 1][c] = acc[j][c]; acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                pendq[3][0] = acc8; acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
+                pm0 = cm0; pn0 = cn0; drip = 0;
+                kc = 0;
+                if (cseq + 1 < my_tiles) { ++cseq; tile_coords(cseq, cm0, cn0); }
+            } else {
+                ++kc;
+            }
+            PP_SB();
+            PP_WAIT_VM_LGKM0(VMOPS);
+            __builtin_amdgcn_s_barrier();
+            PP_SB();
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        step(I0{}, std::true_type{});
+        int g = 1;
+        for (; g + 3 <= total; g += 3) {              // straight-line body: with steps under conditions inside the loop hipcc's wait
+            step(I1{}, std::false_type{});            // bookkeeping merges the paths and drains vmcnt(0) at the loop header
+            step(I2{}, std::false_type{});
+            step(I0{}, std::false_type{});
+        }
+        if (total - g >= 1) step(I1{}, std::false_type{});
+        if (total - g == 2) step(I2{}, std::false_type{});
+        const int last = (total - 1) % 3;             // stage of the last chunk: its first row block is still to be multiplied
+        if (last == 0) mm_range(acc[0], a0, breg[0], 0, NM);
+        else if (last == 1) mm_range(acc[0], a0, breg[1], 0, NM);
+        else mm_range(acc[0], a0, breg[2], 0, NM);
+        PP_WAIT_VM_LGKM0(0);                          // the re-fetched tail chunks: nothing may land in LDS after the workgroup ends
+        // the last tile was handed to the queue by its last step, except for the first row block
+    #pragma unroll
+        for (int c = 0; c < CB; ++c) pendq[4][c] = acc[0][c];      // drip == 0 here: the tile ended with the last step
+        for (; drip < 5; ++drip) { load_residual(drip); store_front(drip); }
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    step(I0{}, std::true_type{});
-    int g = 1;
-    for (; g + 3 <= total; g += 3) {              // straight-line body: with steps under conditions inside the loop hipcc's wait
-        step(I1{}, std::false_type{});            // bookkeeping merges the paths and drains vmcnt(0) at the loop header
-        step(I2{}, std::false_type{});
-        step(I0{}, std::false_type{});
-    }
-    if (total - g >= 1) step(I1{}, std::false_type{});
-    if (total - g == 2) step(I2{}, std::false_type{});
-    const int last = (total - 1) % 3;             // stage of the last chunk: its first row block is still to be multiplied
-    if (last == 0) mm_range(acc[0], a0, breg[0], 0, NM);
-    else if (last == 1) mm_range(acc[0], a0, breg[1], 0, NM);
-    else mm_range(acc[0], a0, breg[2], 0, NM);
-    PP_WAIT_VM_LGKM0(0);                          // the re-fetched tail chunks: nothing may land in LDS after the workgroup ends
-    // the last tile was handed to the queue by its last step, except for the first row block
-#pragma unroll
-    for (int c = 0; c < CB; ++c) pendq[4][c] = acc[0][c];      // drip == 0 here: the tile ended with the last step
-    for (; drip < 5; ++drip) { load_residual(drip); store_front(drip); }
+    if (wm == 0) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 // X[rows][K] fp32 -> planes; one thread per 16-byte unit, consecutive threads = consecutive lanes of a fragment

@@ -9,9 +9,9 @@
 //                     relative transforms A[m][j] = [G_j | P_j - G_j J_j] and the pose feature (R_j - I, j >= 1).
 //   gemm_f32_kernel   pose blendshapes as a fp32-MFMA GEMM: off[N, V*3] = pose_feature[N, 486] . posedirs
 //                     (30.5 MFLOP per frame -- the one dense contraction of the body model).
-//   lbs_skin_kernel   one thread per (frame, vertex): v_template + shapedirs.beta + off, blended transform
-//                     sum_j w[v][j] A[m][j] from LDS, + transl.  HBM-bound: 12 B read (off) + 12 B written per vertex;
-//                     weights / bases are L2-resident and read coalesced (weights stored [J, V]).
+//   lbs_skin_kernel   one thread per vertex x 8 frames: v_template + shapedirs.beta + off, blended transform
+//                     sum_j w[v][j] A[m][j] with A through the scalar cache, + transl.  Algorithmic traffic 12 B read (off) +
+//                     12 B written per vertex-frame; the per-vertex constants are read once per 8 frames (weights stored [J, V]).
 // Expression coefficients are taken as zero (every reference call site passes zeros, :383-388).
 #include "common.h"
 #include "smplx_fk.h"
@@ -115,39 +115,65 @@ __global__ __launch_bounds__(64) void lbs_finish_pose_kernel(const float* __rest
     for (int c = 0; c < 3; ++c) o[9 + c] -= w[c];
 }
 
+// Skinning.  One thread per vertex, SKIN_F consecutive frames per block.  Everything that belongs to the vertex (its J
+// skinning weights, v_template, the ten shape directions) is loaded ONCE and used for all frames of the block; everything that
+// belongs to a frame (the relative joint transforms A[n][j], betas, transl) is the same for every lane, so its addresses are
+// wave-uniform and hipcc fetches it through the scalar cache -- the blend T = sum_j w[v][j] A[n][j] is J x 12 v_fma with a
+// scalar operand, no LDS and no per-frame re-read of per-vertex data.  (The round-2 kernel was one block per frame: 364 B of
+// L2 traffic and 660 broadcast LDS reads per vertex-frame for 24 B of payload -- 2.74 ms for 4576 frames, 0.05 of HBM.)
+// Sums run over j in ascending order with fmaf, as before: results are bit-identical to the one-frame kernel.
+constexpr int SKIN_F = 8;
+
 __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ vt, const float* __restrict__ sd,
                                                        const float* __restrict__ wT, const float* __restrict__ off, int ldo,
                                                        const float* __restrict__ A, const float* __restrict__ betas,
-                                                       const float* __restrict__ transl, int J, int V,
+                                                       const float* __restrict__ transl, int J, int V, int N,
                                                        float* __restrict__ verts) {
-    __shared__ float sA[kMaxJ * 12];
-    __shared__ float sb[NBETA + 3];
-    const int n = blockIdx.y;
-    for (int i = threadIdx.x; i < J * 12; i += blockDim.x) sA[i] = A[(size_t)n * J * 12 + i];
-    if (threadIdx.x < NBETA) sb[threadIdx.x] = betas[(size_t)n * NBETA + threadIdx.x];
-    if (threadIdx.x >= 32 && threadIdx.x < 35) sb[NBETA + threadIdx.x - 32] = transl[(size_t)n * 3 + threadIdx.x - 32];
-    __syncthreads();
+    const int n0 = blockIdx.y * SKIN_F;
+    const int nf = (N - n0 < SKIN_F) ? N - n0 : SKIN_F;        // frames of this block (uniform)
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
-    float p[3];
+    float T[SKIN_F][12];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float x = vt[v * 3 + c];
+    for (int f = 0; f < SKIN_F; ++f)
 #pragma unroll
-        for (int k = 0; k < NBETA; ++k) x = fmaf(sd[((size_t)v * 3 + c) * NBETA + k], sb[k], x);
-        p[c] = x + off[(size_t)n * ldo + v * 3 + c];
-    }
-    float T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+        for (int i = 0; i < 12; ++i) T[f][i] = 0.f;
     for (int j = 0; j < J; ++j) {
         const float w = wT[(size_t)j * V + v];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = fmaf(w, sA[j * 12 + i], T[i]);
+        for (int f = 0; f < SKIN_F; ++f) {
+            if (f < nf) {
+                const float* a = A + ((size_t)(n0 + f) * J + j) * 12;       // wave-uniform: scalar loads
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[f][i] = fmaf(w, a[i], T[f][i]);
+            }
+        }
+    }
+    float base[3], sdv[3][NBETA];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        base[c] = vt[v * 3 + c];
+#pragma unroll
+        for (int k = 0; k < NBETA; ++k) sdv[c][k] = sd[((size_t)v * 3 + c) * NBETA + k];
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        verts[((size_t)n * V + v) * 3 + c] = T[c * 3] * p[0] + T[c * 3 + 1] * p[1] + T[c * 3 + 2] * p[2] + T[9 + c] + sb[NBETA + c];
+    for (int f = 0; f < SKIN_F; ++f) {
+        if (f < nf) {
+            const int n = n0 + f;
+            float p[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float x = base[c];
+#pragma unroll
+                for (int k = 0; k < NBETA; ++k) x = fmaf(sdv[c][k], betas[(size_t)n * NBETA + k], x);
+                p[c] = x + off[(size_t)n * ldo + v * 3 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                verts[((size_t)n * V + v) * 3 + c] =
+                    T[f][c * 3] * p[0] + T[f][c * 3 + 1] * p[1] + T[f][c * 3 + 2] * p[2] + T[f][9 + c] + transl[(size_t)n * 3 + c];
+        }
+    }
 }
 
 // dst[c][r] = src[r][c] for r < R, c < Cc; dst rows padded to ldd (pre-zeroed)
@@ -257,8 +283,8 @@ int rohm_smplx_forward(const rohm_smplx_t* h, const float* pose, int n_pose, int
     int rc = launch_gemm(g, EPI_BIAS, s);
     if (rc) return rc;
     prof::Scope ps("lbs_skin", 2.0 * N * h->V * (h->J * 12 + 30 + 12), 24.0 * N * h->V, s);
-    hipLaunchKernelGGL(lbs_skin_kernel, dim3((h->V + 255) / 256, N), dim3(256), 0, s, h->d_vt, h->d_sd, h->d_wT, off, h->NP, A,
-                       betas, transl, h->J, h->V, verts);
+    hipLaunchKernelGGL(lbs_skin_kernel, dim3((h->V + 255) / 256, (N + SKIN_F - 1) / SKIN_F), dim3(256), 0, s, h->d_vt, h->d_sd,
+                       h->d_wT, off, h->NP, A, betas, transl, h->J, h->V, N, verts);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
