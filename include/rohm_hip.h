@@ -55,6 +55,7 @@ typedef struct {
     double flops;
     double bytes;
 } rohm_profile_row;
+/* The profiler is one process-wide recorder: start / stop / detail must not overlap launches issued by other host threads. */
 int rohm_profile_start(int step_stride);
 int rohm_profile_stop(rohm_profile_row* rows, int max_rows, int* n_rows);
 /* on != 0: GEMM / conv-GEMM / GroupNorm launches are recorded under a label that carries their shape ("conv_gemm/64 M576
@@ -176,10 +177,12 @@ int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float*
  *                             sigma = exp(0.5*posterior_log_variance_clipped) (0 when t == 0)
  *   noise    [n_steps, B, C_in, 1, T] injected Gaussian noise (row i used at loop step i)
  *   x0_last  optional [B, C_in, 1, T]: pred_xstart of the last executed step (early_stop result)
+ *   x_in_last optional [B, C_in, 1, T]: the INPUT x_t of the last executed step -- what the reference leaves in
+ *            batch['x_t'] after a run (p_mean_variance, gaussian_diffusion_posenet.py:264)
  * All per-step scalars are host arrays (the loop is driven from the host, kernels stay async). */
 int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* cond, const int64_t* t_model,
-                             const float* coef, const float* noise, float* x0_last, int n_steps, int B,
-                             int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
+                             const float* coef, const float* noise, float* x0_last, float* x_in_last, int n_steps,
+                             int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
 
 /* ------------------------------------------------------------------------- TrajNet / TrajControl
  * model/trajnet.py:10-275 + model/heads.py:12-106: conv U-Net x0-predictor of the 13-channel trajectory,
@@ -215,10 +218,11 @@ int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float*
                          rohm_stream_t stream);
 
 /* Device-resident DDPM loop (diffusion/gaussian_diffusion_trajnet.py:559-627, 440-466); arguments as
- * rohm_posenet_sample_loop with tensors of shape [B, T, c_traj]. */
+ * rohm_posenet_sample_loop with tensors of shape [B, T, c_traj] (x0_last / x_in_last optional, as there). */
 int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* cond, const float* control_cond,
                              const int64_t* t_model, const float* coef, const float* noise, float* x0_last,
-                             int n_steps, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
+                             float* x_in_last, int n_steps, int B, int T, void* ws, size_t ws_bytes,
+                             rohm_stream_t stream);
 
 /* ------------------------------------------------------------------------- SMPL-X + guidance
  * Joints-only SMPL-X (third-party smplx==0.1.28 `SMPLX.forward` / `lbs`, called from

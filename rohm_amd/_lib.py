@@ -82,7 +82,7 @@ SIGNATURES = {
     'rohm_posenet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_posenet_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p, C.c_void_p,
-                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                            C.c_void_p]),
     'rohm_trajnet_create': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(TrajNetWeights), C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int]),
@@ -92,7 +92,7 @@ SIGNATURES = {
     'rohm_trajnet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_trajnet_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p,
-                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.c_size_t, C.c_void_p]),
     'rohm_smplx_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int]),

@@ -1,4 +1,5 @@
 // C-ABI glue: error channel + the building-block entry points declared in include/rohm_hip.h.
+#include <mutex>
 #include <string>
 #include <string.h>
 #include <vector>
@@ -48,6 +49,8 @@ static bool g_detail = false;
 bool detail() { return g_detail && g_active; }
 const char* intern(const char* s) {        // stable storage for labels composed at launch time (detail mode only)
     static std::vector<std::string*> pool;
+    static std::mutex mu;                  // launches may come from several host threads (one stream each)
+    std::lock_guard<std::mutex> lock(mu);
     for (std::string* q : pool)
         if (*q == s) return q->c_str();
     pool.push_back(new std::string(s));

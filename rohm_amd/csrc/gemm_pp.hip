@@ -325,6 +325,11 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
 // a second register set (`pend`) and the next tile starts at once -- the stores of the finished tile are DRIPPED out one unit
 // (one 16-row block of the wave) per chunk of the next tile, between its MFMAs.  Only the last tile of a workgroup has an
 // exposed epilogue.
+// What was measured around this kernel in round 3 and did NOT pay (NOTES.md, profiles/r3_f_*): eight waves side by side along N
+// (no B fragment loaded twice: 51 instead of 75 KB of operands per chunk) with the A tile by LDS-DMA and, in a second variant, through
+// registers + ds_write_b128 -- both 1.39-1.49 us per chunk against 1.30-1.41 here: the loop is bound by the MFMA issue rate under DVFS
+// (a bare stream of these MFMAs on random operands runs at 1.7-2.0 GHz, 8.4-10.3 ns per MFMA; this loop needs 12.2-13 ns), not by
+// the L2 -> CU path, the LDS-DMA rate or LDS bandwidth.
 // Counted waits with stores in the stream: on gfx9 stores share vmcnt with loads; loads return in order among loads, so
 // `vmcnt(n)` with n <= (loads issued since the data we need) can never be satisfied while an older load is outstanding,
 // whatever order the stores complete in.  Every step waits vmcnt(VMOPS) = the DMA pieces + B loads of that step.
@@ -781,15 +786,16 @@ int launch_pp(const PlaneGemmParams& p, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_stream_kernel<EPI, NP, CB, POUT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+
         attr_set[dev] = true;
     }
     static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv"};
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64"};
     prof::Scope ps(CB == 1 ? kNames64[EPI] : kNames[EPI], 2.0 * p.M * p.N * p.K,
                    2.0 * NP * ((double)p.M * p.K + (double)p.N * p.K) + (p.C ? 4.0 : 0.0) * p.M * p.N + (p.Cp ? 2.0 * NP : 0.0) * p.M * p.N, s);
+    const int grid = tiles < kStreamCUs ? tiles : kStreamCUs;      // persistent: one workgroup per CU (a multiple of 8: a
+                                                                   // workgroup's tiles stay on its XCD), or one per tile if fewer
     if (stream) {
-        // persistent workgroups: one per CU (a multiple of 8, so a workgroup's tiles stay on its XCD), or one per tile if fewer
-        const int grid = tiles < kStreamCUs ? tiles : kStreamCUs;
         hipLaunchKernelGGL((gemm_pp_stream_kernel<EPI, NP, CB, POUT>), dim3(grid), dim3(QNT), lds, s, p);
     } else {
         hipLaunchKernelGGL((gemm_pp_kernel<EPI, NP, CB, POUT>), dim3(tiles), dim3(QNT), lds, s, p);

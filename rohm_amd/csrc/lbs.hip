@@ -10,8 +10,8 @@
 //   gemm_f32_kernel   pose blendshapes as a fp32-MFMA GEMM: off[N, V*3] = pose_feature[N, 486] . posedirs
 //                     (30.5 MFLOP per frame -- the one dense contraction of the body model).
 //   lbs_skin_kernel   one thread per vertex x 8 frames: v_template + shapedirs.beta + off, blended transform
-//                     sum_j w[v][j] A[m][j] with A through the scalar cache, + transl.  Algorithmic traffic 12 B read (off) +
-//                     12 B written per vertex-frame; the per-vertex constants are read once per 8 frames (weights stored [J, V]).
+//                     sum_j w[v][j] A[m][j] (A broadcast from LDS), + transl.  Algorithmic traffic 12 B read (off) + 12 B written
+//                     per vertex-frame; per-vertex constants are read once per 8 frames (weights stored [J, V]).
 // Expression coefficients are taken as zero (every reference call site passes zeros, :383-388).
 #include "common.h"
 #include "smplx_fk.h"
@@ -115,13 +115,14 @@ __global__ __launch_bounds__(64) void lbs_finish_pose_kernel(const float* __rest
     for (int c = 0; c < 3; ++c) o[9 + c] -= w[c];
 }
 
-// Skinning.  One thread per vertex, SKIN_F consecutive frames per block.  Everything that belongs to the vertex (its J
-// skinning weights, v_template, the ten shape directions) is loaded ONCE and used for all frames of the block; everything that
-// belongs to a frame (the relative joint transforms A[n][j], betas, transl) is the same for every lane, so its addresses are
-// wave-uniform and hipcc fetches it through the scalar cache -- the blend T = sum_j w[v][j] A[n][j] is J x 12 v_fma with a
-// scalar operand, no LDS and no per-frame re-read of per-vertex data.  (The round-2 kernel was one block per frame: 364 B of
-// L2 traffic and 660 broadcast LDS reads per vertex-frame for 24 B of payload -- 2.74 ms for 4576 frames, 0.05 of HBM.)
-// Sums run over j in ascending order with fmaf, as before: results are bit-identical to the one-frame kernel.
+// Skinning.  One thread per vertex, SKIN_F consecutive frames per block.  What belongs to the vertex -- its J skinning weights,
+// v_template, the ten shape directions -- is loaded ONCE per block and reused for all its frames (a weight lives in one register
+// while it is blended into the SKIN_F transforms the thread accumulates); what belongs to a frame -- the relative joint transforms
+// A[n][j], betas, transl -- is staged in LDS and read as broadcasts (every lane wants the same 16 bytes).  Per vertex-frame that
+// leaves 12 B read (off) + 12 B written against J x 12 = 660 v_fma: the VALU, not memory, bounds the kernel.  (Round 2: one block
+// per frame, 364 B of L2 traffic per vertex-frame for the same 24 B of payload, 2.74 ms for 4576 frames.  Also measured and dropped:
+// joint transforms through the scalar cache instead of LDS -- latency-bound, 4.1 ms.)  Sums run over j in ascending order with fmaf:
+// bit-identical to the one-frame kernel.
 constexpr int SKIN_F = 8;
 
 __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ vt, const float* __restrict__ sd,
@@ -129,8 +130,20 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
                                                        const float* __restrict__ A, const float* __restrict__ betas,
                                                        const float* __restrict__ transl, int J, int V, int N,
                                                        float* __restrict__ verts) {
+    extern __shared__ __attribute__((aligned(16))) float sA[];       // [J][SKIN_F][12], then betas [SKIN_F][NBETA], transl [SKIN_F][3]
     const int n0 = blockIdx.y * SKIN_F;
-    const int nf = (N - n0 < SKIN_F) ? N - n0 : SKIN_F;        // frames of this block (uniform)
+    const int nf = (N - n0 < SKIN_F) ? N - n0 : SKIN_F;              // frames of this block (uniform)
+    float* sb = sA + SKIN_F * J * 12;
+    float* st = sb + SKIN_F * NBETA;
+    // joint-major image: the SKIN_F transforms of joint j are contiguous (one run of broadcast reads per joint); frames past
+    // the end of the batch are zero-filled (their results are not stored)
+    for (int i = threadIdx.x; i < SKIN_F * J * 12; i += blockDim.x) {
+        const int j = i / (SKIN_F * 12), r = i % (SKIN_F * 12), f = r / 12, c = r % 12;
+        sA[i] = (f < nf) ? A[((size_t)(n0 + f) * J + j) * 12 + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < SKIN_F * NBETA; i += blockDim.x) sb[i] = (i < nf * NBETA) ? betas[(size_t)n0 * NBETA + i] : 0.f;
+    for (int i = threadIdx.x; i < SKIN_F * 3; i += blockDim.x) st[i] = (i < nf * 3) ? transl[(size_t)n0 * 3 + i] : 0.f;
+    __syncthreads();
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     float T[SKIN_F][12];
@@ -140,14 +153,11 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
         for (int i = 0; i < 12; ++i) T[f][i] = 0.f;
     for (int j = 0; j < J; ++j) {
         const float w = wT[(size_t)j * V + v];
+        const float* a = sA + j * (SKIN_F * 12);
 #pragma unroll
-        for (int f = 0; f < SKIN_F; ++f) {
-            if (f < nf) {
-                const float* a = A + ((size_t)(n0 + f) * J + j) * 12;       // wave-uniform: scalar loads
+        for (int f = 0; f < SKIN_F; ++f)
 #pragma unroll
-                for (int i = 0; i < 12; ++i) T[f][i] = fmaf(w, a[i], T[f][i]);
-            }
-        }
+            for (int i = 0; i < 12; ++i) T[f][i] = fmaf(w, a[f * 12 + i], T[f][i]);
     }
     float base[3], sdv[3][NBETA];
 #pragma unroll
@@ -160,18 +170,18 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
     for (int f = 0; f < SKIN_F; ++f) {
         if (f < nf) {
             const int n = n0 + f;
-            float p[3];
+            float pq[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float x = base[c];
 #pragma unroll
-                for (int k = 0; k < NBETA; ++k) x = fmaf(sdv[c][k], betas[(size_t)n * NBETA + k], x);
-                p[c] = x + off[(size_t)n * ldo + v * 3 + c];
+                for (int k = 0; k < NBETA; ++k) x = fmaf(sdv[c][k], sb[f * NBETA + k], x);
+                pq[c] = x + off[(size_t)n * ldo + v * 3 + c];
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 verts[((size_t)n * V + v) * 3 + c] =
-                    T[f][c * 3] * p[0] + T[f][c * 3 + 1] * p[1] + T[f][c * 3 + 2] * p[2] + T[f][9 + c] + transl[(size_t)n * 3 + c];
+                    T[f][c * 3] * pq[0] + T[f][c * 3 + 1] * pq[1] + T[f][c * 3 + 2] * pq[2] + T[f][9 + c] + st[f * 3 + c];
         }
     }
 }
@@ -283,8 +293,10 @@ int rohm_smplx_forward(const rohm_smplx_t* h, const float* pose, int n_pose, int
     int rc = launch_gemm(g, EPI_BIAS, s);
     if (rc) return rc;
     prof::Scope ps("lbs_skin", 2.0 * N * h->V * (h->J * 12 + 30 + 12), 24.0 * N * h->V, s);
-    hipLaunchKernelGGL(lbs_skin_kernel, dim3((h->V + 255) / 256, (N + SKIN_F - 1) / SKIN_F), dim3(256), 0, s, h->d_vt, h->d_sd,
-                       h->d_wT, off, h->NP, A, betas, transl, h->J, h->V, N, verts);
+    const dim3 sgrid((h->V + 255) / 256, (N + SKIN_F - 1) / SKIN_F);
+    const size_t slds = (size_t)SKIN_F * (h->J * 12 + NBETA + 3) * sizeof(float);      // 21.5 KB for 55 joints
+    hipLaunchKernelGGL(lbs_skin_kernel, sgrid, dim3(256), slds, s, h->d_vt, h->d_sd, h->d_wT, off, h->NP, A, betas, transl, h->J,
+                       h->V, N, verts);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }

@@ -585,8 +585,8 @@ int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float*
 }
 
 int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* cond, const int64_t* t_model,
-                             const float* coef, const float* noise, float* x0_last, int n_steps, int B, int T,
-                             void* ws, size_t ws_bytes, rohm_stream_t stream) {
+                             const float* coef, const float* noise, float* x0_last, float* x_in_last, int n_steps, int B,
+                             int T, void* ws, size_t ws_bytes, rohm_stream_t stream) {
     int rc = check_shape(h, B, T);
     if (rc) return rc;
     ROHM_ARG_CHECK(x && cond && t_model && coef && ws, "posenet_sample_loop: null argument");
@@ -607,6 +607,8 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
         ROHM_ARG_CHECK(sigma == 0.f || noise, "posenet_sample_loop: noise is required when sigma != 0");
+        if (x_in_last && i == n_steps - 1)       // the reference keeps the input of the last step in batch['x_t']
+            ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((rc = launch_pack(h, x, w.apack, B, T, 0, s))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
         if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s))) return rc;

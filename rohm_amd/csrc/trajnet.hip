@@ -14,6 +14,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <atomic>
 #include "common.h"
 
 namespace rohm {
@@ -429,21 +430,23 @@ struct SplitInfo { int S = 1; size_t slab = 0; int ldp = 0; const float* base = 
 // Launch shape of the latency-bound convolutions (rohm_trajnet_tune): workgroups per CU the conv GEMMs may occupy (a
 // 144 x 64 tile needs 60 KB of LDS, so two fit a CU; one is pinned by padding the LDS request) and the fewest K chunks a
 // split-K slice may get.
-static int g_conv_wg_per_cu = 1;
-static int g_split_min_chunks = 2;      // measured: B = 32 loop 69.0 ms at 4, 66.7 at 2; B = 1 54.1 / 49.6
-static int g_split_pow2 = 0;      // 1: split counts are powers of two, so that split = block % S stays tied to XCD = block % 8
+static std::atomic<int> g_conv_wg_per_cu{1};      // launch-shape knobs (rohm_trajnet_tune): read by every launch, possibly from
+static std::atomic<int> g_split_min_chunks{2};    // several host threads (one stream / workspace each) -> atomics, relaxed
+// g_split_min_chunks:      // measured: B = 32 loop 69.0 ms at 4, 66.7 at 2; B = 1 54.1 / 49.6
+static std::atomic<int> g_split_pow2{0};      // 1: split counts are powers of two, so that split = block % S stays tied to XCD = block % 8
 
 static void plan_split(GemmParams& g, float* buf = nullptr, SplitInfo* defer = nullptr) {
     const int tm = (g.M + 143) / 144;
     const int bn = (tm * ((g.N + 127) / 128) >= 256 && g.N % 128 == 0) ? 128 : 64;
     const int tiles = tm * ((g.N + bn - 1) / bn);
-    const int slots = 256 * g_conv_wg_per_cu;
-    g.wg_per_cu = (tiles <= slots) ? g_conv_wg_per_cu : 1;      // multi-round grids keep one workgroup per CU (gemm_f32.hip)
+    const int wg_per_cu = g_conv_wg_per_cu.load(std::memory_order_relaxed);
+    const int slots = 256 * wg_per_cu;
+    g.wg_per_cu = (tiles <= slots) ? wg_per_cu : 1;      // multi-round grids keep one workgroup per CU (gemm_f32.hip)
     if (!buf) buf = tl_splitk;
     if (!buf) return;
     const int nk = g.K / 32;
-    int S = std::min(slots / tiles, nk / g_split_min_chunks);
-    if (g_split_pow2 && S > 1) S = 1 << (31 - __builtin_clz((unsigned)S));
+    int S = std::min(slots / tiles, nk / g_split_min_chunks.load(std::memory_order_relaxed));
+    if (g_split_pow2.load(std::memory_order_relaxed) && S > 1) S = 1 << (31 - __builtin_clz((unsigned)S));
     const int ldp = (g.N + 3) / 4 * 4;
     if (tiles > slots / 2 || S < 2 || (size_t)S * g.M * ldp > kSplitKFloats) return;
     g.ksplit = S; g.partial = buf; g.ld_partial = ldp;
@@ -790,7 +793,7 @@ static bool graph_replay_ok(int n_steps) {
 // stream torch hands out by default, so the loop runs on a private non-blocking stream fenced with events against
 // the caller's stream.  Returns ROHM_ERR_UNSUPPORTED (nothing enqueued) if capture cannot start.
 static int sample_loop_graph(const rohm_trajnet* h, const TWs& w, float* x, const float* noise, const int64_t* t_model,
-                             const float* coef, float* x0_last, int n_steps, int B, int T, size_t M, size_t n,
+                             const float* coef, float* x0_last, float* x_in_last, int n_steps, int B, int T, size_t M, size_t n,
                              hipStream_t caller) {
     static thread_local hipStream_t gs = nullptr;
     static thread_local hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -813,6 +816,8 @@ static int sample_loop_graph(const rohm_trajnet* h, const TWs& w, float* x, cons
         return launch_advance_counter(w.step_ctr, s);
     };
     int rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, gs);     // x_T; afterwards the tail kernel keeps the padded copy current
+    if (!rc && x_in_last && n_steps == 1)
+        ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, gs));
     if (!rc) rc = one_step(gs);                // step 0 directly (also sets every kernel's launch attributes)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -826,6 +831,8 @@ static int sample_loop_graph(const rohm_trajnet* h, const TWs& w, float* x, cons
         }
         if (!captured) (void)hipGetLastError();        // plain launches on the private stream instead
         for (int i = 1; i < n_steps && !rc; ++i) {
+            if (x_in_last && i == n_steps - 1 &&
+                hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, gs) != hipSuccess) { rc = ROHM_ERR_HIP; break; }
             if (captured) rc = (hipGraphLaunch(exec, gs) == hipSuccess) ? ROHM_OK : ROHM_ERR_HIP;
             else rc = one_step(gs);
         }
@@ -1088,9 +1095,9 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
 int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks, int split_pow2) {
     ROHM_ARG_CHECK(conv_wg_per_cu >= 1 && conv_wg_per_cu <= 2 && split_min_chunks >= 1 && split_min_chunks <= 64,
                    "trajnet_tune: conv_wg_per_cu must be 1 or 2, split_min_chunks 1..64");
-    g_conv_wg_per_cu = conv_wg_per_cu;
-    g_split_min_chunks = split_min_chunks;
-    g_split_pow2 = split_pow2 ? 1 : 0;
+    g_conv_wg_per_cu.store(conv_wg_per_cu, std::memory_order_relaxed);
+    g_split_min_chunks.store(split_min_chunks, std::memory_order_relaxed);
+    g_split_pow2.store(split_pow2 ? 1 : 0, std::memory_order_relaxed);
     return ROHM_OK;
 }
 
@@ -1135,7 +1142,7 @@ int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float*
 
 int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* cond, const float* control_cond,
                              const int64_t* t_model, const float* coef, const float* noise, float* x0_last,
-                             int n_steps, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream) {
+                             float* x_in_last, int n_steps, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream) {
     int rc = check_t(h, B, T);
     if (rc) return rc;
     ROHM_ARG_CHECK(x && cond && t_model && coef && ws, "trajnet_sample_loop: null argument");
@@ -1163,7 +1170,7 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         // hipGraph replay (opt-in, see graph_replay_ok): one denoising step is captured into a hipGraph whose kernels read
         // the per-step values (timestep, c1 / c2 / sigma, noise slice) from device tables through a device-side step
         // counter, and the graph is replayed for the remaining steps.
-        rc = sample_loop_graph(h, w, x, noise, t_model, coef, x0_last, n_steps, B, T, M, n, s);
+        rc = sample_loop_graph(h, w, x, noise, t_model, coef, x0_last, x_in_last, n_steps, B, T, M, n, s);
         if (rc != ROHM_ERR_UNSUPPORTED) return rc;
         // capture not available on this stream / runtime: fall through to the plain loop
     }
@@ -1171,6 +1178,8 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
+        if (x_in_last && i == n_steps - 1)       // the reference keeps the input of the last step in batch['x_t']
+            ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (i % kTbSteps == 0) {
             // the time path depends on t only (trajnet.py:120-125, heads.py:35-38): one launch covers the next run of
             // steps (37 us per step before)

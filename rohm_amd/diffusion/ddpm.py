@@ -275,8 +275,6 @@ class DDPMSampler:
             x_in_last = None
             while pos < n_free:
                 n = min(self.fused_chunk, n_free - pos)
-                if pos + n == len(indices) and n > 1:
-                    n -= 1        # the very last step runs on its own so that its input can be kept for batch['x_t']
                 ts = indices[pos:pos + n]
                 coef = np.empty((n, 3), np.float32)
                 for k, i in enumerate(ts):
@@ -287,10 +285,10 @@ class DDPMSampler:
                 else:
                     nz = torch.randn((n,) + tuple(x.shape), device=x.device, dtype=torch.float32)
                 last = (pos + n == len(indices))
-                if last:
-                    x_in_last = x.clone()
+                if last:      # the native loop copies the input of its last step out (one device copy, no extra loop call)
+                    x_in_last = torch.empty_like(x)
                 x0 = raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz,
-                                            want_x0_last=last, batch=batch)
+                                            want_x0_last=last, batch=batch, x_in_last=x_in_last if last else None)
                 if last:
                     x0_last = x0
                 pos += n

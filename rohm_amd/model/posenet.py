@@ -220,12 +220,12 @@ class PoseNet(nn.Module):
         return out
 
     # ------------------------------------------------------------------ fused sampling loop
-    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False, batch=None):
+    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False, batch=None, x_in_last=None):
         """Run `n = len(t_model)` DDPM steps on the device (rohm_posenet_sample_loop).
 
         x [B,C,1,T] is updated in place; noise [n,B,C,1,T]; coef float32 host array [n,3] of
         (coef1, coef2, sigma); t_model int64 host array [n].  Returns pred_xstart of the last step
-        when `want_x0_last`."""
+        when `want_x0_last`; `x_in_last` (optional, shaped like x) receives the input of the last step."""
         import numpy as np
         _lib.require_hip(x, cond, noise)
         nat = self.native(x.device)
@@ -248,8 +248,8 @@ class PoseNet(nn.Module):
         ws = nat.workspace(B, T)
         check(lib().rohm_posenet_sample_loop(nat.handle, ptr(x), ptr(cond),
                                              t_arr.ctypes.data_as(_lib.c_int64_p),
-                                             c_arr.ctypes.data_as(_lib.c_float_p), ptr(noise), ptr(x0_last), n, B, T,
-                                             ptr(ws), ws.numel(), stream_ptr(x.device)),
+                                             c_arr.ctypes.data_as(_lib.c_float_p), ptr(noise), ptr(x0_last), ptr(x_in_last),
+                                             n, B, T, ptr(ws), ws.numel(), stream_ptr(x.device)),
               'rohm_posenet_sample_loop')
         return x0_last
 

@@ -228,8 +228,9 @@ class TrajNet(nn.Module):
                                          ws.numel(), stream_ptr(x.device)), 'rohm_trajnet_forward')
         return out
 
-    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False, batch=None):
-        """`n` DDPM steps on the device (rohm_trajnet_sample_loop); x [B, T, 13] is updated in place."""
+    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False, batch=None, x_in_last=None):
+        """`n` DDPM steps on the device (rohm_trajnet_sample_loop); x [B, T, 13] is updated in place.  `x_in_last` (optional,
+        shaped like x) receives the input of the last step."""
         import numpy as np
         _lib.require_hip(x, cond, noise)
         nat = self.native(x.device)
@@ -250,8 +251,8 @@ class TrajNet(nn.Module):
         ws = nat.workspace(B, T)
         check(lib().rohm_trajnet_sample_loop(nat.handle, ptr(x), ptr(cond), ptr(ctrl),
                                              t_arr.ctypes.data_as(_lib.c_int64_p),
-                                             c_arr.ctypes.data_as(_lib.c_float_p), ptr(noise), ptr(x0_last), n, B, T,
-                                             ptr(ws), ws.numel(), stream_ptr(x.device)), 'rohm_trajnet_sample_loop')
+                                             c_arr.ctypes.data_as(_lib.c_float_p), ptr(noise), ptr(x0_last), ptr(x_in_last),
+                                             n, B, T, ptr(ws), ws.numel(), stream_ptr(x.device)), 'rohm_trajnet_sample_loop')
         return x0_last
 
     def compute_losses_with_smpl(self, batch, model_output, smplx_model=None):

@@ -39,7 +39,7 @@ def test_planes_split_is_the_cut_in_fragment_major_layout(nplane):
 SHAPES = [(144, 64, 32), (144, 128, 64), (288, 192, 96), (144, 512, 128), (144 * 3, 512, 512), (144 * 2, 512, 544),
           (144 * 2, 256, 576), (144 * 3, 512, 1024), (144 * 64, 512, 512), (144 * 64, 1536, 512), (144 * 64, 1024, 512),
           (144 * 64, 512, 1024), (144 * 32, 512, 512), (144 * 32, 1536, 512), (144 * 65, 512, 192), (144 * 40, 512, 224),
-          (144 * 66, 1024, 160), (144 * 66, 1024, 512)]
+          (144 * 66, 1024, 160), (144 * 66, 1024, 512), (144 * 65, 512, 320), (144 * 64, 1536, 352)]
 
 
 @pytest.mark.parametrize('M,N,K', SHAPES)
@@ -85,7 +85,7 @@ def test_gemm_planes_identity_asymmetric():
 
 
 @pytest.mark.parametrize('M,N,K', [(144 * 64, 1024, 512), (144 * 2, 1024, 512), (144 * 64, 512, 64), (144 * 65, 1024, 192),
-                                   (144 * 40, 1024, 224)])
+                                   (144 * 40, 1024, 224), (144 * 65, 1024, 320)])
 @pytest.mark.parametrize('nplane', [3, 2])
 @pytest.mark.parametrize('flags', [0, 1])
 def test_gemm_plane_output_is_the_cut_of_the_fp32_output(M, N, K, nplane, flags):
@@ -150,7 +150,7 @@ def test_the_one_tile_per_workgroup_kernel_too():
     import os
     import subprocess
     import sys
-    if os.environ.get('ROHM_PP_STREAM') == '0':
+    if 'ROHM_PP_STREAM' in os.environ:
         pytest.skip('already the child')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_gpu_planes.py',
