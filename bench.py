@@ -675,7 +675,13 @@ def main(argv=None):
                 'peak': PEAK_F32_MFMA_TFLOPS if not _PRODUCTS else PEAK_BF16_MFMA_TFLOPS / _PRODUCTS, 'unit': 'TFLOP/s',
                 'frac': (achieved / (PEAK_F32_MFMA_TFLOPS if not _PRODUCTS else PEAK_BF16_MFMA_TFLOPS / _PRODUCTS))
                 if achieved else None,
-                'peak_note': 'fp32 MFMA' if not _PRODUCTS else f'bf16 MFMA peak / {_PRODUCTS} products (fp32-equivalent flops)',
+                'peak_note': ('fp32 MFMA at the nominal 2.4 GHz.  Under this kernel the chip does not hold 2.4 GHz: in-kernel cycle counter vs '
+                              'wall clock gives 2.05-2.13 GHz in the main loop on random operands and 2.27-2.34 GHz on all-zero operands (same '
+                              'binary; profiles/r3_gemm_timeline.txt, r3_gemm_timeline_zero.txt; host telemetry is static in this VF, '
+                              'profiles/r3_power_sclk_bench.txt) -- a power-limited (DVFS) ceiling of ~135-140 TFLOP/s, of which the loops reach '
+                              '~0.9') if not _PRODUCTS else
+                             (f'bf16 MFMA peak (2.5 PFLOP/s at 2.4 GHz) / {_PRODUCTS} products = fp32-equivalent flops.  A bare stream of these MFMAs '
+                              'on random operands sustains 1.63-2.0 PFLOP/s (1.7-2.0 GHz under load, profiles/r3_g_mfma_bf16_chain_probe.txt)'),
                 'traffic': pmc_traffic()[0] if not _PRODUCTS else None, 'traffic_unit': 'bytes per launch (HBM side, PMC)',
                 'traffic_source': pmc_traffic()[1],
                 'mfma_busy_pmc': pmc_mfma(B),
