@@ -209,6 +209,48 @@ def golden_guided_step(ref):
     print('guided_step.npz', os.path.getsize(os.path.join(OUT, 'guided_step.npz')))
 
 
+GUIDED_HEAD_T = (103, 102, 101, 100, 99, 98, 97)
+
+
+def golden_guided_head(ref):
+    """A free-running GUIDED run at the reference's own weights over the stretch where it is still well conditioned: the
+    reference's `p_sample_with_grad(grad_type='prox')` called step after step on ITS OWN samples for t = 103 .. 97 (three
+    un-guided steps, then the first four guided ones: 2-D term x 3e5 + skating term x 1e5), noise from one seed per step.
+    scripts/guided_chaos.py / profiles/r3_guided_chaos.txt show why it stops there: after t = 96 the reference and its
+    restatement drift apart by more than 1e-3 and the samples leave |x| ~ 50."""
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    refload.set_body_model(body)
+    seeds = dict(stats_seed=0, x_seed=61, xn_seed=62, cond_seed=63, cam_seed=2, weight_seed=13, body_seed=0)
+    mean, std, x, cond, cam = guided_step_inputs(seeds)
+
+    class GDS:
+        pose_feat_dim, traj_feat_dim, joints_num = 272, 22, 22
+        Mean, Std = mean, std
+        cam_R = torch.tensor(synth.SYNTH_CAM_R)
+        cam_t = torch.tensor(synth.SYNTH_CAM_T)
+    net = ref.posenet.PoseNet(GDS(), 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                              device='cpu').eval()
+    net.smplx_model = body
+    net.load_state_dict(synth.posenet_state_dict(seeds['weight_seed']), strict=False)
+    diff = ref.model_util.create_gaussian_diffusion(_Args, ref.gd_posenet, ref.respace.SpacedDiffusionPoseNet,
+                                                    1000, '', device='cpu')
+    xx = x.clone()
+    out = {}
+    for k, i in enumerate(GUIDED_HEAD_T):
+        batch = dict(cam)
+        batch['cond'] = cond
+        torch.manual_seed(900 + k)
+        with torch.no_grad():
+            r = diff.p_sample_with_grad(net, batch, xx.clone(), torch.tensor([i] * 2), clip_denoised=False, grad_type='prox')
+        xx = r['sample']
+        out[f'max_abs_{k}'] = float(xx.abs().max())
+        print('guided_head t', i, 'max|sample|', out[f'max_abs_{k}'])
+    np.savez_compressed(os.path.join(OUT, 'guided_head.npz'), n_steps=len(GUIDED_HEAD_T), t=np.asarray(GUIDED_HEAD_T), noise_seed0=900,
+                        sample=xx.numpy(), **seeds, **out)
+    print('guided_head.npz', os.path.getsize(os.path.join(OUT, 'guided_head.npz')))
+
+
 SCHEME_CASES = (
     ('amass', dict(mask_scheme='lower')),
     ('amass', dict(mask_scheme='upper', iter2_cond_noisy_pose=False, iter2_cond_noisy_traj=False)),
@@ -464,6 +506,9 @@ def main():
     if sys.argv[1:] == ['guided_step']:
         warnings.filterwarnings('ignore')
         return golden_guided_step(refload.load())
+    if sys.argv[1:] == ['guided_head']:
+        warnings.filterwarnings('ignore')
+        return golden_guided_head(refload.load())
     if sys.argv[1:] == ['ddim']:
         warnings.filterwarnings('ignore')
         return golden_ddim(refload.load())

@@ -317,3 +317,26 @@ def test_early_stop_index_list_is_the_references():
     idx = diff._indices(0, True)
     assert len(idx) == 980 and idx[0] == 999 and idx[-1] == 20
     assert diff._indices(0, False)[-1] == 0
+
+
+def test_free_running_guided_head_vs_reference_golden():
+    """A guided RUN at the reference's own weights, free-running: `p_sample_with_grad(grad_type='prox')` through the HIP kernels
+    iterated on its own samples over t = 103 .. 97 (three un-guided steps, the first four guided ones with 3e5 / 1e5) against the
+    reference's own free-running result (tests/golden/guided_head.npz).  The stretch ends where the reference and its restatement
+    part ways (profiles/r3_guided_chaos.txt); the samples grow from |x| ~ 5 to ~ 40 on the way, hence the relative bar."""
+    from oracle.make_golden import guided_step_inputs
+    g = golden('guided_head.npz')
+    net = _prox_net(g)
+    mean, std, x, cond, cam = guided_step_inputs(g)
+    diff = _diffusion()
+    batch = {kk: v.to(DEV) for kk, v in cam.items()}
+    batch['cond'] = cond.to(DEV)
+    xx = x.to(DEV)
+    for k, i in enumerate(int(v) for v in g['t']):
+        torch.manual_seed(int(g['noise_seed0']) + k)
+        noise = torch.randn(2, 294, 1, 143)
+        diff.noise_source = lambda step, like, noise=noise: noise
+        t = torch.full((2,), i, device=DEV, dtype=torch.int64)
+        xx = diff.p_sample_with_grad(net, batch, xx, t, clip_denoised=False, grad_type='prox')['sample']
+    ref = torch.from_numpy(g['sample'])
+    assert max_abs(xx.cpu(), ref) < 2e-3 * float(ref.abs().max())
