@@ -22,8 +22,8 @@ timed region on the launch stream) and, at N = 1, `cpu_baseline` (the reference'
 
 At N = 1 the default run then adds, each measured by a child process AFTER the headline leg (thermal history: the headline
 always runs first on a cold chip) and none of them ever replacing `value` / `dtype` / `roofline`, which stay exact fp32:
-  `second_line`  the same workload under ROHM_GEMM_PRECISION=bf16x6 (split-bf16 GEMMs on planes) with its
-                 own dtype, roofline (bf16 MFMA peak / 6) and 1000-step accuracy against the reference's own run;
+  `second_line`  the same workload under ROHM_GEMM_PRECISION=fp16x3 (split GEMMs on fp16 planes) with its own dtype,
+                 roofline (fp16 MFMA peak / 3) and 1000-step accuracy against the reference's own run (+ `also.bf16x6`);
   `configs`      one short pass each of the other BASELINE.json configurations on this GPU: `b32` (PoseNet at the per-GPU
                  batch of configs[2..4]), `scheme_b32` (configs[2]), `prox_b32` (configs[3]), `egobody_b32` (configs[4]).
 `--no-extras` skips both (the children run with it).  `--force-dist` initialises the RCCL process group even at world size
@@ -48,7 +48,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA
 # Opt-in precision ladder of the GEMMs (rohm_amd/csrc/gemm_f32.hip): the default and the headline are exact fp32 MFMA.
 _PREC = os.environ.get('ROHM_GEMM_PRECISION', '')
-_PRODUCTS = {'bf16x6': 6, 'bf16x3': 3}.get(_PREC, 0)
+_PRODUCTS = {'bf16x6': 6, 'bf16x3': 3, 'fp16x3': 3}.get(_PREC, 0)
+_PLANE_TYPE = 'fp16' if _PREC == 'fp16x3' else 'bf16'
 POSENET_GFLOP_PER_CLIP_STEP = 5.298   # SURVEY.md §8(d) / BASELINE.md §2
 
 
@@ -418,16 +419,29 @@ def brief(d):
 def extras(args):
     """`second_line` and `configs` of the N = 1 record (see the module docstring); headline first, these afterwards."""
     S = str(args.ddpm_steps)
-    sl = run_child(['--workload', 'posenet', '--batch', str(args.batch), '--ddpm-steps', S, '--steps', '2', '--warmup', '1',
-                    '--with-accuracy'], {'ROHM_GEMM_PRECISION': 'bf16x6'})
-    second = brief(sl)
-    if 'error' not in sl:
-        second['roofline'] = {k: sl['roofline'].get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'peak_note',
-                                                                  'launches_timed', 'avg_launch_us')}
-        second['accuracy'] = sl.get('accuracy')
-        second['label'] = ('opt-in ROHM_GEMM_PRECISION=bf16x6: every fp32 product of the four encoder Linears emulated by six bf16 MFMA '
-                           'products of exact truncation planes, fp32 accumulation; held to the fp32 parity bars by '
-                           'tests/test_gpu_precision_ladder.py; NEVER the headline (narrower arithmetic than the reference)')
+    labels = {
+        'fp16x3': ('opt-in ROHM_GEMM_PRECISION=fp16x3: every fp32 product of the four encoder Linears emulated by three fp16 MFMA products of '
+                   'two fp16 planes (h = fp16(x), l = fp16((x - h) 2^11); cross terms in a second accumulator of weight 2^-11), fp32 '
+                   'accumulation; ~2^-22 per product; held to the fp32 parity bars by tests/test_gpu_precision_ladder.py (whole PoseNet '
+                   'suite); NEVER the headline (narrower arithmetic than the reference)'),
+        'bf16x6': ('opt-in ROHM_GEMM_PRECISION=bf16x6: six bf16 MFMA products of three exact truncation planes per fp32 product, fp32 '
+                   'accumulation; held to the fp32 parity bars by the same suite; NEVER the headline'),
+    }
+
+    def line(mode):
+        sl = run_child(['--workload', 'posenet', '--batch', str(args.batch), '--ddpm-steps', S, '--steps', '2', '--warmup', '1',
+                        '--with-accuracy'], {'ROHM_GEMM_PRECISION': mode})
+        out = brief(sl)
+        if 'error' not in sl:
+            out['roofline'] = {k: sl['roofline'].get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'peak_note',
+                                                                   'launches_timed', 'avg_launch_us')}
+            out['accuracy'] = sl.get('accuracy')
+            out['label'] = labels[mode]
+        out['mode'] = mode
+        return out
+    second = line('fp16x3')
+    second['also'] = {'bf16x6': {k: v for k, v in line('bf16x6').items() if k in ('value', 'unit', 'ms_per_pass', 'dtype', 'accuracy', 'error',
+                                                                                  'label', 'gemm_roofline')}}
     cfg = {}
     for key, argv in (('b32', ['--workload', 'posenet', '--batch', '32']), ('scheme_b32', ['--workload', 'scheme', '--batch', '32']),
                       ('prox_b32', ['--workload', 'prox', '--batch', '32']), ('egobody_b32', ['--workload', 'egobody', '--batch', '32'])):
@@ -655,7 +669,7 @@ def main(argv=None):
             'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'world_size': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if not _PRODUCTS else f'f32 emulated with {_PRODUCTS} bf16 MFMA products per product, f32 accumulate '
+            'dtype': 'f32' if not _PRODUCTS else f'f32 emulated with {_PRODUCTS} {_PLANE_TYPE} MFMA products per product, f32 accumulate '
                                                   f'(ROHM_GEMM_PRECISION={_PREC}, opt-in)',
             'data': 'synthetic',
             'config': {'workload': (f'PoseNet {S}-step DDPM with PROX test-time guidance, early stop at 980 steps, batch={B} '
@@ -680,7 +694,7 @@ def main(argv=None):
                               'binary; profiles/r3_gemm_timeline.txt, r3_gemm_timeline_zero.txt; host telemetry is static in this VF, '
                               'profiles/r3_power_sclk_bench.txt) -- a power-limited (DVFS) ceiling of ~135-140 TFLOP/s, of which the loops reach '
                               '~0.9') if not _PRODUCTS else
-                             (f'bf16 MFMA peak (2.5 PFLOP/s at 2.4 GHz) / {_PRODUCTS} products = fp32-equivalent flops.  A bare stream of these MFMAs '
+                             (f'{_PLANE_TYPE} MFMA peak (2.5 PFLOP/s at 2.4 GHz) / {_PRODUCTS} products = fp32-equivalent flops.  A bare stream of these MFMAs '
                               'on random operands sustains 1.63-2.0 PFLOP/s (1.7-2.0 GHz under load, profiles/r3_g_mfma_bf16_chain_probe.txt)'),
                 'traffic': pmc_traffic()[0] if not _PRODUCTS else None, 'traffic_unit': 'bytes per launch (HBM side, PMC)',
                 'traffic_source': pmc_traffic()[1],

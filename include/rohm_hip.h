@@ -87,21 +87,25 @@ int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, i
 int rohm_attention_f32(const float* qkv, float* ctx, int n_seq, int n_head, int n_tok, int head_dim,
                        rohm_stream_t stream);
 
-/* ---- opt-in precision ladder: split-bf16 GEMMs on bf16 PLANES of the fp32 operands ----
- * The same Linears as rohm_gemm_f32 (model/posenet.py:63-69), each fp32 product a.w emulated by bf16 MFMA products of
- * planes cut by TRUNCATION (x = h + m + l exactly; nplane = 3: six products, fp32-class accuracy; nplane = 2: three
- * products, ~2^-16).  A plane tensor of X[rows][K] (rows % 16 == 0, K % 32 == 0) is rohm_planes_bytes(rows, K, nplane)
- * bytes in the fragment-major layout of rohm_amd/csrc/planes.h; producers write it (LayerNorm, attention, the GELU GEMM)
- * or rohm_planes_split cuts it from an fp32 matrix.  Never the default: rohm_posenet_create selects it only under
- * ROHM_GEMM_PRECISION=bf16x6 | bf16x3. */
+/* ---- opt-in precision ladder: split GEMMs on 16-bit PLANES of the fp32 operands ----
+ * The same Linears as rohm_gemm_f32 (model/posenet.py:63-69), each fp32 product a.w emulated by bf16 / fp16 MFMA products of
+ * planes.  `nplane` is the MODE everywhere:  3 = bf16x6 (three bf16 planes cut by truncation, x = h + m + l exactly, six products,
+ * fp32-class accuracy),  2 = bf16x3 (two bf16 planes, three products, ~2^-16),  16 = fp16x3 (two FP16 planes h = fp16(x),
+ * l' = fp16((x - h) 2^11): x = h + 2^-11 l' to 2^-24 for 6e-5 <= |x| <= 65504; three products, the two cross terms in a second
+ * accumulator of weight 2^-11: ~2^-22 per product).  A plane tensor of X[rows][K] (rows % 16 == 0, K % 32 == 0) is
+ * rohm_planes_bytes(rows, K, mode) bytes in the fragment-major layout of rohm_amd/csrc/planes.h; producers write it (LayerNorm,
+ * attention, the GELU GEMM) or rohm_planes_split cuts it from scale * X (scale: a power of two, 1 for activations; fp16 weight
+ * planes are cut from 2^8 W and the GEMM is given acc_scale = 2^-8).  Never the default: rohm_posenet_create selects a mode only
+ * under ROHM_GEMM_PRECISION=bf16x6 | bf16x3 | fp16x3. */
 size_t rohm_planes_bytes(int rows, int K, int nplane);
-int rohm_planes_split(const float* X, int ldx, int rows, int K, int nplane, void* planes, rohm_stream_t stream);
+int rohm_planes_split(const float* X, int ldx, int rows, int K, int nplane, float scale, void* planes, rohm_stream_t stream);
 /* C[M,N] = epi(A . W^T) from the planes of A [M][K] and W [N][K]; M % 144 == 0, N % 64 == 0, K % 32 == 0.
  * epi: 0 = +bias, 1 = +bias, erf GELU, 2 = +bias +R, 3 = (+bias) * (n < qcols ? qscale : 1).  C (fp32, ldc) and / or
- * Cp (planes of the result over [M][N]) receive the result.  flags bit 0: plane output through 8-byte stores. */
+ * Cp (planes of the result over [M][N]) receive the result; the accumulator is multiplied by acc_scale first (0 = 1).
+ * flags bit 0: plane output through 8-byte stores. */
 int rohm_gemm_planes(const void* Ap, const void* Wp, float* C, int ldc, void* Cp, int M, int N, int K,
-                     const float* bias, const float* R, int ldr, int qcols, float qscale, int epi, int nplane,
-                     int flags, rohm_stream_t stream);
+                     const float* bias, const float* R, int ldr, int qcols, float qscale, float acc_scale, int epi,
+                     int nplane, int flags, rohm_stream_t stream);
 /* rohm_layernorm_f32 that also writes the planes of its result (M % 16 == 0); the fp32 result is bit-identical. */
 int rohm_layernorm_planes_f32(float* x, const float* gamma, const float* beta, int M, int D, int nplane,
                               void* planes, rohm_stream_t stream);
@@ -159,7 +163,7 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
                         int d_ff, int n_layer, int c_in, int c_out, int traj_dim, int device);
 void rohm_posenet_destroy(rohm_posenet_t* h);
 size_t rohm_posenet_workspace_bytes(const rohm_posenet_t* h, int B, int T);
-/* 0: exact fp32 MFMA GEMMs (default); 3 / 2: the handle was created under ROHM_GEMM_PRECISION=bf16x6 / bf16x3 and runs
+/* 0: exact fp32 MFMA GEMMs (default); 3 / 2 / 16: the handle was created under ROHM_GEMM_PRECISION=bf16x6 / bf16x3 / fp16x3 and runs
  * the four Linears of every encoder layer (model/posenet.py:63-69) as split-bf16 GEMMs on planes. */
 int rohm_posenet_precision(const rohm_posenet_t* h);
 

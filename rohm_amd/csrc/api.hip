@@ -135,16 +135,16 @@ size_t rohm_planes_bytes(int rows, int K, int nplane) {
     return plane_tensor_bytes(rows, K, nplane);
 }
 
-int rohm_planes_split(const float* X, int ldx, int rows, int K, int nplane, void* planes, rohm_stream_t stream) {
-    return launch_plane_split(X, ldx, rows, K, nplane, planes, (hipStream_t)stream);
+int rohm_planes_split(const float* X, int ldx, int rows, int K, int nplane, float scale, void* planes, rohm_stream_t stream) {
+    return launch_plane_split(X, ldx, rows, K, nplane, scale, planes, (hipStream_t)stream);
 }
 
 int rohm_gemm_planes(const void* Ap, const void* Wp, float* C, int ldc, void* Cp, int M, int N, int K,
-                     const float* bias, const float* R, int ldr, int qcols, float qscale, int epi, int nplane,
+                     const float* bias, const float* R, int ldr, int qcols, float qscale, float acc_scale, int epi, int nplane,
                      int flags, rohm_stream_t stream) {
     PlaneGemmParams g{};
     g.Ap = Ap; g.Wp = Wp; g.C = C; g.ldc = ldc; g.Cp = Cp; g.M = M; g.N = N; g.K = K;
-    g.bias = bias; g.R = R; g.ldr = ldr; g.qcols = qcols; g.qscale = qscale; g.no_swap = flags & 1;
+    g.bias = bias; g.R = R; g.ldr = ldr; g.qcols = qcols; g.qscale = qscale; g.acc_scale = acc_scale; g.no_swap = flags & 1;
     return launch_gemm_pp(g, epi, nplane, (hipStream_t)stream);
 }
 

@@ -62,7 +62,7 @@ __device__ __forceinline__ void at_dma16(const float* src, float* lds_dst) {
 #define AT_STAMP(i)
 #endif
 
-// NPO = 0: ctx is the fp32 matrix [n_seq * 144][n_head * 128]; NPO = 2 / 3: ctx receives the bf16 PLANES of that matrix
+// NPO = 0: ctx is the fp32 matrix [n_seq * 144][n_head * 128]; NPO = 2 / 3 / 16: ctx receives the bf16 (fp16) PLANES of that matrix
 // instead (planes.h; the consumer is the out-projection of the split-bf16 path, gemm_pp.hip).  For plane output the P.V
 // MFMAs run with their operands exchanged (O^T = V^T P^T: the same products summed in the same order), which leaves a lane
 // with 16 CONSECUTIVE output columns of one query row -- two complete 16-byte units per plane, 256 contiguous bytes per 16 lanes.
@@ -571,9 +571,10 @@ int launch_attention(const float* qkv, float* ctx, int n_seq, int n_head, int n_
 int launch_attention_planes(const float* qkv, void* ctx_planes, int n_seq, int n_head, int nplane, hipStream_t s) {
     ROHM_ARG_CHECK(n_seq > 0 && n_head > 0 && qkv && ctx_planes, "attention_planes: empty problem / null pointer");
     ROHM_ARG_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx_planes % 16) == 0, "attention_planes: operands must be 16-byte aligned");
-    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "attention_planes: 2 or 3 planes");
-    return nplane == 3 ? launch_special<3>(qkv, (float*)ctx_planes, n_seq, n_head, s)
-                       : launch_special<2>(qkv, (float*)ctx_planes, n_seq, n_head, s);
+    ROHM_ARG_CHECK(mode_ok(nplane), "attention_planes: mode must be 3, 2 or 16");
+    if (nplane == 3) return launch_special<3>(qkv, (float*)ctx_planes, n_seq, n_head, s);
+    if (nplane == 2) return launch_special<2>(qkv, (float*)ctx_planes, n_seq, n_head, s);
+    return launch_special<kModeF16>(qkv, (float*)ctx_planes, n_seq, n_head, s);
 }
 #endif  // AT_TIMELINE
 

@@ -124,13 +124,14 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(float* __restrict
 
 int launch_layernorm_planes(float* x, const float* g, const float* b, int M, int D, int nplane, void* planes, hipStream_t s) {
     ROHM_ARG_CHECK(M > 0 && M % 16 == 0 && planes, "layernorm_planes: M must be a positive multiple of 16");
-    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "layernorm_planes: 2 or 3 planes");
+    ROHM_ARG_CHECK(mode_ok(nplane), "layernorm_planes: mode must be 3, 2 or 16");
     const dim3 grid(M / 16), block(256);
-    prof::Scope ps("layernorm", 0.0, (8.0 + 2.0 * nplane) * M * D, s);
+    prof::Scope ps("layernorm", 0.0, (8.0 + 2.0 * mode_planes(nplane)) * M * D, s);
 #define ROHM_LNP(DD)                                                                                                     \
     do {                                                                                                                 \
         if (nplane == 3) hipLaunchKernelGGL((layernorm_planes_kernel<DD, 3>), grid, block, 0, s, x, g, b, (char*)planes); \
-        else hipLaunchKernelGGL((layernorm_planes_kernel<DD, 2>), grid, block, 0, s, x, g, b, (char*)planes);            \
+        else if (nplane == 2) hipLaunchKernelGGL((layernorm_planes_kernel<DD, 2>), grid, block, 0, s, x, g, b, (char*)planes); \
+        else hipLaunchKernelGGL((layernorm_planes_kernel<DD, kModeF16>), grid, block, 0, s, x, g, b, (char*)planes);      \
     } while (0)
     if (D == 512) ROHM_LNP(512);
     else if (D == 256) ROHM_LNP(256);

@@ -34,6 +34,7 @@ constexpr int QM = 144, QRB = 9, QNT = 512, QSTAGE = 3;
 constexpr int kStreamCUs = 256;      // MI355X: persistent workgroups of the stream kernel
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // s_waitcnt vmcnt(n) lgkmcnt(0) (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4] = 7, lgkmcnt [11:8])
 #define PP_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (0 << 8) | (((n) >> 4) << 14))
@@ -43,12 +44,14 @@ struct Frag { u32x4 p[NP]; };
 
 template <int EPI, int NP, int CB, bool POUT>
 __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
+    constexpr int NPL = mode_planes(NP);           // planes per operand (NP is the mode: 3 / 2 bf16 planes, 16 = two fp16 planes)
+    constexpr bool F16 = (NP == kModeF16);
     constexpr int NPROD = (NP == 3) ? 6 : 3;
     constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};    // plane pairs (activation, weight), smallest terms first
     constexpr int BN = 4 * CB * 16;
-    constexpr int NF = QRB * NP;                  // A fragments (1 KiB) per chunk
+    constexpr int NF = QRB * NPL;                  // A fragments (1 KiB) per chunk
     constexpr int PIECES = (NF + 7) / 8;          // LDS-DMA instructions per wave per chunk
-    constexpr int VMOPS = PIECES + CB * NP;       // vector-memory operations per wave per chunk
+    constexpr int VMOPS = PIECES + CB * NPL;       // vector-memory operations per wave per chunk
     constexpr int STAGE_B = NF * 1024;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
     const int mblk0 = (tile / tiles_n) * QRB;     // first 16-row block of the tile
     const int n0 = (tile % tiles_n) * BN;
     const int nkc = p.K / 32;
-    const size_t chunk_b = (size_t)NP * 1024;     // bytes of one (row block, chunk) in either operand
+    const size_t chunk_b = (size_t)NPL * 1024;     // bytes of one (row block, chunk) in either operand
 
     // ---- A: LDS-DMA, fragment f = wave + 8 j of the chunk (row block f / NP, plane f % NP) --------------------------------
     const char* a_src[PIECES];
@@ -76,8 +79,8 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
     for (int j = 0; j < PIECES; ++j) {
         const int f = wave + 8 * j;
         const bool ok = f < NF;
-        const int rb = ok ? f / NP : 0, pl = ok ? f % NP : 0;
-        a_src[j] = reinterpret_cast<const char*>(p.Ap) + ((size_t)(mblk0 + rb) * nkc * NP + pl) * 1024 + lane * 16;
+        const int rb = ok ? f / NPL : 0, pl = ok ? f % NPL : 0;
+        a_src[j] = reinterpret_cast<const char*>(p.Ap) + ((size_t)(mblk0 + rb) * nkc * NPL + pl) * 1024 + lane * 16;
         a_dst[j] = ok ? f * 1024 : -1;
     }
     auto dma_piece = [&](int stage, int kc, int j) {
@@ -94,55 +97,75 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
 #pragma unroll
     for (int c = 0; c < CB; ++c)
         b_src[c] = reinterpret_cast<const char*>(p.Wp) + (size_t)((n0 >> 4) + wn * CB + c) * nkc * chunk_b + lane * 16;
-    Frag<NP> breg[QSTAGE][CB];
-    auto bload = [&](Frag<NP> (&dst)[CB], int kc) {
+    Frag<NPL> breg[QSTAGE][CB];
+    auto bload = [&](Frag<NPL> (&dst)[CB], int kc) {
 #pragma unroll
         for (int c = 0; c < CB; ++c)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
                 dst[c].p[pl] = *reinterpret_cast<const u32x4*>(b_src[c] + (size_t)kc * chunk_b + pl * 1024);
     };
-    auto aread = [&](Frag<NP>& dst, int stage, int rb) {     // row block rb of the chunk in `stage`
+    auto aread = [&](Frag<NPL>& dst, int stage, int rb) {     // row block rb of the chunk in `stage`
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-            dst.p[pl] = *reinterpret_cast<const u32x4*>(smem + stage * STAGE_B + (rb * NP + pl) * 1024 + lane * 16);
+        for (int pl = 0; pl < NPL; ++pl)
+            dst.p[pl] = *reinterpret_cast<const u32x4*>(smem + stage * STAGE_B + (rb * NPL + pl) * 1024 + lane * 16);
     };
 
     f32x4 acc[4][CB], acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accx[4][CB], acc8x = f32x4{0.f, 0.f, 0.f, 0.f};       // cross-term accumulators (fp16 mode only; dead otherwise)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < CB; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mfma = [](const u32x4& w, const u32x4& a, const f32x4& c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+        for (int c = 0; c < CB; ++c) { acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // main + 2^-11 cross, times the power-of-two scale the weight planes were cut with
+    const float acc_scale = (p.acc_scale != 0.f) ? p.acc_scale : 1.0f;
+    auto combine = [&](const f32x4& m, const f32x4& x) {
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = F16 ? (m[q] + x[q] * (1.0f / kF16LowScale)) * acc_scale : m[q] * acc_scale;
+        return r;
     };
+    auto mfma = [](const u32x4& w, const u32x4& a, const f32x4& c) {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    };
+    // fp16 mode: products 3, 4 of the table (a_l' w_h, a_h w_l') are the cross terms: they go to the second accumulator
+    // set, which enters the result with weight 2^-11; product 5 (a_h w_h) goes to the first
+    auto is_cross = [](int q) { return F16 && q < 5; };
     // MFMAs [lo, hi) of one row block, product-major (consecutive MFMAs hit different accumulators): t = product * CB + column
-    auto mm_range = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP> (&b)[CB], int lo, int hi) {
+    auto mm_range = [&](f32x4 (&d)[CB], f32x4 (&dx)[CB], const Frag<NPL>& a, const Frag<NPL> (&b)[CB], int lo, int hi) {
 #pragma unroll
         for (int t = 0; t < NPROD * CB; ++t) {
             if (t < lo || t >= hi) continue;
             const int q = 6 - NPROD + t / CB, c = t % CB;
-            d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+            if (is_cross(q)) dx[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], dx[c]);
+            else d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
         }
     };
-    auto mm = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP> (&b)[CB]) { mm_range(d, a, b, 0, NPROD * CB); };
+    auto mm = [&](f32x4 (&d)[CB], f32x4 (&dx)[CB], const Frag<NPL>& a, const Frag<NPL> (&b)[CB]) { mm_range(d, dx, a, b, 0, NPROD * CB); };
     // the wave's share of row block 8: column block wm of its two (CB = 2), or the only one for wm = 0 (CB = 1)
-    auto b8 = [&](const Frag<NP> (&b)[CB]) {
-        Frag<NP> r;
+    auto b8 = [&](const Frag<NPL> (&b)[CB]) {
+        Frag<NPL> r;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int q = 0; q < 4; ++q) r.p[pl][q] = wm ? b[CB - 1].p[pl][q] : b[0].p[pl][q];
         return r;
     };
     // [last full row block | the share of row block 8], CB = 2: three accumulators round-robin, MFMAs [lo, hi) of 3 NPROD
-    auto mm_last = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP>& a8, const Frag<NP> (&b)[CB], const Frag<NP>& bh, int lo, int hi) {
+    auto mm_last = [&](f32x4 (&d)[CB], f32x4 (&dx)[CB], const Frag<NPL>& a, const Frag<NPL>& a8, const Frag<NPL> (&b)[CB], const Frag<NPL>& bh,
+                       int lo, int hi) {
 #pragma unroll
         for (int t = 0; t < 3 * NPROD; ++t) {
             if (t < lo || t >= hi) continue;
             const int q = 6 - NPROD + t / 3, c = t % 3;
-            if (c < 2) d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
-            else acc8 = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8);
+            if (c < 2) {
+                if (is_cross(q)) dx[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], dx[c]);
+                else d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+            } else {
+                if (is_cross(q)) acc8x = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8x);
+                else acc8 = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8);
+            }
         }
     };
 
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
     constexpr int kMfma = 0x008, kVmem = 0x010;
     constexpr int NM = CB * NPROD;                // MFMAs of one full row block
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
-    Frag<NP> a0, a1, a2, a3;
+    Frag<NPL> a0, a1, a2, a3;
     auto step = [&](auto s_tag, auto first_tag, int kc) {
         constexpr int S = decltype(s_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -177,58 +200,61 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
             dma(SP, kn);
         } else {
             constexpr int G = (NM - 1) / PIECES;  // MFMAs between two DMA pieces
-            mm_range(acc[0], a0, breg[SP], 0, 1);
+            mm_range(acc[0], accx[0], a0, breg[SP], 0, 1);
             PP_SB();
             aread(a1, S, r0 + 1);
             PP_SB();
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
-                mm_range(acc[0], a0, breg[SP], 1 + i * G, 1 + (i + 1) * G);
+                mm_range(acc[0], accx[0], a0, breg[SP], 1 + i * G, 1 + (i + 1) * G);
                 PP_SB();
                 dma_piece(SP, kn, i);
                 PP_SB();
             }
-            mm_range(acc[0], a0, breg[SP], 1 + PIECES * G, NM);
+            mm_range(acc[0], accx[0], a0, breg[SP], 1 + PIECES * G, NM);
         }
         PP_SB();
         // -- section 2: row block r0 + 1, B fragments of chunk kc + 2 (their registers were last read in section 1)
-        mm_range(acc[1], a1, breg[S], 0, 1);
+        mm_range(acc[1], accx[1], a1, breg[S], 0, 1);
         PP_SB();
         aread(a2, S, r0 + 2);
         PP_SB();
         bload(breg[SP], kn);
-        mm_range(acc[1], a1, breg[S], 1, NM);
+        mm_range(acc[1], accx[1], a1, breg[S], 1, NM);
 #pragma unroll
-        for (int i = 0; i < CB * NP; ++i) {
-            __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NP), 1);
+        for (int i = 0; i < CB * NPL; ++i) {
+            __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NPL), 1);
             __builtin_amdgcn_sched_group_barrier(kVmem, 1, 1);
         }
         PP_SB();
         // -- section 3: row block r0 + 2
-        mm_range(acc[2], a2, breg[S], 0, 1);
+        mm_range(acc[2], accx[2], a2, breg[S], 0, 1);
         PP_SB();
         aread(a1, S, r0 + 3);
         aread(a3, S, 8);
         PP_SB();
-        mm_range(acc[2], a2, breg[S], 1, NM);
+        mm_range(acc[2], accx[2], a2, breg[S], 1, NM);
         PP_SB();
         // -- section 4: row block r0 + 3 and the share of row block 8; the first row block is read for the next step
         if constexpr (CB == 2) {
-            const Frag<NP> bh = b8(breg[S]);
-            mm_last(acc[3], a1, a3, breg[S], bh, 0, 1);
+            const Frag<NPL> bh = b8(breg[S]);
+            mm_last(acc[3], accx[3], a1, a3, breg[S], bh, 0, 1);
             PP_SB();
             aread(a0, S, r0);
             PP_SB();
-            mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
+            mm_last(acc[3], accx[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
         } else {
-            mm_range(acc[3], a1, breg[S], 0, 1);
+            mm_range(acc[3], accx[3], a1, breg[S], 0, 1);
             PP_SB();
             aread(a0, S, r0);
             PP_SB();
-            mm_range(acc[3], a1, breg[S], 1, NM);
+            mm_range(acc[3], accx[3], a1, breg[S], 1, NM);
             if (wm == 0) {          // wave-uniform
 #pragma unroll
-                for (int q = 6 - NPROD; q < 6; ++q) acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
+                for (int q = 6 - NPROD; q < 6; ++q) {
+                    if (is_cross(q)) acc8x = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8x);
+                    else acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
+                }
             }
         }
         PP_SB();
@@ -250,9 +276,9 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
     const int rem = nkc - kc;
     if (rem >= 1) step(I1{}, std::false_type{}, kc);
     if (rem == 2) step(I2{}, std::false_type{}, kc + 1);
-    if (rem == 0) mm(acc[0], a0, breg[0]);
-    else if (rem == 1) mm(acc[0], a0, breg[1]);
-    else mm(acc[0], a0, breg[2]);
+    if (rem == 0) mm(acc[0], accx[0], a0, breg[0]);
+    else if (rem == 1) mm(acc[0], accx[0], a0, breg[1]);
+    else mm(acc[0], accx[0], a0, breg[2]);
     PP_WAIT_VM_LGKM0(0);                          // the re-fetched tail chunks: nothing may land in LDS after the workgroup ends
 
     // ---- epilogue: lane holds C[m][nb .. nb + 3] ------------------------------------------------------------------------------
@@ -287,20 +313,20 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
         const int m = (mblk0 + r0 + j) * 16 + li;
         f32x4 v[CB];
 #pragma unroll
-        for (int c = 0; c < CB; ++c) v[c] = finish(acc[j][c], m, n0 + (wn * CB + c) * 16 + lg * 4);
+        for (int c = 0; c < CB; ++c) v[c] = finish(combine(acc[j][c], accx[j][c]), m, n0 + (wn * CB + c) * 16 + lg * 4);
         if constexpr (POUT) {
             if (CB == 2 && !p.no_swap) {
                 // lanes (li, lg) and (li, lg ^ 1) trade: the even one ends with columns 4 lg .. 4 lg + 7 of block 0, the odd
                 // one with columns 4 (lg - 1) .. + 7 of block 1 -- one complete 16-byte unit per lane and plane
-                u32x2 c0[NP], c1[NP];
+                u32x2 c0[NPL], c1[NPL];
                 plane_cut4<NP>(v[0], c0);
                 plane_cut4<NP>(v[CB - 1], c1);
                 const int col = n0 + wn * 32 + ((lg & 1) ? 16 + (lg - 1) * 4 : lg * 4);
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
                     const u32x2 s0 = __builtin_amdgcn_permlane16_swap(c0[pl][0], c1[pl][0], false, false);
                     const u32x2 s1 = __builtin_amdgcn_permlane16_swap(c0[pl][1], c1[pl][1], false, false);
-                    *reinterpret_cast<u32x4*>(cp + plane_unit(m, col >> 3, nkc_out, NP, pl) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<u32x4*>(cp + plane_unit(m, col >> 3, nkc_out, NPL, pl) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
             } else {
 #pragma unroll
@@ -311,7 +337,7 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
     if (CB == 2 || wm == 0) {        // the share of row block 8
         const int m = (mblk0 + 8) * 16 + li;
         const int nb = n0 + (wn * CB + (CB == 2 ? wm : 0)) * 16 + lg * 4;
-        const f32x4 v = finish(acc8, m, nb);
+        const f32x4 v = finish(combine(acc8, acc8x), m, nb);
         if constexpr (POUT) plane_store4<NP>(cp, m, nb, nkc_out, v);
     }
 }
@@ -335,12 +361,14 @@ __global__ __launch_bounds__(QNT) void gemm_pp_kernel(PlaneGemmParams p) {
 // whatever order the stores complete in.  Every step waits vmcnt(VMOPS) = the DMA pieces + B loads of that step.
 template <int EPI, int NP, int CB, bool POUT>
 __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) {
+    constexpr int NPL = mode_planes(NP);           // planes per operand (NP is the mode: 3 / 2 bf16 planes, 16 = two fp16 planes)
+    constexpr bool F16 = (NP == kModeF16);
     constexpr int NPROD = (NP == 3) ? 6 : 3;
     constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
     constexpr int BN = 4 * CB * 16;
-    constexpr int NF = QRB * NP;
+    constexpr int NF = QRB * NPL;
     constexpr int PIECES = (NF + 7) / 8;
-    constexpr int VMOPS = PIECES + CB * NP;
+    constexpr int VMOPS = PIECES + CB * NPL;
     constexpr int STAGE_B = NF * 1024;
     constexpr int NM = CB * NPROD;
 
@@ -363,7 +391,7 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;      // >= 1 (grid <= tiles)
     const int nkc = p.K / 32;
     const int total = my_tiles * nkc;                                 // chunks of this workgroup
-    const size_t chunk_b = (size_t)NP * 1024;
+    const size_t chunk_b = (size_t)NPL * 1024;
 
     // tile seq -> (first row block, first column); linear ids of one workgroup keep their XCD (G is a multiple of 8 or == tiles)
     auto tile_coords = [&](int seq, int& mblk0, int& n0) {
@@ -379,8 +407,8 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
     for (int j = 0; j < PIECES; ++j) {
         const int f = wave + 8 * j;
         const bool ok = f < NF;
-        const int rb = ok ? f / NP : 0, pl = ok ? f % NP : 0;
-        a_base[j] = reinterpret_cast<const char*>(p.Ap) + ((size_t)rb * nkc * NP + pl) * 1024 + lane * 16;
+        const int rb = ok ? f / NPL : 0, pl = ok ? f % NPL : 0;
+        a_base[j] = reinterpret_cast<const char*>(p.Ap) + ((size_t)rb * nkc * NPL + pl) * 1024 + lane * 16;
         a_dst[j] = ok ? f * 1024 : -1;
     }
     const char* b_base[CB];
@@ -416,51 +444,71 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) dma_piece(stage, j);
     };
-    Frag<NP> breg[QSTAGE][CB];
-    auto bload = [&](Frag<NP> (&dst)[CB]) {
+    Frag<NPL> breg[QSTAGE][CB];
+    auto bload = [&](Frag<NPL> (&dst)[CB]) {
 #pragma unroll
         for (int c = 0; c < CB; ++c)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
                 dst[c].p[pl] = *reinterpret_cast<const u32x4*>(b_base[c] + pf_b + pl * 1024);
     };
-    auto aread = [&](Frag<NP>& dst, int stage, int rb) {
+    auto aread = [&](Frag<NPL>& dst, int stage, int rb) {
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-            dst.p[pl] = *reinterpret_cast<const u32x4*>(smem + stage * STAGE_B + (rb * NP + pl) * 1024 + lane * 16);
+        for (int pl = 0; pl < NPL; ++pl)
+            dst.p[pl] = *reinterpret_cast<const u32x4*>(smem + stage * STAGE_B + (rb * NPL + pl) * 1024 + lane * 16);
     };
 
     f32x4 acc[4][CB], acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accx[4][CB], acc8x = f32x4{0.f, 0.f, 0.f, 0.f};       // cross-term accumulators (fp16 mode only; dead otherwise)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < CB; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mfma = [](const u32x4& w, const u32x4& a, const f32x4& c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+        for (int c = 0; c < CB; ++c) { acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // main + 2^-11 cross, times the power-of-two scale the weight planes were cut with
+    const float acc_scale = (p.acc_scale != 0.f) ? p.acc_scale : 1.0f;
+    auto combine = [&](const f32x4& m, const f32x4& x) {
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = F16 ? (m[q] + x[q] * (1.0f / kF16LowScale)) * acc_scale : m[q] * acc_scale;
+        return r;
     };
-    auto mm_range = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP> (&b)[CB], int lo, int hi) {
+    auto mfma = [](const u32x4& w, const u32x4& a, const f32x4& c) {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    };
+    // fp16 mode: products 3, 4 of the table (a_l' w_h, a_h w_l') are the cross terms: they go to the second accumulator
+    // set, which enters the result with weight 2^-11; product 5 (a_h w_h) goes to the first
+    auto is_cross = [](int q) { return F16 && q < 5; };
+    auto mm_range = [&](f32x4 (&d)[CB], f32x4 (&dx)[CB], const Frag<NPL>& a, const Frag<NPL> (&b)[CB], int lo, int hi) {
 #pragma unroll
         for (int t = 0; t < NPROD * CB; ++t) {
             if (t < lo || t >= hi) continue;
             const int q = 6 - NPROD + t / CB, c = t % CB;
-            d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+            if (is_cross(q)) dx[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], dx[c]);
+            else d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
         }
     };
-    auto b8 = [&](const Frag<NP> (&b)[CB]) {
-        Frag<NP> r;
+    auto b8 = [&](const Frag<NPL> (&b)[CB]) {
+        Frag<NPL> r;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int q = 0; q < 4; ++q) r.p[pl][q] = wm ? b[CB - 1].p[pl][q] : b[0].p[pl][q];
         return r;
     };
-    auto mm_last = [&](f32x4 (&d)[CB], const Frag<NP>& a, const Frag<NP>& a8, const Frag<NP> (&b)[CB], const Frag<NP>& bh, int lo, int hi) {
+    auto mm_last = [&](f32x4 (&d)[CB], f32x4 (&dx)[CB], const Frag<NPL>& a, const Frag<NPL>& a8, const Frag<NPL> (&b)[CB], const Frag<NPL>& bh,
+                       int lo, int hi) {
 #pragma unroll
         for (int t = 0; t < 3 * NPROD; ++t) {
             if (t < lo || t >= hi) continue;
             const int q = 6 - NPROD + t / 3, c = t % 3;
-            if (c < 2) d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
-            else acc8 = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8);
+            if (c < 2) {
+                if (is_cross(q)) dx[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], dx[c]);
+                else d[c] = mfma(b[c].p[ib[q]], a.p[ia[q]], d[c]);
+            } else {
+                if (is_cross(q)) acc8x = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8x);
+                else acc8 = mfma(bh.p[ib[q]], a8.p[ia[q]], acc8);
+            }
         }
     };
 
@@ -540,15 +588,15 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
         }
         if constexpr (POUT) {
             if (d != 3 && CB == 2 && !p.no_swap) {
-                u32x2 c0[NP], c1[NP];
+                u32x2 c0[NPL], c1[NPL];
                 plane_cut4<NP>(v[0], c0);
                 plane_cut4<NP>(v[CB - 1], c1);
                 const int col = pn0 + wn * 32 + ((lg & 1) ? 16 + (lg - 1) * 4 : lg * 4);
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
                     const u32x2 s0 = __builtin_amdgcn_permlane16_swap(c0[pl][0], c1[pl][0], false, false);
                     const u32x2 s1 = __builtin_amdgcn_permlane16_swap(c0[pl][1], c1[pl][1], false, false);
-                    *reinterpret_cast<u32x4*>(cp + plane_unit(m, col >> 3, nkc_out, NP, pl) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<u32x4*>(cp + plane_unit(m, col >> 3, nkc_out, NPL, pl) * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
             } else if (d != 3) {
 #pragma unroll
@@ -580,7 +628,7 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
         __builtin_amdgcn_sched_barrier(0);
 
         constexpr int kMfma = 0x008, kVmem = 0x010;
-        Frag<NP> a0, a1, a2, a3;
+        Frag<NPL> a0, a1, a2, a3;
         int kc = 0;                           // chunk of the current tile being multiplied
         int cm0 = 0, cn0 = 0, cseq = 0;       // current tile
         tile_coords(0, cm0, cn0);
@@ -600,47 +648,50 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
                 dma(SP);
             } else {
                 constexpr int GQ = (NM - 1) / PIECES;
-                mm_range(acc[0], a0, breg[SP], 0, 1);
+                mm_range(acc[0], accx[0], a0, breg[SP], 0, 1);
                 PP_SB();
                 aread(a1, S, r0 + 1);
                 PP_SB();
                 if constexpr (EARLY) {
     #pragma unroll
                     for (int i = 0; i < PIECES; ++i) {
-                        mm_range(acc[0], a0, breg[SP], 1 + i * GQ, 1 + (i + 1) * GQ);
+                        mm_range(acc[0], accx[0], a0, breg[SP], 1 + i * GQ, 1 + (i + 1) * GQ);
                         PP_SB();
                         dma_piece(SP, i);
                         PP_SB();
                     }
-                    mm_range(acc[0], a0, breg[SP], 1 + PIECES * GQ, NM);
+                    mm_range(acc[0], accx[0], a0, breg[SP], 1 + PIECES * GQ, NM);
                 } else {
-                    mm_range(acc[0], a0, breg[SP], 1, NM);
+                    mm_range(acc[0], accx[0], a0, breg[SP], 1, NM);
                 }
                 if (tile_first) {             // that was the last chunk of the previous tile: its first row block is complete now
     #pragma unroll                        // (no unit of that tile has gone out yet: the queue's last slot is still position 4)
-                    for (int c = 0; c < CB; ++c) { pendq[4][c] = acc[0][c]; acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    for (int c = 0; c < CB; ++c) {
+                        pendq[4][c] = combine(acc[0][c], accx[0][c]);
+                        acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[0][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
             PP_SB();
             // -- section 2: row block r0 + 1 (+ B fragments of chunk g + 2: their registers were last read in section 1)
-            mm_range(acc[1], a1, breg[S], 0, 1);
+            mm_range(acc[1], accx[1], a1, breg[S], 0, 1);
             PP_SB();
             aread(a2, S, r0 + 2);
             PP_SB();
             if constexpr (FIRST || EARLY) {
                 bload(breg[SP]);
-                mm_range(acc[1], a1, breg[S], 1, NM);
+                mm_range(acc[1], accx[1], a1, breg[S], 1, NM);
     #pragma unroll
-                for (int i = 0; i < CB * NP; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NP), 1);
+                for (int i = 0; i < CB * NPL; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(kMfma, (NM - 1) / (CB * NPL), 1);
                     __builtin_amdgcn_sched_group_barrier(kVmem, 1, 1);
                 }
             } else {
-                mm_range(acc[1], a1, breg[S], 1, NM);
+                mm_range(acc[1], accx[1], a1, breg[S], 1, NM);
             }
             PP_SB();
             // -- section 3: row block r0 + 2 (+ DMA, second row half)
-            mm_range(acc[2], a2, breg[S], 0, 1);
+            mm_range(acc[2], accx[2], a2, breg[S], 0, 1);
             PP_SB();
             aread(a1, S, r0 + 3);
             aread(a3, S, 8);
@@ -649,45 +700,48 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
                 constexpr int GQ = (NM - 1) / PIECES;
     #pragma unroll
                 for (int i = 0; i < PIECES; ++i) {
-                    mm_range(acc[2], a2, breg[S], 1 + i * GQ, 1 + (i + 1) * GQ);
+                    mm_range(acc[2], accx[2], a2, breg[S], 1 + i * GQ, 1 + (i + 1) * GQ);
                     PP_SB();
                     dma_piece(SP, i);
                     PP_SB();
                 }
-                mm_range(acc[2], a2, breg[S], 1 + PIECES * GQ, NM);
+                mm_range(acc[2], accx[2], a2, breg[S], 1 + PIECES * GQ, NM);
             } else {
-                mm_range(acc[2], a2, breg[S], 1, NM);
+                mm_range(acc[2], accx[2], a2, breg[S], 1, NM);
             }
             PP_SB();
             // -- section 4: row block r0 + 3 and the share of row block 8 (+ B loads, second row half); the first row block is read
             //    for the next step
             if constexpr (CB == 2) {
-                const Frag<NP> bh = b8(breg[S]);
-                mm_last(acc[3], a1, a3, breg[S], bh, 0, 1);
+                const Frag<NPL> bh = b8(breg[S]);
+                mm_last(acc[3], accx[3], a1, a3, breg[S], bh, 0, 1);
                 PP_SB();
                 aread(a0, S, r0);
                 PP_SB();
                 if constexpr (!FIRST && !EARLY) {
                     bload(breg[SP]);
-                    mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
+                    mm_last(acc[3], accx[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
     #pragma unroll
-                    for (int i = 0; i < CB * NP; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(kMfma, (3 * NPROD - 1) / (CB * NP), 3);
+                    for (int i = 0; i < CB * NPL; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(kMfma, (3 * NPROD - 1) / (CB * NPL), 3);
                         __builtin_amdgcn_sched_group_barrier(kVmem, 1, 3);
                     }
                 } else {
-                    mm_last(acc[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
+                    mm_last(acc[3], accx[3], a1, a3, breg[S], bh, 1, 3 * NPROD);
                 }
             } else {
-                mm_range(acc[3], a1, breg[S], 0, 1);
+                mm_range(acc[3], accx[3], a1, breg[S], 0, 1);
                 PP_SB();
                 aread(a0, S, r0);
                 PP_SB();
                 if constexpr (!FIRST && !EARLY) bload(breg[SP]);
-                mm_range(acc[3], a1, breg[S], 1, NM);
+                mm_range(acc[3], accx[3], a1, breg[S], 1, NM);
                 if (wm == 0) {
     #pragma unroll
-                    for (int q = 6 - NPROD; q < 6; ++q) acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
+                    for (int q = 6 - NPROD; q < 6; ++q) {
+                    if (is_cross(q)) acc8x = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8x);
+                    else acc8 = mfma(breg[S][0].p[ib[q]], a3.p[ia[q]], acc8);
+                }
                 }
             }
             PP_SB();
@@ -707,8 +761,11 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
     #pragma unroll
                 for (int j = 1; j < 4; ++j)
     #pragma unroll
-                    for (int c = 0; c < CB; ++c) { pendq[j - 1][c] = acc[j][c]; acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                pendq[3][0] = acc8; acc8 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < CB; ++c) {
+                        pendq[j - 1][c] = combine(acc[j][c], accx[j][c]);
+                        acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                pendq[3][0] = combine(acc8, acc8x); acc8 = f32x4{0.f, 0.f, 0.f, 0.f}; acc8x = f32x4{0.f, 0.f, 0.f, 0.f};
                 pm0 = cm0; pn0 = cn0; drip = 0;
                 kc = 0;
                 if (cseq + 1 < my_tiles) { ++cseq; tile_coords(cseq, cm0, cn0); }
@@ -733,13 +790,13 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
         if (total - g >= 1) step(I1{}, std::false_type{});
         if (total - g == 2) step(I2{}, std::false_type{});
         const int last = (total - 1) % 3;             // stage of the last chunk: its first row block is still to be multiplied
-        if (last == 0) mm_range(acc[0], a0, breg[0], 0, NM);
-        else if (last == 1) mm_range(acc[0], a0, breg[1], 0, NM);
-        else mm_range(acc[0], a0, breg[2], 0, NM);
+        if (last == 0) mm_range(acc[0], accx[0], a0, breg[0], 0, NM);
+        else if (last == 1) mm_range(acc[0], accx[0], a0, breg[1], 0, NM);
+        else mm_range(acc[0], accx[0], a0, breg[2], 0, NM);
         PP_WAIT_VM_LGKM0(0);                          // the re-fetched tail chunks: nothing may land in LDS after the workgroup ends
         // the last tile was handed to the queue by its last step, except for the first row block
     #pragma unroll
-        for (int c = 0; c < CB; ++c) pendq[4][c] = acc[0][c];      // drip == 0 here: the tile ended with the last step
+        for (int c = 0; c < CB; ++c) pendq[4][c] = combine(acc[0][c], accx[0][c]);      // drip == 0 here: the tile ended with the last step
         for (; drip < 5; ++drip) { load_residual(drip); store_front(drip); }
     };
     if (wm == 0) run(std::true_type{});
@@ -748,7 +805,8 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
 
 // X[rows][K] fp32 -> planes; one thread per 16-byte unit, consecutive threads = consecutive lanes of a fragment
 template <int NP>
-__global__ __launch_bounds__(256) void plane_split_kernel(const float* __restrict__ X, int ld, int rows, int K, char* __restrict__ out) {
+__global__ __launch_bounds__(256) void plane_split_kernel(const float* __restrict__ X, int ld, int rows, int K, float scale,
+                                                          char* __restrict__ out) {
     const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int nkc = K / 32;
     const size_t units = (size_t)(rows / 16) * nkc * 64;
@@ -758,7 +816,10 @@ __global__ __launch_bounds__(256) void plane_split_kernel(const float* __restric
     const int kc = (int)(blk % nkc), rb = (int)(blk / nkc);
     const int row = rb * 16 + (lane & 15), kg = kc * 4 + (lane >> 4);
     const float* src = X + (size_t)row * ld + kg * 8;
-    plane_store8<NP>(out, row, kg, nkc, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+    f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { lo[q] *= scale; hi[q] *= scale; }      // a power of two: exact
+    plane_store8<NP>(out, row, kg, nkc, lo, hi);
 }
 
 inline bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
@@ -775,13 +836,13 @@ template <int EPI, int NP, int CB, bool POUT>
 int launch_pp(const PlaneGemmParams& p, hipStream_t s) {
     constexpr int BN = 4 * CB * 16;
     const int tiles = (p.M / QM) * (p.N / BN);
-    const size_t lds = (size_t)QSTAGE * QRB * NP * 1024 + 1024 + (size_t)p.N * sizeof(float);
+    const size_t lds = (size_t)QSTAGE * QRB * mode_planes(NP) * 1024 + 1024 + (size_t)p.N * sizeof(float);
     const bool stream = pp_stream_enabled() && p.K / 32 >= 6;     // the dripped epilogue needs five steps of the next tile
     static bool attr_set[64] = {};
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
-        const int lds_max = QSTAGE * QRB * NP * 1024 + 1024 + 16384;      // + the bias vector (N <= 4096, checked at entry)
+        const int lds_max = QSTAGE * QRB * mode_planes(NP) * 1024 + 1024 + 16384;      // + the bias vector (N <= 4096, checked at entry)
         ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, NP, CB, POUT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_stream_kernel<EPI, NP, CB, POUT>),
@@ -792,7 +853,8 @@ int launch_pp(const PlaneGemmParams& p, hipStream_t s) {
     static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv"};
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64"};
     prof::Scope ps(CB == 1 ? kNames64[EPI] : kNames[EPI], 2.0 * p.M * p.N * p.K,
-                   2.0 * NP * ((double)p.M * p.K + (double)p.N * p.K) + (p.C ? 4.0 : 0.0) * p.M * p.N + (p.Cp ? 2.0 * NP : 0.0) * p.M * p.N, s);
+                   2.0 * mode_planes(NP) * ((double)p.M * p.K + (double)p.N * p.K) + (p.C ? 4.0 : 0.0) * p.M * p.N +
+                       (p.Cp ? 2.0 * mode_planes(NP) : 0.0) * p.M * p.N, s);
     const int grid = tiles < kStreamCUs ? tiles : kStreamCUs;      // persistent: one workgroup per CU (a multiple of 8: a
                                                                    // workgroup's tiles stay on its XCD), or one per tile if fewer
     if (stream) {
@@ -827,7 +889,7 @@ int launch_pp_epi(const PlaneGemmParams& p, int epi, hipStream_t s) {
 }  // namespace
 
 int launch_gemm_pp(const PlaneGemmParams& p, int epi, int nplane, hipStream_t s) {
-    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "gemm_pp: 2 or 3 planes (got %d)", nplane);
+    ROHM_ARG_CHECK(mode_ok(nplane), "gemm_pp: mode must be 3 (bf16x6), 2 (bf16x3) or 16 (fp16x3), got %d", nplane);
     ROHM_ARG_CHECK(p.Ap && p.Wp && (p.C || p.Cp), "gemm_pp: null operand / no output");
     ROHM_ARG_CHECK(p.N <= 4096, "gemm_pp: N = %d exceeds the 4096 columns the kernel keeps a bias copy for", p.N);
     ROHM_ARG_CHECK(p.M > 0 && p.M % QM == 0 && p.N > 0 && p.N % 64 == 0 && p.K > 0 && p.K % 32 == 0,
@@ -836,18 +898,21 @@ int launch_gemm_pp(const PlaneGemmParams& p, int epi, int nplane, hipStream_t s)
                    "gemm_pp: operands must be 16-byte aligned");
     if (epi == EPI_BIAS_RES) ROHM_ARG_CHECK(p.R && al16(p.R) && p.ldr % 4 == 0, "gemm_pp: bad residual");
     if (epi == EPI_QKV) ROHM_ARG_CHECK(p.qcols % 4 == 0, "gemm_pp: qcols must be a multiple of 4");
-    return nplane == 3 ? launch_pp_epi<3>(p, epi, s) : launch_pp_epi<2>(p, epi, s);
+    if (nplane == 3) return launch_pp_epi<3>(p, epi, s);
+    if (nplane == 2) return launch_pp_epi<2>(p, epi, s);
+    return launch_pp_epi<kModeF16>(p, epi, s);
 }
 
-int launch_plane_split(const float* X, int ld, int rows, int K, int nplane, void* out, hipStream_t s) {
+int launch_plane_split(const float* X, int ld, int rows, int K, int nplane, float scale, void* out, hipStream_t s) {
     ROHM_ARG_CHECK(X && out && rows > 0 && rows % 16 == 0 && K > 0 && K % 32 == 0 && ld % 4 == 0 && al16(X) && al16(out),
                    "plane_split: rows %% 16, K %% 32, 16-byte aligned operands required (rows=%d, K=%d)", rows, K);
-    ROHM_ARG_CHECK(nplane == 2 || nplane == 3, "plane_split: 2 or 3 planes (got %d)", nplane);
+    ROHM_ARG_CHECK(mode_ok(nplane), "plane_split: mode must be 3, 2 or 16 (got %d)", nplane);
     const size_t units = (size_t)(rows / 16) * (K / 32) * 64;
-    prof::Scope ps("plane_split", 0.0, (4.0 + 2.0 * nplane) * rows * K, s);
+    prof::Scope ps("plane_split", 0.0, (4.0 + 2.0 * mode_planes(nplane)) * rows * K, s);
     const dim3 grid((unsigned)((units + 255) / 256));
-    if (nplane == 3) hipLaunchKernelGGL(plane_split_kernel<3>, grid, dim3(256), 0, s, X, ld, rows, K, (char*)out);
-    else hipLaunchKernelGGL(plane_split_kernel<2>, grid, dim3(256), 0, s, X, ld, rows, K, (char*)out);
+    if (nplane == 3) hipLaunchKernelGGL(plane_split_kernel<3>, grid, dim3(256), 0, s, X, ld, rows, K, scale, (char*)out);
+    else if (nplane == 2) hipLaunchKernelGGL(plane_split_kernel<2>, grid, dim3(256), 0, s, X, ld, rows, K, scale, (char*)out);
+    else hipLaunchKernelGGL(plane_split_kernel<kModeF16>, grid, dim3(256), 0, s, X, ld, rows, K, scale, (char*)out);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }

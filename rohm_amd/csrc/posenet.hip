@@ -25,6 +25,7 @@ namespace rohm {
 
 constexpr int kMaxTok = 256;
 constexpr int kLoopChunk = 1024;   // max denoising steps per rohm_posenet_sample_loop call
+constexpr float kF16WeightScale = 256.0f;      // fp16x3 mode: weight planes are cut from 2^8 w
 
 struct LayerW {
     float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
@@ -50,7 +51,7 @@ struct rohm_posenet {
     float *out_w, *out_b;                 // [Cout, D], [Cout]
     float *out_c;                         // LayerNorm folding of the last norm2 into the output head
     bool ln_fold;                         // LayerNorm folded into the surrounding GEMMs (default) or run as a kernel
-    int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2: split-bf16 GEMMs on planes (bf16x6 / bf16x3)
+    int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2 / 16: split GEMMs on planes (bf16x6 / bf16x3 / fp16x3)
     char* wplanes;                        // one allocation holding the weight planes of every layer
     std::vector<rohm::LayerW> layers;
 };
@@ -282,25 +283,26 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         // Split-bf16 mode: every producer hands its consumer bf16 planes (planes.h) -- LayerNorm writes fp32 (the residual)
         // AND planes, attention and the GELU GEMM write planes only; the embed output is cut by a small kernel (once per step).
         const int np = p->nplane;
-        if ((rc = launch_plane_split(h, D, M, D, np, w.hP, s))) return rc;
+        if ((rc = launch_plane_split(h, D, M, D, np, 1.0f, w.hP, s))) return rc;
+        const float wsc = (np == kModeF16) ? 1.0f / kF16WeightScale : 0.f;
         for (int l = 0; l < p->L; ++l) {
             const LayerW& lw = p->layers[l];
             PlaneGemmParams g{};
             g.Ap = w.hP; g.Wp = lw.in_wp; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
-            g.bias = lw.in_b; g.qcols = D; g.qscale = 1.0f / sqrtf((float)(D / p->H));
+            g.bias = lw.in_b; g.qcols = D; g.qscale = 1.0f / sqrtf((float)(D / p->H)); g.acc_scale = wsc;
             if ((rc = launch_gemm_pp(g, EPI_QKV, np, s))) return rc;
             if ((rc = launch_attention_planes(w.qkv, w.ctxP, B, p->H, np, s))) return rc;
             g = PlaneGemmParams{};
             g.Ap = w.ctxP; g.Wp = lw.out_wp; g.C = y; g.ldc = D; g.M = M; g.N = D; g.K = D;
-            g.bias = lw.out_b; g.R = h; g.ldr = D;
+            g.bias = lw.out_b; g.R = h; g.ldr = D; g.acc_scale = wsc;
             if ((rc = launch_gemm_pp(g, EPI_BIAS_RES, np, s))) return rc;
             if ((rc = launch_layernorm_planes(y, lw.n1_w, lw.n1_b, M, D, np, w.yP, s))) return rc;
             g = PlaneGemmParams{};
-            g.Ap = w.yP; g.Wp = lw.l1_wp; g.Cp = w.ffP; g.M = M; g.N = p->F; g.K = D; g.bias = lw.l1_b;
+            g.Ap = w.yP; g.Wp = lw.l1_wp; g.Cp = w.ffP; g.M = M; g.N = p->F; g.K = D; g.bias = lw.l1_b; g.acc_scale = wsc;
             if ((rc = launch_gemm_pp(g, EPI_BIAS_GELU, np, s))) return rc;
             g = PlaneGemmParams{};
             g.Ap = w.ffP; g.Wp = lw.l2_wp; g.C = h; g.ldc = D; g.M = M; g.N = D; g.K = p->F;
-            g.bias = lw.l2_b; g.R = y; g.ldr = D;
+            g.bias = lw.l2_b; g.R = y; g.ldr = D; g.acc_scale = wsc;
             if ((rc = launch_gemm_pp(g, EPI_BIAS_RES, np, s))) return rc;
             if ((rc = launch_layernorm_planes(h, lw.n2_w, lw.n2_b, M, D, np, w.hP, s))) return rc;
         }
@@ -443,14 +445,15 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         // Opt-in for further tuning: ROHM_POSENET_LNFOLD=1.
         const char* e2 = getenv("ROHM_POSENET_LNFOLD");
         p->ln_fold = (e2 && atoi(e2) == 1) && d_model <= 512;       // 8 statistic slots of 64 columns
-        // Opt-in precision ladder: ROHM_GEMM_PRECISION=bf16x6 | bf16x3 runs the four Linears of every
+        // Opt-in precision ladder: ROHM_GEMM_PRECISION=bf16x6 | bf16x3 | fp16x3 runs the four Linears of every
         // encoder layer as split-bf16 GEMMs on planes (gemm_pp.hip).  The default -- and every headline number -- is exact fp32.
         const char* e3 = getenv("ROHM_GEMM_PRECISION");
         p->nplane = 0;
         if (e3 && !strcmp(e3, "bf16x6")) p->nplane = 3;
         else if (e3 && !strcmp(e3, "bf16x3")) p->nplane = 2;
+        else if (e3 && !strcmp(e3, "fp16x3")) p->nplane = kModeF16;
         else if (e3 && *e3 && strcmp(e3, "fp32")) {
-            set_error("posenet_create: ROHM_GEMM_PRECISION must be fp32, bf16x6 or bf16x3 (got '%s')", e3);
+            set_error("posenet_create: ROHM_GEMM_PRECISION must be fp32, bf16x6, bf16x3 or fp16x3 (got '%s')", e3);
             (void)hipFree(p->arena);
             delete p;
             return ROHM_ERR_ARG;
@@ -519,10 +522,13 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         for (int l = 0; l < n_layer && rc4 == ROHM_OK; ++l) {
             LayerW& d = p->layers[l];
             d.in_wp = wp; wp += b_in; d.out_wp = wp; wp += b_out; d.l1_wp = wp; wp += b_l1; d.l2_wp = wp; wp += b_l2;
-            rc4 = launch_plane_split(d.in_w, d_model, 3 * d_model, d_model, p->nplane, d.in_wp, 0);
-            if (!rc4) rc4 = launch_plane_split(d.out_w, d_model, d_model, d_model, p->nplane, d.out_wp, 0);
-            if (!rc4) rc4 = launch_plane_split(d.l1_w, d_model, d_ff, d_model, p->nplane, d.l1_wp, 0);
-            if (!rc4) rc4 = launch_plane_split(d.l2_w, d_ff, d_model, d_ff, p->nplane, d.l2_wp, 0);
+            // fp16 planes: the weights are cut from 2^8 w (Linear weights are ~1e-2: lifted clear of fp16's 6e-5 underflow
+            // threshold, and |w| < 255 still fits); the GEMMs multiply their accumulators by 2^-8
+            const float ws = (p->nplane == kModeF16) ? kF16WeightScale : 1.0f;
+            rc4 = launch_plane_split(d.in_w, d_model, 3 * d_model, d_model, p->nplane, ws, d.in_wp, 0);
+            if (!rc4) rc4 = launch_plane_split(d.out_w, d_model, d_model, d_model, p->nplane, ws, d.out_wp, 0);
+            if (!rc4) rc4 = launch_plane_split(d.l1_w, d_model, d_ff, d_model, p->nplane, ws, d.l1_wp, 0);
+            if (!rc4) rc4 = launch_plane_split(d.l2_w, d_ff, d_model, d_ff, p->nplane, ws, d.l2_wp, 0);
         }
         if (rc4 != ROHM_OK || hipDeviceSynchronize() != hipSuccess) {
             if (rc4 == ROHM_OK) set_error("posenet_create: cutting the weight planes failed");

@@ -174,9 +174,9 @@ class PoseNet(nn.Module):
 
     @property
     def gemm_precision(self):
-        """'fp32' (default) or the opt-in 'bf16x6' / 'bf16x3' the native handle was created under (ROHM_GEMM_PRECISION)."""
+        """'fp32' (default) or the opt-in 'bf16x6' / 'bf16x3' / 'fp16x3' the native handle was created under (ROHM_GEMM_PRECISION)."""
         n = self._native.gemm_planes if self._native is not None else 0
-        return {0: 'fp32', 3: 'bf16x6', 2: 'bf16x3'}[n]
+        return {0: 'fp32', 3: 'bf16x6', 2: 'bf16x3', 16: 'fp16x3'}[n]
 
     def native(self, device=None):
         """The `rohm_posenet_t` for the current weights on `device` (rebuilt if they changed)."""

@@ -56,23 +56,23 @@ def planes_empty(rows, k, nplane, device):
     return torch.empty(n // 2, dtype=torch.int16, device=device)
 
 
-def planes_split(x, nplane=3):
-    """fp32 [rows, K] (rows % 16 == 0, K % 32 == 0) -> its bf16 planes."""
+def planes_split(x, nplane=3, scale=1.0):
+    """fp32 [rows, K] (rows % 16 == 0, K % 32 == 0) -> the planes of scale * x (nplane = mode: 3 / 2 bf16 planes, 16 = two fp16)."""
     _lib.require_hip(x)
     rows, k = x.shape
     out = planes_empty(rows, k, nplane, x.device)
-    check(lib().rohm_planes_split(ptr(x), x.stride(0), rows, k, nplane, ptr(out), stream_ptr(x.device)), 'rohm_planes_split')
+    check(lib().rohm_planes_split(ptr(x), x.stride(0), rows, k, nplane, scale, ptr(out), stream_ptr(x.device)), 'rohm_planes_split')
     return out
 
 
 def gemm_planes(a_planes, w_planes, m, n, k, nplane=3, bias=None, residual=None, epi=EPI_BIAS, qcols=0, qscale=1.0,
-                out_f32=True, out_planes=False, flags=0):
+                out_f32=True, out_planes=False, flags=0, acc_scale=0.0):
     """epi(A @ W^T) from the planes of A [m, k] and W [n, k] -> (fp32 [m, n] or None, planes of it or None)."""
     _lib.require_hip(a_planes, w_planes)
     c = torch.empty(m, n, device=a_planes.device, dtype=torch.float32) if out_f32 else None
     cp = planes_empty(m, n, nplane, a_planes.device) if out_planes else None
     check(lib().rohm_gemm_planes(ptr(a_planes), ptr(w_planes), ptr(c), n, ptr(cp), m, n, k, ptr(bias), ptr(residual),
-                                 residual.stride(0) if residual is not None else 0, qcols, qscale, epi, nplane, flags,
+                                 residual.stride(0) if residual is not None else 0, qcols, qscale, acc_scale, epi, nplane, flags,
                                  stream_ptr(a_planes.device)), 'rohm_gemm_planes')
     return c, cp
 

@@ -42,7 +42,7 @@ def main():
                 out = torch.empty(M, N, device=dev)
                 bias = torch.zeros(N, device=dev)
                 from rohm_amd._lib import check, lib, ptr, stream_ptr
-                fn = lambda: check(lib().rohm_gemm_planes(ptr(ap), ptr(wp), ptr(out), N, None, M, N, K, ptr(bias), None, 0, 0, 1.0, 0,
+                fn = lambda: check(lib().rohm_gemm_planes(ptr(ap), ptr(wp), ptr(out), N, None, M, N, K, ptr(bias), None, 0, 0, 1.0, 0.0, 0,
                                                           nplane, 0, stream_ptr(dev)), 'gemm')
                 ts[K] = timed(fn)
             tiles_per_cu = (M // 144) * (N // 128) / 256.0

@@ -21,15 +21,19 @@ def _dev():
     return torch.device('cuda', 0)
 
 
-@pytest.mark.parametrize('nplane', [3, 2])
+@pytest.mark.parametrize('nplane', [3, 2, 16])
 def test_planes_split_is_the_cut_in_fragment_major_layout(nplane):
     from rohm_amd import ops
     x = seeded(11, 144 * 2, 96) * 3.0
-    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-20, 3e20, 0.333333343, -7.0])
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-20, 3e20 if nplane != 16 else 6.0e4, 0.333333343, -7.0])
+    x[1, :4] = torch.tensor([1e-5, -3e-6, 6.1e-5, 2049.0])          # fp16 subnormal range / a tie of round-to-nearest-even
     got = ops.planes_split(x.to(_dev()), nplane).cpu().numpy()
     assert np.array_equal(got, oplanes.encode(x.numpy(), nplane))
     if nplane == 3:
         assert np.array_equal(oplanes.decode(got, 288, 96, 3).astype(np.float64).sum(0), x.numpy().astype(np.float64))
+    if nplane == 16:
+        rec = oplanes.value(oplanes.decode(got, 288, 96, 16), 16)
+        assert np.abs(rec - x.numpy().astype(np.float64)).max() <= 2.0 ** -22 * np.abs(x.numpy()).max()
 
 
 # shapes: one tile / several; K chunk counts 1, 2, 3, 4, 16, 17, 18, 32 (every remainder of the 3-stage ring);
@@ -44,7 +48,8 @@ SHAPES = [(144, 64, 32), (144, 128, 64), (288, 192, 96), (144, 512, 128), (144 *
 
 @pytest.mark.parametrize('M,N,K', SHAPES)
 @pytest.mark.parametrize('epi', [0, 1, 2, 3])
-def test_gemm_planes_bf16x6_meets_the_fp32_bar(M, N, K, epi):
+@pytest.mark.parametrize('mode', [3, 16])
+def test_gemm_planes_bf16x6_and_fp16x3_meet_the_fp32_bar(M, N, K, epi, mode):
     from rohm_amd import ops
     if M * N > 144 * 64 * 512 and epi in (0, 3) and K > 512:
         pytest.skip('covered by the other epilogues at this size')
@@ -58,8 +63,10 @@ def test_gemm_planes_bf16x6_meets_the_fp32_bar(M, N, K, epi):
     if epi == 3:
         ref[:, :N // 2] *= 0.25
     d = _dev()
-    ap, wp = ops.planes_split(a.to(d), 3), ops.planes_split(w.to(d), 3)
-    out, _ = ops.gemm_planes(ap, wp, M, N, K, 3, bias.to(d), res.to(d) if epi == 2 else None, epi, qcols=N // 2, qscale=0.25)
+    ws = 256.0 if mode == 16 else 1.0      # fp16 weight planes are cut from 2^8 w, the accumulator is scaled back (posenet.hip)
+    ap, wp = ops.planes_split(a.to(d), mode), ops.planes_split(w.to(d), mode, scale=ws)
+    out, _ = ops.gemm_planes(ap, wp, M, N, K, mode, bias.to(d), res.to(d) if epi == 2 else None, epi, qcols=N // 2, qscale=0.25,
+                             acc_scale=1.0 / ws)
     assert max_abs(out.cpu(), ref) < 2e-5 * math.sqrt(K / 32)       # the exact-fp32 kernel's bar
 
 
@@ -86,7 +93,7 @@ def test_gemm_planes_identity_asymmetric():
 
 @pytest.mark.parametrize('M,N,K', [(144 * 64, 1024, 512), (144 * 2, 1024, 512), (144 * 64, 512, 64), (144 * 65, 1024, 192),
                                    (144 * 40, 1024, 224), (144 * 65, 1024, 320)])
-@pytest.mark.parametrize('nplane', [3, 2])
+@pytest.mark.parametrize('nplane', [3, 2, 16])
 @pytest.mark.parametrize('flags', [0, 1])
 def test_gemm_plane_output_is_the_cut_of_the_fp32_output(M, N, K, nplane, flags):
     """The GELU GEMM that feeds FF2 writes planes only; both store forms (lane-swapped 16-byte units / 8-byte halves) and
@@ -102,7 +109,7 @@ def test_gemm_plane_output_is_the_cut_of_the_fp32_output(M, N, K, nplane, flags)
 
 
 @pytest.mark.parametrize('M', [16, 144, 144 * 7])
-@pytest.mark.parametrize('nplane', [3, 2])
+@pytest.mark.parametrize('nplane', [3, 2, 16])
 def test_layernorm_planes(M, nplane):
     from rohm_amd import ops
     x, g, b = seeded(M, M, 512) * 3 + 0.5, seeded(1, 512), seeded(2, 512)
@@ -116,7 +123,7 @@ def test_layernorm_planes(M, nplane):
 
 
 @pytest.mark.parametrize('n_seq,n_head', [(1, 4), (3, 4), (32, 4), (33, 4), (64, 4)])      # split / full launch shapes
-@pytest.mark.parametrize('nplane', [3, 2])
+@pytest.mark.parametrize('nplane', [3, 2, 16])
 def test_attention_planes(n_seq, n_head, nplane):
     """Plane output runs the P.V MFMAs with exchanged operands (the same products in the same order): the planes must be the
     cut of what the fp32 kernel stores."""
@@ -128,8 +135,8 @@ def test_attention_planes(n_seq, n_head, nplane):
     dec = oplanes.decode(pl, n_seq * 144, D, nplane)
     want = np.stack(oplanes.cut(ctx.cpu().numpy(), nplane))
     if not np.array_equal(dec, want):                  # tolerate a different rounding of the exchanged MFMA, nothing more
-        assert nplane == 3
-        assert np.abs(dec.astype(np.float64).sum(0) - ctx.cpu().numpy()).max() < 2e-6
+        assert nplane in (3, 16)
+        assert np.abs(oplanes.value(dec, nplane) - ctx.cpu().numpy()).max() < 2e-6
 
 
 def test_shape_errors_are_raised_before_any_launch():
@@ -142,6 +149,8 @@ def test_shape_errors_are_raised_before_any_launch():
         ops.gemm_planes(ap, wp, 100, 64, 32)                            # M % 144
     with pytest.raises(_lib.RohmHipError):
         ops.gemm_planes(ap, wp, 144, 64, 32, nplane=4)
+    with pytest.raises(_lib.RohmHipError):
+        ops.planes_split(torch.zeros(16, 32, device=d), 8)
 
 
 def test_the_one_tile_per_workgroup_kernel_too():

@@ -1,10 +1,11 @@
 """GPU: the opt-in split-bf16 mode of PoseNet (ROHM_GEMM_PRECISION, read when the native handle is created -> exercised in a
 subprocess) against the SAME tests and the SAME bars as the exact-fp32 default.
 
-bf16x6 (three planes, six bf16 MFMA products per fp32 product) must pass the whole PoseNet file: the reference-golden
-forward, the fused and step-wise 8-step loops, ALL 1000 ancestral steps of one clip against the reference's own run
-(posenet_loop1000.npz), and the headline batch (64 clips x 1000 steps, clip 0 on the reference golden, bit-identical on
-re-run).  bf16x3 (two planes) is held to the north-star tolerance on the forward, the 8-step loops and the 1000-step run.
+bf16x6 (three bf16 planes, six MFMA products per fp32 product) and fp16x3 (two fp16 planes, three products, cross terms in a
+scaled second accumulator) must each pass the whole PoseNet file: the reference-golden forward, the fused and step-wise 8-step
+loops, ALL 1000 ancestral steps of one clip against the reference's own run (posenet_loop1000.npz), and the headline batch
+(64 clips x 1000 steps, clip 0 on the reference golden, bit-identical on re-run).  bf16x3 (two bf16 planes) is held to the
+north-star tolerance on the forward, the 8-step loops and the 1000-step run.
 The kernels of the mode are tested one by one in tests/test_gpu_planes.py."""
 import os
 import subprocess
@@ -27,6 +28,11 @@ def _run(mode, args, timeout=1500, **extra):
 
 def test_bf16x6_passes_the_whole_posenet_suite_at_the_fp32_bars():
     out = _run('bf16x6', [PN, 'tests/test_gpu_precision_ladder.py::test_mode_is_active'])
+    assert ' passed' in out and 'failed' not in out
+
+
+def test_fp16x3_passes_the_whole_posenet_suite_at_the_fp32_bars():
+    out = _run('fp16x3', [PN, 'tests/test_gpu_precision_ladder.py::test_mode_is_active'])
     assert ' passed' in out and 'failed' not in out
 
 

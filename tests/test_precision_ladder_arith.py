@@ -77,3 +77,30 @@ def test_plane_layout_restatement_round_trips():
         assert got == op.cut(x, nplane)[p][row, k]
     h, m = op.cut(np.float32([1.2345678]), 2)
     assert is_bf16(h) and is_bf16(m) and abs(float(h[0]) + float(m[0]) - 1.2345678) < 1.2345678 * 2.0 ** -15
+
+
+def test_fp16_two_plane_split_is_fp32_class_with_three_products():
+    """The fp16x3 mode (planes.h MODE 16): h = fp16(x), l' = fp16((x - h) 2^11) reproduce x to 2^-24 |x| over fp16's normal range, and
+    the three products it keeps (a_h w_h; a_h w_l' + a_l' w_h at weight 2^-11) leave ~2^-22 per product -- between bf16x6
+    (2^-23) and fp32's own rounding, four orders of magnitude below bf16x3."""
+    from oracle import planes as op
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(200000) * 3, rng.standard_normal(2000) * 1e-3, rng.uniform(-6e4, 6e4, 2000)]).astype(np.float32)
+    h, lp = op.cut(x, 16)
+    assert np.all(h == h.astype(np.float16).astype(np.float32)) and np.all(lp == lp.astype(np.float16).astype(np.float32))
+    ok = np.abs(x) >= 6.2e-5
+    rel = np.abs(op.value(np.stack([h, lp]), 16) - x.astype(np.float64))[ok] / np.abs(x[ok])
+    assert rel.max() < 2.0 ** -22 and np.percentile(rel, 99) < 2.0 ** -23      # l' carries 11 more bits behind h's 11
+    assert np.abs(lp).max() <= np.abs(x).max()                                 # scaled remainder sits next to h: no underflow, no overflow
+    K = 1024
+    a = rng.standard_normal((64, K)).astype(np.float32)
+    w = (rng.standard_normal((64, K)) * 0.03).astype(np.float32)
+    exact = np.einsum('ik,jk->ij', a.astype(np.float64), w.astype(np.float64))
+    (ah, al), (wh, wl) = op.cut(a, 16), op.cut(w * np.float32(256.0), 16)      # weights are cut from 2^8 w (posenet.hip)
+    d = lambda p, q: np.einsum('ik,jk->ij', p.astype(np.float64), q.astype(np.float64))
+    emu = (d(ah, wh) + (d(ah, wl) + d(al, wh)) / 2048.0) / 256.0
+    scale = np.sqrt(K) * 0.03
+    e16 = np.abs(emu - exact).max() / scale
+    e32 = np.abs((a @ w.T).astype(np.float64) - exact).max() / scale
+    assert e16 < 2.0 ** -20, e16
+    assert e16 < 8 * max(e32, 2.0 ** -24)
