@@ -114,3 +114,33 @@ def test_force_dist_at_world_size_1_goes_through_the_process_group():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = _json_line(r.stdout)
     assert rec['n_gpus'] == 1 and rec['gathered_clips'] == 3 and rec['ranks_seen'] == [0]
+
+
+def test_extras_attach_second_line_and_configs_and_survive_a_failing_child(monkeypatch):
+    """The N = 1 record's `second_line` / `configs` come from child processes; a child that fails must leave an {'error': ...}
+    entry, never cost the headline line.  (Pure host logic: the children are stubbed.)"""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location('bench_mod', BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    def fake_child(argv, env_extra=None, timeout=600):
+        calls.append((tuple(argv), dict(env_extra or {})))
+        if 'egobody' in argv:
+            return {'error': 'rc=1', 'argv': list(argv)}
+        mode = (env_extra or {}).get('ROHM_GEMM_PRECISION', 'fp32')
+        return {'metric': 'm', 'value': 30.0 if mode != 'fp32' else 18.0, 'unit': 'clips/s', 'ms_per_step': 1.0, 'steps': 1, 'warmup': 1,
+                'dtype': mode, 'config': {'workload': ' '.join(argv)},
+                'roofline': {'achieved': 1.0, 'peak': 2.0, 'frac': 0.5, 'unit': 'TFLOP/s', 'kernel': 'k', 'bound': 'mfma'},
+                'accuracy': {'max_abs_vs_reference': 5e-6}, 'child_wall_s': 1.0}
+    monkeypatch.setattr(bench, 'run_child', fake_child)
+    second, cfg = bench.extras(types.SimpleNamespace(ddpm_steps=1000, batch=64))
+    assert second['mode'] == 'fp16x3' and second['value'] == 30.0 and second['accuracy']['max_abs_vs_reference'] == 5e-6
+    assert second['roofline']['frac'] == 0.5 and 'NEVER the headline' in second['label']
+    assert second['also']['bf16x6']['value'] == 30.0
+    assert set(cfg) == {'b32', 'scheme_b32', 'prox_b32', 'egobody_b32'}
+    assert cfg['b32']['value'] == 18.0 and cfg['egobody_b32']['error'] == 'rc=1'
+    # the precision variable reaches only the second-line children; every child runs without the extras and the CPU leg
+    assert [c[1].get('ROHM_GEMM_PRECISION') for c in calls] == ['fp16x3', 'bf16x6', None, None, None, None]

@@ -5,6 +5,7 @@ Producers of bf16 planes (rohm_planes_split, the LayerNorm / attention / GELU-GE
 at the exact-fp32 kernel's own bar (tests/test_gpu_kernels.py::test_gemm) for three planes, and to the north-star class
 for two.  The whole-network proofs (reference goldens, 1000 steps, 64 clips) are in tests/test_gpu_precision_ladder.py."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -40,10 +41,12 @@ def test_planes_split_is_the_cut_in_fragment_major_layout(nplane):
 # 144 x 128 tiles (>= 192 of them) and 144 x 64 tiles (fewer)
 # -- and for the persistent stream kernel (K >= 192): one, two and three tiles per workgroup, uneven tile counts (260, 320, 528
 # tiles on 256 workgroups), tiles of five to seven chunks
-SHAPES = [(144, 64, 32), (144, 128, 64), (288, 192, 96), (144, 512, 128), (144 * 3, 512, 512), (144 * 2, 512, 544),
+_ALL_SHAPES = [(144, 64, 32), (144, 128, 64), (288, 192, 96), (144, 512, 128), (144 * 3, 512, 512), (144 * 2, 512, 544),
           (144 * 2, 256, 576), (144 * 3, 512, 1024), (144 * 64, 512, 512), (144 * 64, 1536, 512), (144 * 64, 1024, 512),
           (144 * 64, 512, 1024), (144 * 32, 512, 512), (144 * 32, 1536, 512), (144 * 65, 512, 192), (144 * 40, 512, 224),
           (144 * 66, 1024, 160), (144 * 66, 1024, 512), (144 * 65, 512, 320), (144 * 64, 1536, 352)]
+# the child run of the one-workgroup-per-tile kernel only needs the shapes the default path gives to the stream kernel (K >= 192)
+SHAPES = [sh for sh in _ALL_SHAPES if sh[2] >= 192 and sh[0] * sh[1] <= 144 * 66 * 1024] if os.environ.get('ROHM_PP_STREAM') == '0' else _ALL_SHAPES
 
 
 @pytest.mark.parametrize('M,N,K', SHAPES)
@@ -156,7 +159,6 @@ def test_shape_errors_are_raised_before_any_launch():
 def test_the_one_tile_per_workgroup_kernel_too():
     """ROHM_PP_STREAM=0 (read at the first launch -> a child process) selects gemm_pp_kernel, which the default path only uses
     for K < 192: the GEMM tests of this file must hold for it as well."""
-    import os
     import subprocess
     import sys
     if 'ROHM_PP_STREAM' in os.environ:
