@@ -743,12 +743,6 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
         }
     } else if (tiles128 >= want && p.N % 128 == 0) {
         best = 128;
-    } else if (EPI == EPI_OUT_T && p.conv_taps == 0 && p.N % 128 == 0) {
-        // the transposed output head (M = 272 channels = two row tiles): at B = 64 the 144 x 64 tiling is 288 workgroups = two
-        // rounds, the second one an eighth full; 144 x 128 is 144 workgroups in one round (same cost model as above)
-        const long t64 = (long)tm * ((p.N + 63) / 64), t128 = tiles128;
-        const long c64 = ((t64 + want - 1) / want) * (64 + 24), c128 = ((t128 + want - 1) / want) * (128 + 24);
-        if (c128 < c64) best = 128;
     }
     if constexpr (EPI != EPI_OUT_T) {
         if (p.conv_taps == 0) {

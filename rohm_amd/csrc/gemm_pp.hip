@@ -1,9 +1,15 @@
-// Split-bf16 GEMM on READY-MADE planes for gfx950 (opt-in precision ladder):
-//   C[M,N] = epi(A[M,K] . W[N,K]^T),  every fp32 product a.w emulated by bf16 MFMA products of the bf16 PLANES of the
-//   operands (planes.h), fp32 accumulation.  Same Linears as gemm_f32.hip (model/posenet.py:63-69).
+// Split GEMM on READY-MADE 16-bit planes for gfx950 (opt-in precision ladder):
+//   C[M,N] = epi(A[M,K] . W[N,K]^T),  every fp32 product a.w emulated by 16-bit MFMA products of the PLANES of the operands
+//   (planes.h), fp32 accumulation.  Same Linears as gemm_f32.hip (model/posenet.py:63-69).  The template parameter NP is the MODE:
 //
-//   three planes (bf16x6): the six plane products of weight >= 2^-16 -- fp32-class accuracy
-//   two planes   (bf16x3): three products (~2^-16 per product)
+//   NP = 16 (fp16x3): two fp16 planes h, l' = (x - h) 2^11; three products: a_h w_h -> accumulator, a_h w_l' + a_l' w_h -> a second
+//                     accumulator that enters with weight 2^-11 when the tile is handed over (~2^-22 per product)
+//   NP = 3  (bf16x6): three bf16 planes; the six plane products of weight >= 2^-16 -- fp32-class accuracy
+//   NP = 2  (bf16x3): two bf16 planes, three products (~2^-16 per product)
+//
+// The row-block layout of wave (wm, wn) in both kernels: row blocks 4 wm .. 4 wm + 3 of its CB column blocks, plus of row block 8
+// the column block(s) of half wm -- every wave multiplies 4 CB + CB / 2 blocks per chunk, every SIMD (waves w, w + 4) nine row
+// blocks' worth.
 //
 // Round 2 cut the planes INSIDE the GEMM (fp32 tiles staged through LDS, cut by the VALU, written back to LDS as fragments):
 // 221 KB of LDS traffic per K chunk for 1.0 us of MFMA -- the LDS pipe, not the matrix core, set the pace (MFMA busy 0.36).
@@ -14,9 +20,9 @@
 //   * the B fragments never touch LDS: a wave loads the planes of its own 32 (16) columns straight into registers
 //     (1 KiB contiguous per load), two chunks ahead;
 //   -> 27 KB of DMA + 108 KB of fragment reads per chunk at 144 x 128, no VALU work in the loop at all.
-//   * 8 waves = two per SIMD on a 144 x (64 | 128) tile, 2 x 4 wave grid: wave (wm, wn) owns row blocks 0-4 / 5-8 of the
-//     column group wn; waves w and w + 4 share a SIMD, so every SIMD carries nine row blocks and the partner issues MFMAs
-//     while a wave sits in a DMA issue, an LDS wait or the barrier;
+//   * 8 waves = two per SIMD on a 144 x (64 | 128) tile, 2 x 4 wave grid (wave (wm, wn): row half wm of column group wn);
+//     waves w and w + 4 share a SIMD, so every SIMD carries nine row blocks and the partner issues MFMAs while a wave sits
+//     in a DMA issue, an LDS wait or the barrier;
 //   * three LDS stages, DMA two chunks ahead, ONE barrier per chunk; the barrier sits between two MFMA groups whose
 //     operands are already in registers (the first row block of chunk k is multiplied AFTER the barrier that publishes chunk
 //     k + 1), so no LDS latency is exposed behind it; waits are counted (vmcnt(ops of the youngest chunk)).

@@ -1,4 +1,4 @@
-// bf16 PLANES of fp32 tensors (opt-in precision ladder): layout and the cut, shared by every kernel that
+// 16-bit PLANES (bf16 or fp16) of fp32 tensors (opt-in precision ladder): layout and the cut, shared by every kernel that
 // produces or consumes them (gemm_pp.hip, elementwise.hip LayerNorm, attention_f32.hip, posenet.hip).
 //
 // MODE 3 / 2 -- bf16 planes cut by truncation:  h = upper 16 bits of x,  m = upper 16 bits of x - h,  l = x - h - m.  Every
