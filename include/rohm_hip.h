@@ -106,6 +106,19 @@ int rohm_planes_split(const float* X, int ldx, int rows, int K, int nplane, floa
 int rohm_gemm_planes(const void* Ap, const void* Wp, float* C, int ldc, void* Cp, int M, int N, int K,
                      const float* bias, const float* R, int ldr, int qcols, float qscale, float acc_scale, int epi,
                      int nplane, int flags, rohm_stream_t stream);
+/* rohm_gemm_planes with nn.LayerNorm (model/posenet.py:60-69 norm1 / norm2 of nn.TransformerEncoderLayer, post-norm) FOLDED into
+ * the GEMMs around it (two-plane modes, K >= 192): the normalised tensor is never stored.  Row statistics travel as partial
+ * (sum, sum of squares) pairs per 16 columns, row-block major: stats[row / 16][ln_dim / 16][row % 16][2] floats.
+ *   out_stats (epi 2, ln_dim == N): receives the statistics of the result rows.
+ *   ln_stats (epi 1 / 3, ln_dim == K): Ap are the planes of the RAW tensor x, Wp those of W[n][k] gamma[k], bias holds
+ *     d[n] = b[n] + sum_k beta[k] W[n][k], ln_c holds c[n] = sum_k gamma[k] W[n][k]; the epilogue computes
+ *     (acc - mu c) rstd + d = LN(x) W^T + b.
+ *   r_stats (epi 2, ln_dim == N): R is raw as well; LN(R) = (R - mu) rstd r_gamma + r_beta is what is added.
+ * Any of the three may be null. */
+int rohm_gemm_planes_ln(const void* Ap, const void* Wp, float* C, int ldc, void* Cp, int M, int N, int K,
+                        const float* bias, const float* R, int ldr, int qcols, float qscale, float acc_scale, int epi,
+                        int nplane, const float* ln_stats, const float* ln_c, const float* r_stats, const float* r_gamma,
+                        const float* r_beta, float* out_stats, int ln_dim, float ln_eps, rohm_stream_t stream);
 /* rohm_layernorm_f32 that also writes the planes of its result (M % 16 == 0); the fp32 result is bit-identical. */
 int rohm_layernorm_planes_f32(float* x, const float* gamma, const float* beta, int M, int D, int nplane,
                               void* planes, rohm_stream_t stream);

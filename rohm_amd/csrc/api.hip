@@ -148,6 +148,18 @@ int rohm_gemm_planes(const void* Ap, const void* Wp, float* C, int ldc, void* Cp
     return launch_gemm_pp(g, epi, nplane, (hipStream_t)stream);
 }
 
+int rohm_gemm_planes_ln(const void* Ap, const void* Wp, float* C, int ldc, void* Cp, int M, int N, int K,
+                        const float* bias, const float* R, int ldr, int qcols, float qscale, float acc_scale, int epi, int nplane,
+                        const float* ln_stats, const float* ln_c, const float* r_stats, const float* r_gamma,
+                        const float* r_beta, float* out_stats, int ln_dim, float ln_eps, rohm_stream_t stream) {
+    PlaneGemmParams g{};
+    g.Ap = Ap; g.Wp = Wp; g.C = C; g.ldc = ldc; g.Cp = Cp; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.R = R; g.ldr = ldr; g.qcols = qcols; g.qscale = qscale; g.acc_scale = acc_scale;
+    g.ln_stats = ln_stats; g.ln_c = ln_c; g.r_stats = r_stats; g.r_gamma = r_gamma; g.r_beta = r_beta; g.out_stats = out_stats;
+    g.ln_dim = ln_dim; g.ln_eps = ln_eps;
+    return launch_gemm_pp(g, epi, nplane, (hipStream_t)stream);
+}
+
 int rohm_layernorm_planes_f32(float* x, const float* gamma, const float* beta, int M, int D, int nplane,
                               void* planes, rohm_stream_t stream) {
     ROHM_ARG_CHECK(x && gamma && beta && planes, "layernorm_planes: null pointer");

@@ -7,6 +7,7 @@
 #include "../../include/rohm_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace rohm {
 

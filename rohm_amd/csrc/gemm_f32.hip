@@ -408,48 +408,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         // N % BN == 0 and 16-byte alignment of C / R / bias / tables, so the hot instantiation carries no edge
         // masks and only 16-byte accesses.
         const bool vec_ok = FULL || ((p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0));
-        auto emit = [&](int m, int nb, f32x4 a, int sl) {
-            if (!FULL && (m >= p.M || nb >= p.N)) return;
-            if constexpr (EPI == EPI_BIAS) {
-                if (ksplit > 1) {      // raw partial tile; ld_partial is a multiple of 4 and covers N rounded up
-                    *reinterpret_cast<f32x4*>(p.partial + ((size_t)split * p.M + m) * p.ld_partial + nb) = a;
-                    return;
-                }
-            }
-            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // An output unit (4 consecutive columns of one row) needs, besides its accumulators, values from memory: the bias, the
+        // fold vectors, the residual.  They are read in `load_ops`, used in `finish`.  The struct members are plain pointers (no
+        // restrict), so hipcc must assume that a store to C changes them and keeps every load behind the store before it: emitted
+        // unit by unit, each unit waits vmcnt(0) for its own loads AND for the acknowledgement of the store before -- one
+        // dependent round trip to memory per unit (18 to 54 per lane).  The hot instantiations (PRE) therefore read the operands of
+        // ALL units first (identical addresses -- the bias of a column group -- collapse into one load) and then only compute
+        // and store.
+        struct ColOps { f32x4 bias, c4, g4, b4; };      // what depends on the column group only
+        constexpr bool PRE = FULL && !CONV && EPI != EPI_EMBED;
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto load_col = [&](int nb) __attribute__((always_inline)) {
+            ColOps o{zero4, zero4, zero4, zero4};
+            if (!FULL && nb >= p.N) return o;
             if constexpr (FULL) {
-                if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                if (p.bias) o.bias = *reinterpret_cast<const f32x4*>(p.bias + nb);
             } else if (p.bias) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bias4[q] = (nb + q < p.N) ? p.bias[nb + q] : 0.f;
+                for (int q = 0; q < 4; ++q) o.bias[q] = (nb + q < p.N) ? p.bias[nb + q] : 0.f;
             }
-            f32x4 v;
-            bool folded = false;
             if constexpr (LN_CONSUMER) {
-                if (p.ln_stats) {       // (acc - mu c_n) rstd + d_n ; d_n arrives as the bias
-                    folded = true;
-                    f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.ln_stats) {
                     if constexpr (FULL) {
-                        c4 = *reinterpret_cast<const f32x4*>(p.ln_c + nb);
+                        o.c4 = *reinterpret_cast<const f32x4*>(p.ln_c + nb);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) c4[q] = (nb + q < p.N) ? p.ln_c[nb + q] : 0.f;
+                        for (int q = 0; q < 4; ++q) o.c4[q] = (nb + q < p.N) ? p.ln_c[nb + q] : 0.f;
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (a[q] - amu[sl] * c4[q]) * ars[sl] + bias4[q];
                 }
             }
-            if (!folded) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = a[q] + bias4[q];
-            }
-            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
-            }
             if constexpr (EPI == EPI_BIAS_RES) {
+                if (p.r_stats) {
+                    if constexpr (FULL) {
+                        o.g4 = *reinterpret_cast<const f32x4*>(p.r_gamma + nb);
+                        o.b4 = *reinterpret_cast<const f32x4*>(p.r_beta + nb);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (nb + q < p.N) { o.g4[q] = p.r_gamma[nb + q]; o.b4[q] = p.r_beta[nb + q]; }
+                    }
+                }
+            }
+            return o;
+        };
+        auto load_res = [&](int m, int nb) __attribute__((always_inline)) {
+            f32x4 rr = zero4;
+            if constexpr (EPI == EPI_BIAS_RES) {
+                if (!FULL && (m >= p.M || nb >= p.N)) return rr;
                 const float* rp = p.R + (size_t)m * p.ldr + nb;
-                f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (FULL || (vec_ok && (p.ldr % 4 == 0) && (((uintptr_t)p.R & 15) == 0))) {
                     rr = *reinterpret_cast<const f32x4*>(rp);
                 } else {
@@ -457,18 +463,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     for (int q = 0; q < 4; ++q)
                         if (nb + q < p.N) rr[q] = rp[q];
                 }
+            }
+            return rr;
+        };
+        auto finish = [&](int m, int nb, f32x4 a, int sl, const ColOps& o, f32x4 rr) __attribute__((always_inline)) {
+            if (!FULL && (m >= p.M || nb >= p.N)) return;
+            if constexpr (EPI == EPI_BIAS) {
+                if (ksplit > 1) {      // raw partial tile; ld_partial is a multiple of 4 and covers N rounded up
+                    *reinterpret_cast<f32x4*>(p.partial + ((size_t)split * p.M + m) * p.ld_partial + nb) = a;
+                    return;
+                }
+            }
+            f32x4 v;
+            bool folded = false;
+            if constexpr (LN_CONSUMER) {
+                if (p.ln_stats) {       // (acc - mu c_n) rstd + d_n ; d_n arrives as the bias
+                    folded = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (a[q] - amu[sl] * o.c4[q]) * ars[sl] + o.bias[q];
+                }
+            }
+            if (!folded) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = a[q] + o.bias[q];
+            }
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+            }
+            if constexpr (EPI == EPI_BIAS_RES) {
                 if (p.r_stats) {        // the residual is LN(raw): normalise it on the fly
-                    f32x4 g4 = f32x4{0.f, 0.f, 0.f, 0.f}, b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (FULL) {
-                        g4 = *reinterpret_cast<const f32x4*>(p.r_gamma + nb);
-                        b4 = *reinterpret_cast<const f32x4*>(p.r_beta + nb);
-                    } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (nb + q < p.N) { g4[q] = p.r_gamma[nb + q]; b4[q] = p.r_beta[nb + q]; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rr[q] = (rr[q] - rmu[sl]) * rrs[sl] * g4[q] + b4[q];
+                    for (int q = 0; q < 4; ++q) rr[q] = (rr[q] - rmu[sl]) * rrs[sl] * o.g4[q] + o.b4[q];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += rr[q];
@@ -507,26 +533,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     if (nb + q < p.N) cp[q] = v[q];
             }
         };
-        if constexpr (M32) {
-            // acc32[rb][cb][4q' + r] = C[m0 + rb*32 + li32][nw + cb*32 + 8q' + 4*lg32 + r]
+        // every unit of this lane, in a fixed order with compile-time indices: fn(unit, column group, row, first column, accumulators, row slot)
+        constexpr int NUNIT = M32 ? 16 * NCB32 + NCB : NCB * NRB;
+        constexpr int NCG = M32 ? 4 * NCB32 + NCB : NCB;
+        auto for_units = [&](auto&& fn) __attribute__((always_inline)) {
+            if constexpr (M32) {
+                // acc32[rb][cb][4q' + r] = C[m0 + rb*32 + li32][nw + cb*32 + 8q' + 4*lg32 + r]
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < NCB32; ++cb)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const f32x16& a = acc32[rb * NCB32 + cb];
+                            fn((rb * NCB32 + cb) * 4 + qq, cb * 4 + qq, m0 + rb * 32 + li32, nw + cb * 32 + 8 * qq + 4 * lg32,
+                               f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]}, rb);
+                        }
+                // acc16[c][r] = C[m0 + 128 + li][nw + c*16 + 4*lg + r]
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) fn(16 * NCB32 + c, 4 * NCB32 + c, m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c], 4);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                    for (int r = 0; r < NRB; ++r) fn(c * NRB + r, c, m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c], r);
+            }
+        };
+        if constexpr (PRE) {
+            ColOps col[NCG];
+            if constexpr (M32) {
 #pragma unroll
                 for (int cb = 0; cb < NCB32; ++cb)
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const f32x16& a = acc32[rb * NCB32 + cb];
-                        emit(m0 + rb * 32 + li32, nw + cb * 32 + 8 * qq + 4 * lg32,
-                             f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]}, rb);
-                    }
-            // acc16[c][r] = C[m0 + 128 + li][nw + c*16 + 4*lg + r]
+                    for (int qq = 0; qq < 4; ++qq) col[cb * 4 + qq] = load_col(nw + cb * 32 + 8 * qq + 4 * lg32);
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) emit(m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c], 4);
+                for (int c = 0; c < NCB; ++c) col[4 * NCB32 + c] = load_col(nw + c * 16 + lg * 4);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) col[c] = load_col(nw + c * 16 + lg * 4);
+            }
+            if constexpr (EPI == EPI_BIAS_RES) {
+                f32x4 res[NUNIT];
+                for_units([&](int i, int, int m, int nb, f32x4, int) __attribute__((always_inline)) { res[i] = load_res(m, nb); });
+                for_units([&](int i, int cg, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, col[cg], res[i]); });
+            } else {
+                for_units([&](int, int cg, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, col[cg], zero4); });
+            }
         } else {
-#pragma unroll
-            for (int c = 0; c < NCB; ++c)
-#pragma unroll
-                for (int r = 0; r < NRB; ++r) emit(m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c], r);
+            for_units([&](int, int, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, load_col(nb), load_res(m, nb)); });
         }
         if constexpr (LN_PRODUCER) {
             if (p.out_stats) {

@@ -384,6 +384,27 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
     // wait vmcnt(0) at its use and drain the prefetch pipeline in the middle of a step
     float* bias_s = reinterpret_cast<float*>(smem + QSTAGE * STAGE_B + 1024);
     for (int i = threadIdx.x; i < p.N; i += QNT) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+    // LayerNorm folding (planes.h): the vectors of the fold next to the bias, then two slots for the row statistics of a tile
+    // (the current tile's block is fetched by LDS-DMA in its first step; the pending tile's block is read by the dripped epilogue)
+    constexpr bool CONSUMER = (EPI == EPI_QKV || EPI == EPI_BIAS_GELU);
+    const float* const stats_src = CONSUMER ? p.ln_stats : (EPI == EPI_BIAS_RES ? p.r_stats : nullptr);
+    const bool has_stats = stats_src != nullptr;
+    const int parts = has_stats || (EPI == EPI_BIAS_RES && p.out_stats) ? p.ln_dim / 16 : 0;
+    float* const vec1_s = bias_s + p.N;              // c_n (consumer) / gamma of the residual's LayerNorm
+    float* const vec2_s = vec1_s + p.N;              // beta of the residual's LayerNorm
+    char* const stats_s = reinterpret_cast<char*>(vec2_s + p.N);
+    const int stats_tile_b = QM * parts * 8;         // bytes of one tile's statistics (144 rows)
+    // (mu, rstd) of the 144 rows of a tile, two slots: reduced ONCE per tile by 144 threads in the tile's second step (the partial
+    // pairs of a row are 256 B apart: read per unit by every wave they were a 16-way bank conflict eight waves wide -- measured:
+    // the QKV GEMM went from 48 to 92 us)
+    float* const murs_s = reinterpret_cast<float*>(stats_s + 2 * stats_tile_b);
+    if (has_stats) {
+        const float* v1 = CONSUMER ? p.ln_c : p.r_gamma;
+        for (int i = threadIdx.x; i < p.N; i += QNT) {
+            vec1_s[i] = v1[i];
+            if (!CONSUMER) vec2_s[i] = p.r_beta[i];
+        }
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -556,17 +577,28 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
             }
         }
     };
-    auto finish = [&](f32x4 v, int m, int nb, const f32x4& rr) __attribute__((always_inline)) {
+    auto finish = [&](f32x4 v, int m, int nb, f32x4 rr, float mu, float rstd) __attribute__((always_inline)) {
         {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + nb);
+            if (CONSUMER && has_stats) {       // LN(x) W^T + b = (acc - mu c_n) rstd + d_n
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(vec1_s + nb);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += b4[q];
+                for (int q = 0; q < 4; ++q) v[q] = (v[q] - mu * c4[q]) * rstd + b4[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += b4[q];
+            }
         }
         if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
         }
         if constexpr (EPI == EPI_BIAS_RES) {
+            if (has_stats) {                   // the residual is LN(raw): normalise it on the fly
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(vec1_s + nb), be4 = *reinterpret_cast<const f32x4*>(vec2_s + nb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rr[q] = (rr[q] - mu) * rstd * g4[q] + be4[q];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] += rr[q];
         }
@@ -579,18 +611,40 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
         return v;
     };
     // store the front unit (queue position d = drip) and move the queue up
+    int pslot = 0;                        // statistics slot of the pending tile
     auto store_front = [&](int d) __attribute__((always_inline)) {
         f32x4 v[CB];
         int m = 0, nb0 = 0;
         bool real0 = false;
+        float mu = 0.f, rstd = 1.f;
+        if (has_stats) {                  // this lane's row of the pending tile
+            const int rb = (d == 3) ? 8 : r0 + (d == 4 ? 0 : d + 1);
+            const float* mr = murs_s + (pslot * QM + rb * 16 + li) * 2;
+            mu = mr[0];
+            rstd = mr[1];
+        }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             int mm_, nb;
             bool real;
             unit_geom(d, c, mm_, nb, real);
             if (c == 0) { m = mm_; nb0 = nb; real0 = real; }
-            v[c] = finish(pendq[0][c], mm_, nb, rpre[c]);
+            v[c] = finish(pendq[0][c], mm_, nb, rpre[c], mu, rstd);
             if (real && p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)mm_ * p.ldc + nb) = v[c];
+            if constexpr (EPI == EPI_BIAS_RES) {
+                if (p.out_stats) {        // partial (sum, sum of squares) of this row over the 16 columns of block c
+                    const float su = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+                    const float sq = (v[c][0] * v[c][0] + v[c][1] * v[c][1]) + (v[c][2] * v[c][2] + v[c][3] * v[c][3]);
+                    // the four lanes of a row (16 apart) summed on the VALU (two lane swaps; __shfl_xor goes through the LDS crossbar
+                    // and its lgkmcnt wait also waits for the ring's LDS-DMA): lane rows 0 / 2 end with the sum, 1 / 3 with the squares
+                    const u32x2 s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(su), __float_as_uint(sq), false, false);
+                    const float t = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+                    const u32x2 s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+                    const float tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+                    if (real && (lg >> 1) == c)      // [row block][part][row in block][2]: the sixteen rows of a unit share a 128-byte line
+                        p.out_stats[((((size_t)(mm_ >> 4) * parts + (nb >> 4)) * 16 + li) << 1) + (lg & 1)] = tot;
+                }
+            }
         }
         if constexpr (POUT) {
             if (d != 3 && CB == 2 && !p.no_swap) {
@@ -643,6 +697,31 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
             constexpr bool FIRST = decltype(first_tag)::value;
             constexpr int SP = (S + 2) % 3;
             const bool tile_first = (kc == 0), tile_last = (kc + 1 == nkc);
+            if (kc == 2 && has_stats && threadIdx.x < 2 * QM) {
+                // the block requested at the end of the tile's first step has landed (the closing wait of the second step covers it:
+                // everything older than that step's own VMOPS prefetches) and is visible (its barrier).  Two threads per row (the even
+                // and the odd partial pairs: 128 bytes apart, different banks) sum in index order and are combined over the lane
+                // pair; biased variance, eps inside the root (nn.LayerNorm).  [row block][part][row][2]: consecutive rows are
+                // consecutive pairs.  The chain of dependent LDS reads is what this costs (about 0.5 us per tile), hence two threads.
+                const int row = (int)threadIdx.x >> 1, half = (int)threadIdx.x & 1;
+                const f32x2* sp = reinterpret_cast<const f32x2*>(stats_s + (cseq & 1) * stats_tile_b) +
+                                  ((row >> 4) * parts + half) * 16 + (row & 15);
+                float su = 0.f, sq = 0.f;
+                for (int i = 0; i < parts; i += 4) {          // parts % 8 == 0 (launcher); two reads in flight (more spill: 256 VGPRs)
+                    const f32x2 t0 = sp[i * 16], t1 = sp[(i + 2) * 16];
+                    su += t0[0] + t1[0];
+                    sq += t0[1] + t1[1];
+                }
+                su += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(su), 0xB1, 0xf, 0xf, true));     // lane ^ 1
+                sq += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(sq), 0xB1, 0xf, 0xf, true));
+                const float inv = 1.0f / (float)p.ln_dim;
+                const float mu_ = su * inv;
+                if (half == 0) {
+                    float* mr = murs_s + ((cseq & 1) * QM + row) * 2;
+                    mr[0] = mu_;
+                    mr[1] = 1.0f / sqrtf(fmaxf(sq * inv - mu_ * mu_, 0.f) + p.ln_eps);
+                }
+            }
             if constexpr (!FIRST) load_residual(drip);
             // The two waves of a SIMD (row halves wm = 0 / 1) leave every barrier together and run the same code: without help they
             // would issue their DMA pieces and B loads at the same moment and the matrix core would idle behind both.  So the
@@ -761,6 +840,17 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
                     ++drip;
                 }
             }
+            // The statistics of this tile's 144 rows -> slot cseq & 1 (1 KiB pieces).  Requested LAST in the tile's first step, behind
+            // the step's own prefetches: the closing wait below (all but the newest VMOPS operations) then leaves them in flight for
+            // one more step -- requested at the top of the step they had to land within it, a whole HBM latency on the critical
+            // path of every tile (all of it for the one-tile-per-workgroup GEMMs).
+            if (tile_first && has_stats) {
+                const char* src = reinterpret_cast<const char*>(stats_src) + (size_t)cm0 * 16 * parts * 8 + lane * 16;
+                for (int f = wave; f * 1024 < stats_tile_b; f += 8)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
+                                                     (__attribute__((address_space(3))) void*)(stats_s + (cseq & 1) * stats_tile_b + f * 1024),
+                                                     16, 0, 0);
+            }
             if (tile_last) {
                 // hand the finished blocks over (the first row block follows after section 1 of the next step).  The launcher
                 // guarantees nkc >= 6, so the five units of the tile before have gone out by now.
@@ -772,7 +862,7 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
                         acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 pendq[3][0] = combine(acc8, acc8x); acc8 = f32x4{0.f, 0.f, 0.f, 0.f}; acc8x = f32x4{0.f, 0.f, 0.f, 0.f};
-                pm0 = cm0; pn0 = cn0; drip = 0;
+                pm0 = cm0; pn0 = cn0; drip = 0; pslot = cseq & 1;
                 kc = 0;
                 if (cseq + 1 < my_tiles) { ++cseq; tile_coords(cseq, cm0, cn0); }
             } else {
@@ -803,7 +893,28 @@ __global__ __launch_bounds__(QNT) void gemm_pp_stream_kernel(PlaneGemmParams p) 
         // the last tile was handed to the queue by its last step, except for the first row block
     #pragma unroll
         for (int c = 0; c < CB; ++c) pendq[4][c] = combine(acc[0][c], accx[0][c]);      // drip == 0 here: the tile ended with the last step
-        for (; drip < 5; ++drip) { load_residual(drip); store_front(drip); }
+        // The flush of the last tile (for the one-tile-per-workgroup GEMMs: the whole epilogue).  All five units' residuals are
+        // requested before the first unit is finished: as a loop of (load, store) pairs every unit waited vmcnt(0) -- for its own
+        // residual AND for the stores of the unit before -- five dependent round trips to memory at the end of every workgroup.
+        if constexpr (EPI == EPI_BIAS_RES) {
+            f32x4 rq[5][CB];
+    #pragma unroll
+            for (int d = 0; d < 5; ++d) {
+                load_residual(d);
+    #pragma unroll
+                for (int c = 0; c < CB; ++c) rq[d][c] = rpre[c];
+            }
+    #pragma unroll
+            for (int d = 0; d < 5; ++d) {
+    #pragma unroll
+                for (int c = 0; c < CB; ++c) rpre[c] = rq[d][c];
+                store_front(d);
+            }
+        } else {
+    #pragma unroll
+            for (int d = 0; d < 5; ++d) store_front(d);
+        }
+        drip = 5;
     };
     if (wm == 0) run(std::true_type{});
     else run(std::false_type{});
@@ -842,17 +953,23 @@ template <int EPI, int NP, int CB, bool POUT>
 int launch_pp(const PlaneGemmParams& p, hipStream_t s) {
     constexpr int BN = 4 * CB * 16;
     const int tiles = (p.M / QM) * (p.N / BN);
-    const size_t lds = (size_t)QSTAGE * QRB * mode_planes(NP) * 1024 + 1024 + (size_t)p.N * sizeof(float);
+    const bool fold = p.ln_stats || p.r_stats || p.out_stats;     // LayerNorm folding: stream kernel only (launch_gemm_pp checks)
+    const size_t lds = (size_t)QSTAGE * QRB * mode_planes(NP) * 1024 + 1024 + (size_t)3 * p.N * sizeof(float) +
+                       ((p.ln_stats || p.r_stats) ? (size_t)2 * QM * (p.ln_dim / 16) * 8 + 2 * QM * 2 * sizeof(float) : 0);
     const bool stream = pp_stream_enabled() && p.K / 32 >= 6;     // the dripped epilogue needs five steps of the next tile
+    if (fold && (!stream || lds > 160 * 1024)) {
+        set_error("gemm_pp: LayerNorm folding needs the stream kernel (K >= 192) and %zu bytes of LDS (<= 160 KiB)", lds);
+        return ROHM_ERR_UNSUPPORTED;
+    }
     static bool attr_set[64] = {};
     int dev = 0;
     ROHM_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
-        const int lds_max = QSTAGE * QRB * mode_planes(NP) * 1024 + 1024 + 16384;      // + the bias vector (N <= 4096, checked at entry)
+        const int lds_max = QSTAGE * QRB * mode_planes(NP) * 1024 + 1024 + 3 * 16384;      // + bias / fold vectors (N <= 4096, checked at entry)
         ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, NP, CB, POUT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_stream_kernel<EPI, NP, CB, POUT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
         attr_set[dev] = true;
     }
@@ -904,6 +1021,12 @@ int launch_gemm_pp(const PlaneGemmParams& p, int epi, int nplane, hipStream_t s)
                    "gemm_pp: operands must be 16-byte aligned");
     if (epi == EPI_BIAS_RES) ROHM_ARG_CHECK(p.R && al16(p.R) && p.ldr % 4 == 0, "gemm_pp: bad residual");
     if (epi == EPI_QKV) ROHM_ARG_CHECK(p.qcols % 4 == 0, "gemm_pp: qcols must be a multiple of 4");
+    if (p.ln_stats) ROHM_ARG_CHECK((epi == EPI_QKV || epi == EPI_BIAS_GELU) && p.ln_c && p.bias && p.ln_dim == p.K && p.K % 32 == 0,
+                                   "gemm_pp: a LayerNorm-consuming GEMM needs epilogue 1 / 3, ln_c, bias (= d) and ln_dim == K");
+    if (p.r_stats) ROHM_ARG_CHECK(epi == EPI_BIAS_RES && p.r_gamma && p.r_beta && p.ln_dim == p.N, "gemm_pp: bad residual LayerNorm");
+    if (p.out_stats) ROHM_ARG_CHECK(epi == EPI_BIAS_RES && p.ln_dim == p.N && p.N % 128 == 0, "gemm_pp: row statistics need epilogue 2, ln_dim == N");
+    if (p.ln_stats || p.r_stats || p.out_stats)      // the statistics of a tile move as whole 1 KiB pieces (144 x ln_dim / 16 x 8 bytes)
+        ROHM_ARG_CHECK(p.ln_dim > 0 && p.ln_dim % 128 == 0 && p.ln_eps > 0.f, "gemm_pp: LayerNorm folding needs ln_dim %% 128 == 0 (got %d) and eps > 0", p.ln_dim);
     if (nplane == 3) return launch_pp_epi<3>(p, epi, s);
     if (nplane == 2) return launch_pp_epi<2>(p, epi, s);
     return launch_pp_epi<kModeF16>(p, epi, s);

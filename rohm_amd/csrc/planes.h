@@ -116,6 +116,18 @@ struct PlaneGemmParams {
     float acc_scale;         // the accumulator is multiplied by this before the epilogue (0 = 1: undoes a power-of-two scale the
                              // weight planes were cut with, fp16 mode)
     int no_swap;             // diagnostic: plane output through 8-byte stores instead of the lane-swapped 16-byte form
+    // ---- LayerNorm folded into the GEMMs around it (stream kernel, two-plane modes; posenet.hip).  Row statistics travel as
+    // partial (sum, sum of squares) pairs per 16 columns, row-block major:  stats[row / 16][ln_dim / 16][row % 16][2].
+    //   consumer (EPI_QKV / EPI_BIAS_GELU, ln_stats != null): the A planes are those of the RAW (un-normalised) tensor x, the
+    //     weight planes carry gamma (W_nk gamma_k), `bias` carries d_n = b_n + sum_k beta_k W_nk, ln_c carries c_n = sum_k gamma_k
+    //     W_nk, and the epilogue finishes LN(x) W^T + b = (acc - mu_m c_n) rstd_m + d_n;  ln_dim = K.
+    //   EPI_BIAS_RES, r_stats != null: the residual R is raw too; LN(R) = (R - mu) rstd r_gamma + r_beta is what is added.
+    //   EPI_BIAS_RES, out_stats != null: the partial statistics of the RESULT rows are written (the next consumer's input).
+    //     For both, ln_dim = N.
+    const float* ln_stats; const float* ln_c;
+    const float* r_stats; const float* r_gamma; const float* r_beta;
+    float* out_stats;
+    int ln_dim; float ln_eps;
 };
 // epi: EPI_BIAS / EPI_BIAS_GELU / EPI_BIAS_RES / EPI_QKV.  M % 144 == 0, N % 64 == 0, K % 32 == 0.  nplane = the mode (2, 3, 16).
 int launch_gemm_pp(const PlaneGemmParams& p, int epi, int nplane, hipStream_t s);

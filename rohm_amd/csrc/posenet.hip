@@ -34,6 +34,10 @@ struct LayerW {
     float *in_c, *l1_c;
     // bf16 planes of the four weight matrices (precision ladder, planes.h); null in the exact-fp32 mode
     char *in_wp, *out_wp, *l1_wp, *l2_wp;
+    // LayerNorm folded into the plane GEMMs (pp_fold): planes of gamma-scaled weights and the fold vectors (planes.h PlaneGemmParams)
+    //   l1_wpf = planes of W1 diag(gamma1), l1_cf / l1_df;  in_wpf = planes of Win diag(gamma2 of the PREVIOUS layer), in_cf / in_df
+    char *l1_wpf, *in_wpf;
+    float *l1_cf, *l1_df, *in_cf, *in_df;
 };
 
 }  // namespace rohm
@@ -53,6 +57,9 @@ struct rohm_posenet {
     bool ln_fold;                         // LayerNorm folded into the surrounding GEMMs (default) or run as a kernel
     int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2 / 16: split GEMMs on planes (bf16x6 / bf16x3 / fp16x3)
     char* wplanes;                        // one allocation holding the weight planes of every layer
+    bool pp_fold;                         // plane modes: LayerNorm folded into the plane GEMMs (ROHM_PP_LNFOLD=1, two-plane modes)
+    float* foldvec;                       // one allocation holding the fold vectors
+    char* wplanes_fold;                   // ... and the planes of the gamma-scaled weights
     std::vector<rohm::LayerW> layers;
 };
 
@@ -239,8 +246,9 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
     w.tab0 = take((size_t)B * p->D);
     w.x0 = take((size_t)B * p->Cin * T);
     w.tok_all = take((size_t)kLoopChunk * p->D);     // timestep tokens of one sample-loop call
-    w.stats_a = take(M * (p->D / 64) * 2);
-    w.stats_b = take(M * (p->D / 64) * 2);
+    // row statistics: one (sum, sum of squares) pair per 64 columns (fp32 LayerNorm folding) or per 16 columns (plane modes)
+    w.stats_a = take(M * (p->D / (p->nplane ? 16 : 64)) * 2);
+    w.stats_b = take(M * (p->D / (p->nplane ? 16 : 64)) * 2);
     w.t_all = reinterpret_cast<int64_t*>(take(2 * (size_t)kLoopChunk));
     w.floats = off;
     return w;
@@ -285,27 +293,45 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         const int np = p->nplane;
         if ((rc = launch_plane_split(h, D, M, D, np, 1.0f, w.hP, s))) return rc;
         const float wsc = (np == kModeF16) ? 1.0f / kF16WeightScale : 0.f;
+        const bool pf = p->pp_fold;       // LayerNorm folded into the GEMMs: h / y hold RAW (pre-norm) values from layer 0's out-projection on
+        auto consumer = [&](PlaneGemmParams& g, const float* stats, const float* c, const float* d) {
+            g.ln_stats = stats; g.ln_c = c; g.bias = d; g.ln_dim = D; g.ln_eps = 1e-5f;
+        };
         for (int l = 0; l < p->L; ++l) {
             const LayerW& lw = p->layers[l];
             PlaneGemmParams g{};
             g.Ap = w.hP; g.Wp = lw.in_wp; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
             g.bias = lw.in_b; g.qcols = D; g.qscale = 1.0f / sqrtf((float)(D / p->H)); g.acc_scale = wsc;
+            if (pf && l > 0) { g.Wp = lw.in_wpf; consumer(g, w.stats_b, lw.in_cf, lw.in_df); }      // LN2 of layer l - 1 folded in
             if ((rc = launch_gemm_pp(g, EPI_QKV, np, s))) return rc;
             if ((rc = launch_attention_planes(w.qkv, w.ctxP, B, p->H, np, s))) return rc;
             g = PlaneGemmParams{};
             g.Ap = w.ctxP; g.Wp = lw.out_wp; g.C = y; g.ldc = D; g.M = M; g.N = D; g.K = D;
             g.bias = lw.out_b; g.R = h; g.ldr = D; g.acc_scale = wsc;
+            if (pf) {
+                g.ln_dim = D; g.ln_eps = 1e-5f;
+                if (l > 0) { g.r_stats = w.stats_b; g.r_gamma = p->layers[l - 1].n2_w; g.r_beta = p->layers[l - 1].n2_b; }
+                g.out_stats = w.stats_a; g.Cp = w.yP;          // raw y: fp32 (FF2's residual), planes (FF1's operand), statistics
+            }
             if ((rc = launch_gemm_pp(g, EPI_BIAS_RES, np, s))) return rc;
-            if ((rc = launch_layernorm_planes(y, lw.n1_w, lw.n1_b, M, D, np, w.yP, s))) return rc;
+            if (!pf && (rc = launch_layernorm_planes(y, lw.n1_w, lw.n1_b, M, D, np, w.yP, s))) return rc;
             g = PlaneGemmParams{};
             g.Ap = w.yP; g.Wp = lw.l1_wp; g.Cp = w.ffP; g.M = M; g.N = p->F; g.K = D; g.bias = lw.l1_b; g.acc_scale = wsc;
+            if (pf) { g.Wp = lw.l1_wpf; consumer(g, w.stats_a, lw.l1_cf, lw.l1_df); }
             if ((rc = launch_gemm_pp(g, EPI_BIAS_GELU, np, s))) return rc;
             g = PlaneGemmParams{};
             g.Ap = w.ffP; g.Wp = lw.l2_wp; g.C = h; g.ldc = D; g.M = M; g.N = D; g.K = p->F;
             g.bias = lw.l2_b; g.R = y; g.ldr = D; g.acc_scale = wsc;
+            if (pf) {
+                g.ln_dim = D; g.ln_eps = 1e-5f;
+                g.r_stats = w.stats_a; g.r_gamma = lw.n1_w; g.r_beta = lw.n1_b;      // the residual is LN1(raw y)
+                g.out_stats = w.stats_b; g.Cp = w.hP;
+            }
             if ((rc = launch_gemm_pp(g, EPI_BIAS_RES, np, s))) return rc;
-            if ((rc = launch_layernorm_planes(h, lw.n2_w, lw.n2_b, M, D, np, w.hP, s))) return rc;
+            if (!pf && (rc = launch_layernorm_planes(h, lw.n2_w, lw.n2_b, M, D, np, w.hP, s))) return rc;
         }
+        // the last norm2 has no GEMM of this kind behind it: one LayerNorm launch in front of the output head
+        if (pf && (rc = launch_layernorm(h, p->layers[p->L - 1].n2_w, p->layers[p->L - 1].n2_b, M, D, s))) return rc;
     }
     const bool fold = p->ln_fold && !planes;
     const int parts = D / 64;
@@ -461,6 +487,12 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         if (d_model / n_head != 128 || d_model % 64 || d_ff % 64) p->nplane = 0;   // shapes the plane kernels do not cover
         if (p->nplane) p->ln_fold = false;
         p->wplanes = nullptr;
+        p->foldvec = nullptr;
+        p->wplanes_fold = nullptr;
+        // LayerNorm folded into the plane GEMMs (fifteen of the sixteen LayerNorm launches of a step disappear): two-plane modes
+        // only (the statistics tiles need the LDS a third plane occupies).  ROHM_PP_LNFOLD=0 switches it off.
+        const char* e5 = getenv("ROHM_PP_LNFOLD");
+        p->pp_fold = (p->nplane == 2 || p->nplane == kModeF16) && !(e5 && e5[0] == '0') && d_model % 128 == 0;
     }
     float* tmp = a + o_tmp;
     float* tmp2 = a + o_tmp2;
@@ -506,7 +538,10 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
     }
 #undef PUT
     ROHM_HIP_CHECK(hipDeviceSynchronize());
-    for (auto& d : p->layers) d.in_wp = d.out_wp = d.l1_wp = d.l2_wp = nullptr;
+    for (auto& d : p->layers) {
+        d.in_wp = d.out_wp = d.l1_wp = d.l2_wp = d.l1_wpf = d.in_wpf = nullptr;
+        d.l1_cf = d.l1_df = d.in_cf = d.in_df = nullptr;
+    }
     if (p->nplane) {
         const size_t b_in = plane_tensor_bytes(3 * d_model, d_model, p->nplane), b_out = plane_tensor_bytes(d_model, d_model, p->nplane),
                      b_l1 = plane_tensor_bytes(d_ff, d_model, p->nplane), b_l2 = plane_tensor_bytes(d_model, d_ff, p->nplane);
@@ -530,8 +565,46 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
             if (!rc4) rc4 = launch_plane_split(d.l1_w, d_model, d_ff, d_model, p->nplane, ws, d.l1_wp, 0);
             if (!rc4) rc4 = launch_plane_split(d.l2_w, d_ff, d_model, d_ff, p->nplane, ws, d.l2_wp, 0);
         }
+        if (rc4 == ROHM_OK && p->pp_fold) {
+            // gamma-scaled copies of W1 (every layer) and Win (layers >= 1, with the previous layer's norm2) are cut into their
+            // own planes; c_n = sum_k gamma_k W_nk and d_n = b_n + sum_k beta_k W_nk come out of the same kernel (fp64 sums)
+            const size_t b_l1f = plane_tensor_bytes(d_ff, d_model, p->nplane), b_inf = plane_tensor_bytes(3 * d_model, d_model, p->nplane);
+            char* fp = nullptr;
+            float *tmpw = nullptr;
+            const size_t vec_floats = (size_t)n_layer * (2 * F + 2 * 3 * D);
+            if (hipMalloc(&fp, (b_l1f + b_inf) * n_layer) != hipSuccess || hipMalloc(&p->foldvec, vec_floats * sizeof(float)) != hipSuccess ||
+                hipMalloc(&tmpw, 3 * D * D * sizeof(float) > F * D * sizeof(float) ? 3 * D * D * sizeof(float) : F * D * sizeof(float)) != hipSuccess) {
+                rc4 = ROHM_ERR_HIP;
+                set_error("posenet_create: hipMalloc of the folded weight planes failed");
+            }
+            p->wplanes_fold = fp;
+            float* fv = p->foldvec;
+            const float ws = (p->nplane == kModeF16) ? kF16WeightScale : 1.0f;
+            for (int l = 0; l < n_layer && rc4 == ROHM_OK; ++l) {
+                LayerW& d = p->layers[l];
+                d.l1_wpf = fp; fp += b_l1f; d.in_wpf = fp; fp += b_inf;
+                d.l1_cf = fv; fv += F; d.l1_df = fv; fv += F; d.in_cf = fv; fv += 3 * D; d.in_df = fv; fv += 3 * D;
+                if (hipMemcpy(tmpw, d.l1_w, F * D * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess ||
+                    hipMemcpy(d.l1_df, d.l1_b, F * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { rc4 = ROHM_ERR_HIP; break; }
+                hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)F), dim3(256), 0, 0, tmpw, d.l1_df, d.n1_w, d.n1_b, d.l1_cf, (int)D);
+                rc4 = launch_plane_split(tmpw, d_model, d_ff, d_model, p->nplane, ws, d.l1_wpf, 0);
+                if (l > 0 && rc4 == ROHM_OK) {
+                    const LayerW& pr = p->layers[l - 1];
+                    if (hipDeviceSynchronize() != hipSuccess ||
+                        hipMemcpy(tmpw, d.in_w, 3 * D * D * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess ||
+                        hipMemcpy(d.in_df, d.in_b, 3 * D * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { rc4 = ROHM_ERR_HIP; break; }
+                    hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)(3 * D)), dim3(256), 0, 0, tmpw, d.in_df, pr.n2_w, pr.n2_b, d.in_cf, (int)D);
+                    rc4 = launch_plane_split(tmpw, d_model, 3 * d_model, d_model, p->nplane, ws, d.in_wpf, 0);
+                }
+                if (hipDeviceSynchronize() != hipSuccess) rc4 = ROHM_ERR_HIP;
+            }
+            if (tmpw) (void)hipFree(tmpw);
+            if (rc4 == ROHM_ERR_HIP) set_error("posenet_create: folding LayerNorm into the weight planes failed");
+        }
         if (rc4 != ROHM_OK || hipDeviceSynchronize() != hipSuccess) {
             if (rc4 == ROHM_OK) set_error("posenet_create: cutting the weight planes failed");
+            if (p->wplanes_fold) (void)hipFree(p->wplanes_fold);
+            if (p->foldvec) (void)hipFree(p->foldvec);
             (void)hipFree(p->wplanes);
             (void)hipFree(p->arena);
             delete p;
@@ -561,6 +634,8 @@ void rohm_posenet_destroy(rohm_posenet_t* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
     if (h->wplanes) (void)hipFree(h->wplanes);
+    if (h->wplanes_fold) (void)hipFree(h->wplanes_fold);
+    if (h->foldvec) (void)hipFree(h->foldvec);
     delete h;
 }
 

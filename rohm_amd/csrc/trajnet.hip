@@ -586,6 +586,9 @@ struct TWs {
     float *mid_a, *mid_b, *kmid_a, *kmid_b;
     float *d[4];                            // decoder block outputs
     float *cz, *ctrl[4], *ctrl_mid;         // control residuals
+    float *ctrl_b[4], *ctrl_mid_b;          // ... second set: the ControlNet branch of the sample loop runs one step ahead on its own stream
+    Scratch sc_ctl;                         // ... with its own block scratch and split-K slabs
+    float *splitk_ctl, *splitk_res_ctl;
     float *fin;                             // final conv block output [M, 32]
     float *tb_all;                          // [B or 1][tb_total]
     float *tb_steps;                        // [kTbSteps][tb_total]: time biases of a run of loop steps (one launch)
@@ -631,6 +634,16 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     w.cond_keep = take(16);
     w.splitk = take(kSplitKFloats);
     w.splitk_res = take(kSplitKFloats);
+    for (int i = 0; i < 4; ++i) w.ctrl_b[i] = nullptr;
+    w.ctrl_mid_b = nullptr; w.sc_ctl = Scratch{}; w.splitk_ctl = w.splitk_res_ctl = nullptr;
+    if (h->control) {
+        for (int i = 0; i < 4; ++i) w.ctrl_b[i] = take((M >> i) * (i == 0 ? 32 : ch[i - 1]));
+        w.ctrl_mid_b = take(M16 * m);
+        const size_t blk = M * (m / 8) > (M >> 3) * m ? M * (m / 8) : (M >> 3) * m;
+        w.sc_ctl.ya = take(2 * blk); w.sc_ctl.hb = take(blk); w.sc_ctl.rc = take(blk);
+        w.splitk_ctl = take(kSplitKFloats);
+        w.splitk_res_ctl = take(kSplitKFloats);
+    }
     w.step_coef = take(3 * (size_t)kGraphMaxSteps);
     w.step_t = reinterpret_cast<int64_t*>(take(2 * (size_t)kGraphMaxSteps));
     w.step_ctr = reinterpret_cast<int*>(take(16));
@@ -668,32 +681,47 @@ static int run_cond_encoder(const rohm_trajnet* h, const TWs& w, int B, int T, h
 }
 
 // everything that depends on x_t / t (and control_cond): trajnet.py:211-275
+// ControlNet.forward, trajnet.py:43-75.  control_zero_conv_0(control_cond) depends on the (loop-invariant) control input only:
+static int run_control_pre(const rohm_trajnet* h, const TWs& w, int B, int T, hipStream_t s) {
+    return conv1(h->c_zero0, w.ctl, kPadCtl, B * T, w.cz, kPadC, s);   // cols 13..63 stay zero
+}
+// ... the rest depends on the timestep (not on x_t): residuals -> ctrl[0..3], ctrl_mid; intermediates in ccat / kdn / kmid and `sc`
+static int run_control(const rohm_trajnet* h, const TWs& w, int B, int T, int ldtb, const float* tb, float* const* ctrl,
+                       float* ctrl_mid, const Scratch& sc, hipStream_t s) {
+    const int m = h->mid;
+    const int ch[4] = {m / 8, m / 4, m / 2, m};
+    int rc;
+    const float* x = w.cz;
+    int ldx = kPadC;
+    for (int i = 0; i < 4; ++i) {
+        const int Ti = T >> i;
+        if ((rc = res_block(h, h->c_enc[i], x, ldx, B, Ti, tb, ldtb, nullptr, 0, w.ccat[i], 2 * ch[i], nullptr, 0, sc, s)))
+            return rc;
+        if ((rc = conv1(h->c_zero[i], w.ccat[i], 2 * ch[i], B * Ti, ctrl[i], i == 0 ? 32 : ch[i - 1], s))) return rc;
+        if ((rc = down(h, h->c_down[i], w.ccat[i], 2 * ch[i], B, Ti, w.kdn[i], 2 * ch[i], s))) return rc;
+        x = w.kdn[i]; ldx = 2 * ch[i];
+    }
+    const int T16 = T >> 4;
+    if ((rc = res_block(h, h->c_mid[0], w.kdn[3], 2 * m, B, T16, tb, ldtb, nullptr, 0, w.kmid_a, m, nullptr, 0, sc, s))) return rc;
+    if ((rc = res_block(h, h->c_mid[1], w.kmid_a, m, B, T16, tb, ldtb, nullptr, 0, w.kmid_b, m, nullptr, 0, sc, s))) return rc;
+    return conv1(h->c_zero_mid, w.kmid_b, m, B * T16, ctrl_mid, m, s);
+}
+
+// The ControlNet residuals of a step when they come from a second stream (sample loop): which set, and the events that order
+// the two streams -- `ready` is waited for before the first consumer (the second middle block), `consumed` recorded behind the last.
+struct CtrlRef { const float* ctrl[4]; const float* mid; hipEvent_t ready, consumed; };
+
 static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int ldtb, float* out, hipStream_t s,
-                        const float* tb_row = nullptr) {
+                        const float* tb_row = nullptr, const CtrlRef* cr = nullptr) {
     const int m = h->mid;
     const int ch[4] = {m / 8, m / 4, m / 2, m};
     const float* tb = tb_row ? tb_row : w.tb_all;      // tb_row: this step's row of the table built at loop start
     int rc;
-    if (h->control) {   // ControlNet.forward, trajnet.py:43-75
-        if ((rc = conv1(h->c_zero0, w.ctl, kPadCtl, B * T, w.cz, kPadC, s))) return rc;   // cols 13..63 stay zero
-        const float* x = w.cz;
-        int ldx = kPadC;
-        for (int i = 0; i < 4; ++i) {
-            const int Ti = T >> i;
-            if ((rc = res_block(h, h->c_enc[i], x, ldx, B, Ti, tb, ldtb, nullptr, 0, w.ccat[i], 2 * ch[i], nullptr, 0,
-                                w.sc, s)))
-                return rc;
-            if ((rc = conv1(h->c_zero[i], w.ccat[i], 2 * ch[i], B * Ti, w.ctrl[i], i == 0 ? 32 : ch[i - 1], s)))
-                return rc;
-            if ((rc = down(h, h->c_down[i], w.ccat[i], 2 * ch[i], B, Ti, w.kdn[i], 2 * ch[i], s))) return rc;
-            x = w.kdn[i]; ldx = 2 * ch[i];
-        }
-        const int T16 = T >> 4;
-        if ((rc = res_block(h, h->c_mid[0], w.kdn[3], 2 * m, B, T16, tb, ldtb, nullptr, 0, w.kmid_a, m, nullptr, 0, w.sc, s)))
-            return rc;
-        if ((rc = res_block(h, h->c_mid[1], w.kmid_a, m, B, T16, tb, ldtb, nullptr, 0, w.kmid_b, m, nullptr, 0, w.sc, s)))
-            return rc;
-        if ((rc = conv1(h->c_zero_mid, w.kmid_b, m, B * T16, w.ctrl_mid, m, s))) return rc;
+    const float* const* ctrl = cr ? cr->ctrl : w.ctrl;
+    const float* ctrl_mid = cr ? cr->mid : w.ctrl_mid;
+    if (h->control && !cr) {            // single stream: the ControlNet branch in front of the U-Net
+        if ((rc = run_control_pre(h, w, B, T, s))) return rc;
+        if ((rc = run_control(h, w, B, T, ldtb, tb, w.ctrl, w.ctrl_mid, w.sc, s))) return rc;
     }
     // U-Net encoder
     const float* x = w.xin;
@@ -710,7 +738,8 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
     const int T16 = T >> 4;
     if ((rc = res_block(h, h->mid_blk[0], w.ddn[3], 2 * m, B, T16, tb, ldtb, nullptr, 0, w.mid_a, m, nullptr, 0, w.sc, s)))
         return rc;
-    if ((rc = res_block(h, h->mid_blk[1], w.mid_a, m, B, T16, tb, ldtb, h->control ? w.ctrl_mid : nullptr, m, w.mid_b, m,
+    if (cr) ROHM_HIP_CHECK(hipStreamWaitEvent(s, cr->ready, 0));
+    if ((rc = res_block(h, h->mid_blk[1], w.mid_a, m, B, T16, tb, ldtb, h->control ? ctrl_mid : nullptr, m, w.mid_b, m,
                         nullptr, 0, w.sc, s)))
         return rc;
     // decoder
@@ -720,11 +749,12 @@ static int run_denoiser(const rohm_trajnet* h, const TWs& w, int B, int T, int l
         if ((rc = upsample(h, h->up[i], x, ldx, B, Tq, w.dcat[i], 2 * ch[i], s))) return rc;
         const int co = (i == 0) ? 32 : ch[i - 1];
         const int ldd = (i == 0) ? kPadC : co;
-        if ((rc = res_block(h, h->dec[i], w.dcat[i], 2 * ch[i], B, Ti, tb, ldtb, h->control ? w.ctrl[i] : nullptr, co,
+        if ((rc = res_block(h, h->dec[i], w.dcat[i], 2 * ch[i], B, Ti, tb, ldtb, h->control ? ctrl[i] : nullptr, co,
                             w.d[i], ldd, nullptr, 0, w.sc, s)))
             return rc;
         x = w.d[i]; ldx = ldd;
     }
+    if (cr) ROHM_HIP_CHECK(hipEventRecord(cr->consumed, s));
     // head: Conv1dBlock(32, 32, k5) + Conv1d(32, 13, 1)  (trajnet.py:158-161)
     SplitInfo sf, none;
     if ((rc = conv5(h, h->final_blk.conv, w.d[0], kPadC, B, T, w.sc.ya, 32, s, &sf))) return rc;
@@ -777,6 +807,31 @@ static int pad_rows(const float* src, float* dst, size_t rows, int cin, int cpad
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, cin, cpad);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
+}
+
+// TrajControl sample loop: the ControlNet branch (27 of the step's 86 dependent launches) depends on the timestep and on
+// loop-invariant inputs only, never on x_t -- it runs on a second stream, up to one step ahead of the U-Net (two sets of residual
+// buffers), so its launch latencies hide behind the U-Net's instead of adding to them.  Same kernels, same split plans:
+// bit-identical to the one-stream order (ROHM_TRAJ_CTRL_STREAM=0).
+struct SideStream {
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_in = nullptr, ev_ctl[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    int device = -1;
+};
+static SideStream* side_stream(int device) {
+    static const bool on = [] { const char* e = getenv("ROHM_TRAJ_CTRL_STREAM"); return !(e && e[0] == '0'); }();
+    if (!on) return nullptr;
+    static thread_local SideStream ss;
+    if (ss.s2 && ss.device == device) return &ss;
+    if (ss.s2) return nullptr;                  // a host thread that drives two devices keeps the one-stream order on the second
+    if (hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) != hipSuccess) { ss.s2 = nullptr; (void)hipGetLastError(); return nullptr; }
+    bool ok = hipEventCreateWithFlags(&ss.ev_in, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipEventCreateWithFlags(&ss.ev_ctl[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ss.ev_free[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); (void)hipStreamDestroy(ss.s2); ss.s2 = nullptr; return nullptr; }
+    ss.device = device;
+    return &ss;
 }
 
 // Opt-in (ROHM_TRAJNET_GRAPH=1): measured on ROCm 7.2 / MI355X the replayed graph is SLOWER than plain stream launches
@@ -1175,6 +1230,8 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         // capture not available on this stream / runtime: fall through to the plain loop
     }
     if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;     // x_T; the tail kernel keeps the padded copy current
+    SideStream* ss = h->control ? side_stream(h->device) : nullptr;
+    if (ss && (rc = run_control_pre(h, w, B, T, s))) return rc;           // control_zero_conv_0(control_cond): once per loop
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
@@ -1191,7 +1248,27 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
                                h->tb_total, w.tb_steps);
             ROHM_LAUNCH_CHECK();
         }
-        if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s, w.tb_steps + (size_t)(i % kTbSteps) * h->tb_total))) return rc;
+        const float* tb_row = w.tb_steps + (size_t)(i % kTbSteps) * h->tb_total;
+        if (ss) {
+            const int b = i & 1;
+            if (i % kTbSteps == 0) {          // the branch reads what this stream has just produced: the time table (and, at i = 0,
+                ROHM_HIP_CHECK(hipEventRecord(ss->ev_in, s));                 // the cond encodings and the projected control input)
+                ROHM_HIP_CHECK(hipStreamWaitEvent(ss->s2, ss->ev_in, 0));
+            }
+            if (i >= 2) ROHM_HIP_CHECK(hipStreamWaitEvent(ss->s2, ss->ev_free[b], 0));      // step i - 2 has consumed this set
+            tl_splitk = w.splitk_ctl; tl_splitk_res = w.splitk_res_ctl;
+            rc = run_control(h, w, B, T, 0, tb_row, b ? w.ctrl_b : w.ctrl, b ? w.ctrl_mid_b : w.ctrl_mid, w.sc_ctl, ss->s2);
+            tl_splitk = w.splitk; tl_splitk_res = w.splitk_res;
+            if (rc) return rc;
+            ROHM_HIP_CHECK(hipEventRecord(ss->ev_ctl[b], ss->s2));
+            CtrlRef cr{};
+            for (int j = 0; j < 4; ++j) cr.ctrl[j] = b ? w.ctrl_b[j] : w.ctrl[j];
+            cr.mid = b ? w.ctrl_mid_b : w.ctrl_mid;
+            cr.ready = ss->ev_ctl[b]; cr.consumed = ss->ev_free[b];
+            if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s, tb_row, &cr))) return rc;
+        } else if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s, tb_row))) {
+            return rc;
+        }
         // head conv + ancestral update + padded copy for the next step: one launch (three before)
         if ((rc = run_tail(h, w, x, (x0_last && i == n_steps - 1) ? x0_last : nullptr, noise ? noise + (size_t)i * n : nullptr,
                            c1, c2, sigma, nullptr, nullptr, nullptr, M, s)))

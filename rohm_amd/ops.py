@@ -77,6 +77,22 @@ def gemm_planes(a_planes, w_planes, m, n, k, nplane=3, bias=None, residual=None,
     return c, cp
 
 
+def gemm_planes_ln(a_planes, w_planes, m, n, k, nplane, bias, residual=None, epi=EPI_BIAS_RES, qcols=0, qscale=1.0, acc_scale=0.0,
+                   ln_stats=None, ln_c=None, r_stats=None, r_gamma=None, r_beta=None, want_stats=False, ln_dim=0, ln_eps=1e-5,
+                   out_planes=False):
+    """gemm_planes with LayerNorm folded in (include/rohm_hip.h rohm_gemm_planes_ln) -> (fp32 [m, n], planes or None, row
+    statistics [m / 16, n / 16, 16, 2] or None)."""
+    _lib.require_hip(a_planes, w_planes)
+    c = torch.empty(m, n, device=a_planes.device, dtype=torch.float32)
+    cp = planes_empty(m, n, nplane, a_planes.device) if out_planes else None
+    st = torch.empty(m // 16, n // 16, 16, 2, device=a_planes.device, dtype=torch.float32) if want_stats else None
+    check(lib().rohm_gemm_planes_ln(ptr(a_planes), ptr(w_planes), ptr(c), n, ptr(cp), m, n, k, ptr(bias), ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, qcols, qscale, acc_scale, epi, nplane,
+                                    ptr(ln_stats), ptr(ln_c), ptr(r_stats), ptr(r_gamma), ptr(r_beta), ptr(st), ln_dim, ln_eps,
+                                    stream_ptr(a_planes.device)), 'rohm_gemm_planes_ln')
+    return c, cp, st
+
+
 def layernorm_planes_(x, gamma, beta, nplane=3):
     """In-place LayerNorm that also returns the planes of its result."""
     _lib.require_hip(x)

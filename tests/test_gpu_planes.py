@@ -165,5 +165,83 @@ def test_the_one_tile_per_workgroup_kernel_too():
         pytest.skip('already the child')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_gpu_planes.py',
-                        '-k', 'gemm'], cwd=root, env=dict(os.environ, ROHM_PP_STREAM='0'), capture_output=True, text=True, timeout=900)
+                        '-k', 'gemm and not ln_fold'], cwd=root, env=dict(os.environ, ROHM_PP_STREAM='0'), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def _row_stats(x):
+    """[M, D] -> the partial (sum, sum of squares) pairs per 16 columns in the layout of rohm_gemm_planes_ln: [M/16, D/16, 16, 2]."""
+    m, d = x.shape
+    g = x.double().reshape(m // 16, 16, d // 16, 16)
+    return torch.stack([g.sum(-1), (g * g).sum(-1)], -1).permute(0, 2, 1, 3).contiguous()
+
+
+@pytest.mark.parametrize('M,N,K', [(144 * 3, 512, 512), (144 * 64, 512, 1024), (144 * 65, 1024, 192), (144 * 40, 256, 224)])
+@pytest.mark.parametrize('mode', [16, 2])
+def test_gemm_ln_fold_producer_writes_row_statistics_of_its_result(M, N, K, mode):
+    """epilogue 2 + out_stats: C is what the plain call gives, bit for bit, and the statistics are the row sums of C."""
+    from rohm_amd import ops
+    a, w, bias, res = seeded(M + N, M, K), seeded(K + 7, N, K) / math.sqrt(K), seeded(3, N), seeded(4, M, N)
+    d = _dev()
+    ws = 256.0 if mode == 16 else 1.0
+    ap, wp = ops.planes_split(a.to(d), mode), ops.planes_split(w.to(d), mode, scale=ws)
+    plain, _ = ops.gemm_planes(ap, wp, M, N, K, mode, bias.to(d), res.to(d), 2, acc_scale=1.0 / ws)
+    c, cp, st = ops.gemm_planes_ln(ap, wp, M, N, K, mode, bias.to(d), res.to(d), 2, acc_scale=1.0 / ws, want_stats=True, ln_dim=N,
+                                   out_planes=True)
+    assert torch.equal(c, plain)
+    assert np.array_equal(cp.cpu().numpy(), oplanes.encode(c.cpu().numpy(), mode))
+    want = _row_stats(c.cpu())
+    assert max_abs(st.cpu(), want) < 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('M,N,K', [(144 * 3, 1536, 512), (144 * 64, 1024, 512), (144 * 65, 512, 256), (144 * 40, 1024, 384)])
+@pytest.mark.parametrize('epi', [1, 3])
+def test_gemm_ln_fold_consumer_equals_layernorm_then_gemm(M, N, K, epi):
+    """ln_stats: planes of RAW x, gamma folded into the weight planes, c / d vectors -> LN(x) W^T + b at the fp32 bar
+    (x has a row mean of about a third of its spread, as the residual stream of the network has)."""
+    from rohm_amd import ops
+    x = seeded(M + N, M, K) * 1.5 + 0.5
+    w, bias, gam, bet = seeded(K + 7, N, K) / math.sqrt(K), seeded(3, N), 1.0 + 0.2 * seeded(5, K), 0.1 * seeded(6, K)
+    ref = nets.layer_norm(x.double(), gam.double(), bet.double()) @ w.double().T + bias.double()
+    if epi == 1:
+        ref = nets.gelu_erf(ref)
+    else:
+        ref[:, :N // 2] *= 0.25
+    wg = (w.double() * gam.double()).float()
+    cvec, dvec = wg.double().sum(1).float(), (bias.double() + w.double() @ bet.double()).float()
+    d = _dev()
+    c, _, _ = ops.gemm_planes_ln(ops.planes_split(x.to(d), 16), ops.planes_split(wg.to(d), 16, scale=256.0), M, N, K, 16, dvec.to(d),
+                                 None, epi, qcols=N // 2, qscale=0.25, acc_scale=1.0 / 256.0, ln_stats=_row_stats(x).float().to(d),
+                                 ln_c=cvec.to(d), ln_dim=K)
+    assert max_abs(c.cpu(), ref) < 4e-5 * math.sqrt(K / 32)          # twice the plain bar: (acc - mu c) rstd cancels mu c
+
+
+@pytest.mark.parametrize('M,N,K', [(144 * 3, 512, 512), (144 * 64, 512, 1024), (144 * 65, 512, 192), (144 * 40, 256, 224)])
+def test_gemm_ln_fold_residual_is_normalised_on_the_fly(M, N, K):
+    from rohm_amd import ops
+    a, w, bias = seeded(M + N, M, K), seeded(K + 7, N, K) / math.sqrt(K), seeded(3, N)
+    raw, gam, bet = seeded(4, M, N) * 1.5 + 0.5, 1.0 + 0.2 * seeded(5, N), 0.1 * seeded(6, N)
+    ref = a.double() @ w.double().T + bias.double() + nets.layer_norm(raw.double(), gam.double(), bet.double())
+    d = _dev()
+    c, _, st = ops.gemm_planes_ln(ops.planes_split(a.to(d), 16), ops.planes_split(w.to(d), 16, scale=256.0), M, N, K, 16, bias.to(d),
+                                  raw.to(d), 2, acc_scale=1.0 / 256.0, r_stats=_row_stats(raw).float().to(d), r_gamma=gam.to(d),
+                                  r_beta=bet.to(d), want_stats=True, ln_dim=N)
+    assert max_abs(c.cpu(), ref) < 2e-5 * math.sqrt(K / 32)
+    want = _row_stats(c.cpu())
+    assert max_abs(st.cpu(), want) < 1e-5 * float(want.abs().max())
+
+
+def test_gemm_ln_fold_refuses_what_it_cannot_do():
+    from rohm_amd import _lib, ops
+    d = _dev()
+    ap, wp = ops.planes_split(torch.zeros(144, 160, device=d), 16), ops.planes_split(torch.zeros(128, 160, device=d), 16)
+    z = torch.zeros(128, device=d)
+    with pytest.raises(_lib.RohmHipError):          # K = 160 < 192: no stream kernel
+        ops.gemm_planes_ln(ap, wp, 144, 128, 160, 16, z, torch.zeros(144, 128, device=d), 2, want_stats=True, ln_dim=128)
+    ap, wp = ops.planes_split(torch.zeros(144, 224, device=d), 16), ops.planes_split(torch.zeros(128, 224, device=d), 16)
+    with pytest.raises(_lib.RohmHipError):          # two statistics slots of 144 x 1024 / 16 pairs do not fit the 160 KiB of LDS
+        ops.gemm_planes_ln(ap, ops.planes_split(torch.zeros(1024, 224, device=d), 16), 144, 1024, 224, 16, torch.zeros(1024, device=d),
+                           torch.zeros(144, 1024, device=d), 2, r_stats=torch.zeros(9, 64, 16, 2, device=d),
+                           r_gamma=torch.zeros(1024, device=d), r_beta=torch.zeros(1024, device=d), ln_dim=1024)
+    with pytest.raises(_lib.RohmHipError):          # ln_dim = K = 224 is not a multiple of 128
+        ops.gemm_planes_ln(ap, wp, 144, 128, 224, 16, z, None, 1, ln_stats=torch.zeros(9, 14, 16, 2, device=d), ln_c=z, ln_dim=224)
