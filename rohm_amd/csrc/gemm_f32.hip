@@ -31,6 +31,7 @@
 //     SIMD a clustered non-MFMA issue slot is an MFMA-pipe bubble.
 //   * XCD-aware tile order: each XCD gets a contiguous run of tiles sharing A panels.
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 #include "common.h"
 
@@ -296,8 +297,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // per-lane row slots -- !M32: slot r = row m0 + 16 r + li; M32: slots 0..3 = rows m0 + 32 rb + li32, slot 4 = row
     // m0 + 128 + li.
     constexpr int NSLOT = M32 ? 5 : NRB;
-    constexpr bool LN_CONSUMER = (EPI == EPI_QKV || EPI == EPI_BIAS_GELU);
-    constexpr bool LN_PRODUCER = (EPI == EPI_BIAS_RES) && !M32;
+    // LayerNorm folding (opt-in, measured slower than the LayerNorm kernel) lives in the general instantiation only: the FULL one
+    // carries no run-time choices in its epilogue (every conditional operand load is a value merge the compiler resolves with a
+    // vmcnt(0) right behind the load)
+    constexpr bool LN_CONSUMER = (EPI == EPI_QKV || EPI == EPI_BIAS_GELU) && !FULL;
+    constexpr bool LN_PRODUCER = (EPI == EPI_BIAS_RES) && !M32 && !FULL;
     float amu[NSLOT], ars[NSLOT], rmu[NSLOT], rrs[NSLOT], osum[NSLOT], osq[NSLOT];
     auto slot_row = [&](int sl) {
         int m;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 row_mu_rstd(p.ln_stats, p.ln_parts, slot_row(sl), p.ln_dim, p.ln_eps, amu[sl], ars[sl]);
         }
     }
-    if constexpr (EPI == EPI_BIAS_RES) {
+    if constexpr (EPI == EPI_BIAS_RES && !FULL) {
         if (p.r_stats) {
 #pragma unroll
             for (int sl = 0; sl < NSLOT; ++sl)
@@ -321,6 +325,175 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) { osum[sl] = 0.f; osq[sl] = 0.f; }
     }
+    // ---- epilogue operands (defined here: the last chunk's iteration already requests them) -------------------------------
+    const int nw = n0 + wave * WN;
+    const bool vec_ok = FULL || ((p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0));
+    // An output unit (4 consecutive columns of one row) needs, besides its accumulators, values from memory: the bias, the
+    // fold vectors, the residual.  They are read in `load_ops`, used in `finish`.  The struct members are plain pointers (no
+    // restrict), so hipcc must assume that a store to C changes them and keeps every load behind the store before it: emitted
+    // unit by unit, each unit waits vmcnt(0) for its own loads AND for the acknowledgement of the store before -- one
+    // dependent round trip to memory per unit (18 to 54 per lane).  The hot instantiations (PRE) therefore read the operands of
+    // ALL units first (identical addresses -- the bias of a column group -- collapse into one load) and then only compute
+    // and store.
+    struct ColOps { f32x4 bias, c4, g4, b4; };      // what depends on the column group only
+    // (not where it would spill: the 384-wide tile keeps 216 accumulators per lane; its QKV form fits, 475 VGPRs)
+    constexpr bool PRE = EPI != EPI_EMBED && !(BN >= 384 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RES));
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_col = [&](int nb) __attribute__((always_inline)) {
+        ColOps o{zero4, zero4, zero4, zero4};
+        if (!FULL && nb >= p.N) return o;
+        if constexpr (FULL) {
+            o.bias = *reinterpret_cast<const f32x4*>(p.bias + nb);        // the launcher proved bias != null
+        } else if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.bias[q] = (nb + q < p.N) ? p.bias[nb + q] : 0.f;
+        }
+        if constexpr (LN_CONSUMER) {
+            if (p.ln_stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o.c4[q] = (nb + q < p.N) ? p.ln_c[nb + q] : 0.f;
+            }
+        }
+        if constexpr (EPI == EPI_BIAS_RES && !FULL) {
+            if (p.r_stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (nb + q < p.N) { o.g4[q] = p.r_gamma[nb + q]; o.b4[q] = p.r_beta[nb + q]; }
+            }
+        }
+        return o;
+    };
+    auto load_res = [&](int m, int nb) __attribute__((always_inline)) {
+        f32x4 rr = zero4;
+        if constexpr (EPI == EPI_BIAS_RES) {
+            if (!FULL && (m >= p.M || nb >= p.N)) return rr;
+            const float* rp = p.R + (size_t)m * p.ldr + nb;
+            if (FULL || (vec_ok && (p.ldr % 4 == 0) && (((uintptr_t)p.R & 15) == 0))) {
+                rr = *reinterpret_cast<const f32x4*>(rp);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (nb + q < p.N) rr[q] = rp[q];
+            }
+        }
+        return rr;
+    };
+    auto finish = [&](int m, int nb, f32x4 a, int sl, const ColOps& o, f32x4 rr) __attribute__((always_inline)) {
+        if (!FULL && (m >= p.M || nb >= p.N)) return;
+        if constexpr (EPI == EPI_BIAS) {
+            if (ksplit > 1) {      // raw partial tile; ld_partial is a multiple of 4 and covers N rounded up
+                *reinterpret_cast<f32x4*>(p.partial + ((size_t)split * p.M + m) * p.ld_partial + nb) = a;
+                return;
+            }
+        }
+        f32x4 v;
+        bool folded = false;
+        if constexpr (LN_CONSUMER) {
+            if (p.ln_stats) {       // (acc - mu c_n) rstd + d_n ; d_n arrives as the bias
+                folded = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (a[q] - amu[sl] * o.c4[q]) * ars[sl] + o.bias[q];
+            }
+        }
+        if (!folded) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = a[q] + o.bias[q];
+        }
+        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+        }
+        if constexpr (EPI == EPI_BIAS_RES) {
+            if constexpr (!FULL) {
+                if (p.r_stats) {        // the residual is LN(raw): normalise it on the fly
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr[q] = (rr[q] - rmu[sl]) * rrs[sl] * o.g4[q] + o.b4[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += rr[q];
+            if constexpr (LN_PRODUCER) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (FULL || nb + q < p.N) { osum[sl] += v[q]; osq[sl] += v[q] * v[q]; }
+            }
+        }
+        if constexpr (EPI == EPI_QKV) {
+            if (nb < p.qcols) {      // qcols is a multiple of 4
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= p.qscale;
+            }
+        }
+        if constexpr (EPI == EPI_EMBED) {
+            const int bidx = m / p.S, tok = m % p.S;
+            const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb
+                                         : p.tab + (size_t)tok * p.ldtab + nb;
+            if constexpr (FULL) {
+                const f32x4 tt = *reinterpret_cast<const f32x4*>(tp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tt[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tp[q];
+            }
+        }
+        const size_t crow = CONV ? (size_t)m * (p.orow_mul_m1 + 1) + p.orow_add : (size_t)m;
+        float* cp = p.C + crow * p.ldc + nb + ((CONV && p.ncol_split && nb >= p.ncol_split) ? p.ncol_jump : 0);
+        if (vec_ok) {
+            *reinterpret_cast<f32x4*>(cp) = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (nb + q < p.N) cp[q] = v[q];
+        }
+    };
+    // every unit of this lane, in a fixed order with compile-time indices: fn(unit, column group, row, first column, accumulators, row slot)
+    constexpr int NUNIT = M32 ? 16 * NCB32 + NCB : NCB * NRB;
+    constexpr int NCG = M32 ? 4 * NCB32 + NCB : NCB;
+    auto for_units = [&](auto&& fn) __attribute__((always_inline)) {
+        if constexpr (M32) {
+            // acc32[rb][cb][4q' + r] = C[m0 + rb*32 + li32][nw + cb*32 + 8q' + 4*lg32 + r]
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB32; ++cb)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x16& a = acc32[rb * NCB32 + cb];
+                        fn((rb * NCB32 + cb) * 4 + qq, cb * 4 + qq, m0 + rb * 32 + li32, nw + cb * 32 + 8 * qq + 4 * lg32,
+                           f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]}, rb);
+                    }
+            // acc16[c][r] = C[m0 + 128 + li][nw + c*16 + 4*lg + r]
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) fn(16 * NCB32 + c, 4 * NCB32 + c, m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c], 4);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < NRB; ++r) fn(c * NRB + r, c, m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c], r);
+        }
+    };
+    // EARLY: the operands are requested at the top of the LAST chunk's iteration and land under its MFMAs (2 us of them); the
+    // 384-wide tile has no registers to spare during the loop and requests them behind it.
+    constexpr bool PEEL = BN <= 256;
+    constexpr bool EARLY = PRE && PEEL && FULL && EPI != EPI_OUT_T && !(BN >= 256 && EPI == EPI_BIAS_RES);
+    ColOps col[PRE ? NCG : 1];
+    f32x4 res[(PRE && EPI == EPI_BIAS_RES) ? NUNIT : 1];
+    auto request_ops = [&]() __attribute__((always_inline)) {
+        if constexpr (M32) {
+#pragma unroll
+            for (int cb = 0; cb < NCB32; ++cb)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) col[cb * 4 + qq] = load_col(nw + cb * 32 + 8 * qq + 4 * lg32);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) col[4 * NCB32 + c] = load_col(nw + c * 16 + lg * 4);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) col[c] = load_col(nw + c * 16 + lg * 4);
+        }
+        if constexpr (EPI == EPI_BIAS_RES)
+            for_units([&](int i, int, int m, int nb, f32x4, int) __attribute__((always_inline)) { res[i] = load_res(m, nb); });
+    };
     // every wave issues exactly PIECES loads per chunk (the statistics loads above are younger: waiting for
     // vmcnt <= PIECES still means chunk 0 has landed)
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
@@ -330,29 +503,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     read_frags(f0, 0, 0);
     constexpr int NG = READS;                       // one LDS read per scheduling group
     constexpr int MF = (MFMAS + NG - 1) / NG;       // MFMAs per group (the tail groups run dry, harmless)
-    for (int kc = 0; kc < nk; ++kc) {
+    // The last chunk's iteration is peeled: it prefetches nothing (no wait, no barrier -- nobody overwrites a buffer any more),
+    // and it is where the epilogue's operands are requested (EARLY).
+    auto chunk = [&](int kc, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const int buf = kc & 1;
         if constexpr (VAR != 5) {
+            if constexpr (LAST && EARLY) request_ops();
             read_frags(f1, buf, 1);
             mma_half(f0);
             SchedGroups<0, NG, MF, READS, 0, 0, CONV ? 6 : 0>::run();
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // chunk k+1 landed
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            // the last two iterations re-fetch the last chunk (into buffers nobody reads again) instead of being
-            // predicated: the body stays one basic block
-            const int kn = kbase + ((kc + 2 < nk) ? (kc + 2) * BK : (nk - 1) * BK);
-            dma(buf, kn);
-            read_frags(f0, buf ^ 1, 0);
-            mma_half(f1);
-            SchedGroups<0, NG, MF, READS, PIECES, 1, CONV ? 6 : 0>::run();
+            if constexpr (!LAST) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // chunk k+1 landed
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                // the last iterations re-fetch the last chunk (into a buffer nobody reads again) instead of being predicated:
+                // the body stays one basic block
+                const int kn = kbase + ((kc + 2 < nk) ? (kc + 2) * BK : (nk - 1) * BK);
+                dma(buf, kn);
+                read_frags(f0, buf ^ 1, 0);
+                mma_half(f1);
+                SchedGroups<0, NG, MF, READS, PIECES, 1, CONV ? 6 : 0>::run();
+            } else {
+                mma_half(f1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         } else {
             mma_half(f0);
             mma_half(f0);
         }
+    };
+    if constexpr (PEEL) {
+        for (int kc = 0; kc + 1 < nk; ++kc) chunk(kc, std::false_type{});
+        chunk(nk - 1, std::true_type{});
+    } else {                                  // 384-wide tile: the peeled copy costs it registers it does not have (82 spills)
+        for (int kc = 0; kc < nk; ++kc) chunk(kc, std::false_type{});
     }
+    // the re-fetched chunk of the second to last iteration must have landed before the workgroup gives its LDS back; with EARLY the
+    // (younger) operand loads are waited for below, which covers it
+    if constexpr (!EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (VAR == 7) { ts_wall[2] = wall_clock64(); ts_cyc[1] = __builtin_readcyclecounter(); }
     if constexpr (VAR == 5 || VAR == 6) {
         // diagnostics: skip the epilogue unless an impossible value appears (keeps the MFMAs live)
@@ -360,7 +550,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------------
-    const int nw = n0 + wave * WN;
     if constexpr (EPI == EPI_OUT_T) {
         // natural operand order: rows = output channels m, cols = tokens n; stored transposed into [B, C_total, 1, T]
         // LN fold: the normalised operand is the token (column) side; a lane's columns are fixed per column block
@@ -376,209 +565,63 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 row_mu_rstd(p.ln_stats, p.ln_parts, n, p.ln_dim, p.ln_eps, cmu[c], crs[c]);
             }
         }
-        auto put = [&](int m, int n, float v, int cslot) {
+        // bias[m] / ln_c[m] of every row of this lane are read BEFORE the first store (see the note on `finish` below: behind a
+        // store to C the compiler must re-read them, one dependent round trip per value)
+        auto row_ops = [&](int m, float& bm, float& cm) __attribute__((always_inline)) {
+            const int mc = m < p.M ? m : p.M - 1;
+            bm = p.bias[mc];
+            cm = p.ln_stats ? p.ln_c[mc] : 0.f;
+        };
+        auto put = [&](int m, int n, float v, int cslot, float bm, float cm) __attribute__((always_inline)) {
             if (m >= p.M || n >= p.N) return;
             const int b = n / p.S, tok = n % p.S;
             if (tok == 0) return;
-            if (p.ln_stats) v = (v - cmu[cslot] * p.ln_c[m]) * crs[cslot];
-            p.C[((size_t)b * p.C_total + p.ch_off + m) * p.T + (tok - 1)] = v + p.bias[m];
+            if (p.ln_stats) v = (v - cmu[cslot] * cm) * crs[cslot];
+            p.C[((size_t)b * p.C_total + p.ch_off + m) * p.T + (tok - 1)] = v + bm;
         };
         if constexpr (M32) {
+            float bm32[4][16], cm32[4][16], bm16[4], cm16[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) row_ops(m0 + rb * 32 + 8 * (q >> 2) + 4 * lg32 + (q & 3), bm32[rb][q], cm32[rb][q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) row_ops(m0 + 128 + lg * 4 + q, bm16[q], cm16[q]);
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < NCB32; ++cb)
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        put(m0 + rb * 32 + 8 * (q >> 2) + 4 * lg32 + (q & 3), nw + cb * 32 + li32, acc32[rb * NCB32 + cb][q], cb);
+                        put(m0 + rb * 32 + 8 * (q >> 2) + 4 * lg32 + (q & 3), nw + cb * 32 + li32, acc32[rb * NCB32 + cb][q], cb,
+                            bm32[rb][q], cm32[rb][q]);
 #pragma unroll
             for (int c = 0; c < NCB; ++c)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) put(m0 + 128 + lg * 4 + q, nw + c * 16 + li, acc16[c][q], NCB32 + c);
+                for (int q = 0; q < 4; ++q) put(m0 + 128 + lg * 4 + q, nw + c * 16 + li, acc16[c][q], NCB32 + c, bm16[q], cm16[q]);
         } else {
+            float bm[NRB][4], cm[NRB][4];
+#pragma unroll
+            for (int r = 0; r < NRB; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) row_ops(m0 + r * 16 + lg * 4 + q, bm[r][q], cm[r][q]);
 #pragma unroll
             for (int r = 0; r < NRB; ++r)
 #pragma unroll
                 for (int c = 0; c < NCB; ++c)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) put(m0 + r * 16 + lg * 4 + q, nw + c * 16 + li, acc16[r * NCB + c][q], c);
+                    for (int q = 0; q < 4; ++q) put(m0 + r * 16 + lg * 4 + q, nw + c * 16 + li, acc16[r * NCB + c][q], c, bm[r][q], cm[r][q]);
         }
     } else {
         // swapped operand order: a lane holds C[m][nb .. nb+3].  FULL: the launcher proved M % 144 == 0,
         // N % BN == 0 and 16-byte alignment of C / R / bias / tables, so the hot instantiation carries no edge
         // masks and only 16-byte accesses.
-        const bool vec_ok = FULL || ((p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0));
-        // An output unit (4 consecutive columns of one row) needs, besides its accumulators, values from memory: the bias, the
-        // fold vectors, the residual.  They are read in `load_ops`, used in `finish`.  The struct members are plain pointers (no
-        // restrict), so hipcc must assume that a store to C changes them and keeps every load behind the store before it: emitted
-        // unit by unit, each unit waits vmcnt(0) for its own loads AND for the acknowledgement of the store before -- one
-        // dependent round trip to memory per unit (18 to 54 per lane).  The hot instantiations (PRE) therefore read the operands of
-        // ALL units first (identical addresses -- the bias of a column group -- collapse into one load) and then only compute
-        // and store.
-        struct ColOps { f32x4 bias, c4, g4, b4; };      // what depends on the column group only
-        constexpr bool PRE = FULL && !CONV && EPI != EPI_EMBED;
-        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto load_col = [&](int nb) __attribute__((always_inline)) {
-            ColOps o{zero4, zero4, zero4, zero4};
-            if (!FULL && nb >= p.N) return o;
-            if constexpr (FULL) {
-                if (p.bias) o.bias = *reinterpret_cast<const f32x4*>(p.bias + nb);
-            } else if (p.bias) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o.bias[q] = (nb + q < p.N) ? p.bias[nb + q] : 0.f;
-            }
-            if constexpr (LN_CONSUMER) {
-                if (p.ln_stats) {
-                    if constexpr (FULL) {
-                        o.c4 = *reinterpret_cast<const f32x4*>(p.ln_c + nb);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) o.c4[q] = (nb + q < p.N) ? p.ln_c[nb + q] : 0.f;
-                    }
-                }
-            }
-            if constexpr (EPI == EPI_BIAS_RES) {
-                if (p.r_stats) {
-                    if constexpr (FULL) {
-                        o.g4 = *reinterpret_cast<const f32x4*>(p.r_gamma + nb);
-                        o.b4 = *reinterpret_cast<const f32x4*>(p.r_beta + nb);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (nb + q < p.N) { o.g4[q] = p.r_gamma[nb + q]; o.b4[q] = p.r_beta[nb + q]; }
-                    }
-                }
-            }
-            return o;
-        };
-        auto load_res = [&](int m, int nb) __attribute__((always_inline)) {
-            f32x4 rr = zero4;
-            if constexpr (EPI == EPI_BIAS_RES) {
-                if (!FULL && (m >= p.M || nb >= p.N)) return rr;
-                const float* rp = p.R + (size_t)m * p.ldr + nb;
-                if (FULL || (vec_ok && (p.ldr % 4 == 0) && (((uintptr_t)p.R & 15) == 0))) {
-                    rr = *reinterpret_cast<const f32x4*>(rp);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (nb + q < p.N) rr[q] = rp[q];
-                }
-            }
-            return rr;
-        };
-        auto finish = [&](int m, int nb, f32x4 a, int sl, const ColOps& o, f32x4 rr) __attribute__((always_inline)) {
-            if (!FULL && (m >= p.M || nb >= p.N)) return;
-            if constexpr (EPI == EPI_BIAS) {
-                if (ksplit > 1) {      // raw partial tile; ld_partial is a multiple of 4 and covers N rounded up
-                    *reinterpret_cast<f32x4*>(p.partial + ((size_t)split * p.M + m) * p.ld_partial + nb) = a;
-                    return;
-                }
-            }
-            f32x4 v;
-            bool folded = false;
-            if constexpr (LN_CONSUMER) {
-                if (p.ln_stats) {       // (acc - mu c_n) rstd + d_n ; d_n arrives as the bias
-                    folded = true;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (a[q] - amu[sl] * o.c4[q]) * ars[sl] + o.bias[q];
-                }
-            }
-            if (!folded) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = a[q] + o.bias[q];
-            }
-            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
-            }
-            if constexpr (EPI == EPI_BIAS_RES) {
-                if (p.r_stats) {        // the residual is LN(raw): normalise it on the fly
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rr[q] = (rr[q] - rmu[sl]) * rrs[sl] * o.g4[q] + o.b4[q];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] += rr[q];
-                if constexpr (LN_PRODUCER) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (FULL || nb + q < p.N) { osum[sl] += v[q]; osq[sl] += v[q] * v[q]; }
-                }
-            }
-            if constexpr (EPI == EPI_QKV) {
-                if (nb < p.qcols) {      // qcols is a multiple of 4
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] *= p.qscale;
-                }
-            }
-            if constexpr (EPI == EPI_EMBED) {
-                const int bidx = m / p.S, tok = m % p.S;
-                const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb
-                                             : p.tab + (size_t)tok * p.ldtab + nb;
-                if constexpr (FULL) {
-                    const f32x4 tt = *reinterpret_cast<const f32x4*>(tp);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tt[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tp[q];
-                }
-            }
-            const size_t crow = CONV ? (size_t)m * (p.orow_mul_m1 + 1) + p.orow_add : (size_t)m;
-            float* cp = p.C + crow * p.ldc + nb + ((CONV && p.ncol_split && nb >= p.ncol_split) ? p.ncol_jump : 0);
-            if (vec_ok) {
-                *reinterpret_cast<f32x4*>(cp) = v;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (nb + q < p.N) cp[q] = v[q];
-            }
-        };
-        // every unit of this lane, in a fixed order with compile-time indices: fn(unit, column group, row, first column, accumulators, row slot)
-        constexpr int NUNIT = M32 ? 16 * NCB32 + NCB : NCB * NRB;
-        constexpr int NCG = M32 ? 4 * NCB32 + NCB : NCB;
-        auto for_units = [&](auto&& fn) __attribute__((always_inline)) {
-            if constexpr (M32) {
-                // acc32[rb][cb][4q' + r] = C[m0 + rb*32 + li32][nw + cb*32 + 8q' + 4*lg32 + r]
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < NCB32; ++cb)
-#pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) {
-                            const f32x16& a = acc32[rb * NCB32 + cb];
-                            fn((rb * NCB32 + cb) * 4 + qq, cb * 4 + qq, m0 + rb * 32 + li32, nw + cb * 32 + 8 * qq + 4 * lg32,
-                               f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]}, rb);
-                        }
-                // acc16[c][r] = C[m0 + 128 + li][nw + c*16 + 4*lg + r]
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) fn(16 * NCB32 + c, 4 * NCB32 + c, m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c], 4);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NCB; ++c)
-#pragma unroll
-                    for (int r = 0; r < NRB; ++r) fn(c * NRB + r, c, m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c], r);
-            }
-        };
         if constexpr (PRE) {
-            ColOps col[NCG];
-            if constexpr (M32) {
-#pragma unroll
-                for (int cb = 0; cb < NCB32; ++cb)
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) col[cb * 4 + qq] = load_col(nw + cb * 32 + 8 * qq + 4 * lg32);
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) col[4 * NCB32 + c] = load_col(nw + c * 16 + lg * 4);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) col[c] = load_col(nw + c * 16 + lg * 4);
-            }
-            if constexpr (EPI == EPI_BIAS_RES) {
-                f32x4 res[NUNIT];
-                for_units([&](int i, int, int m, int nb, f32x4, int) __attribute__((always_inline)) { res[i] = load_res(m, nb); });
+            if constexpr (!EARLY) request_ops();
+            if constexpr (EPI == EPI_BIAS_RES)
                 for_units([&](int i, int cg, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, col[cg], res[i]); });
-            } else {
+            else
                 for_units([&](int, int cg, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, col[cg], zero4); });
-            }
         } else {
             for_units([&](int, int, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, load_col(nb), load_res(m, nb)); });
         }
@@ -725,7 +768,8 @@ static inline bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 
 template <int BN, int EPI, int VAR = 0>
 static int launch_t(const GemmParams& p, hipStream_t s) {
-    bool full = (p.M % BM == 0) && (p.N % BN == 0) && (p.ldc % 4 == 0) && al16(p.C) && al16(p.bias);
+    bool full = (p.M % BM == 0) && (p.N % BN == 0) && (p.ldc % 4 == 0) && al16(p.C) && al16(p.bias) && p.bias;
+    if (p.ln_stats || p.r_stats || p.out_stats) full = false;      // LayerNorm folding: general instantiation only
     if (EPI == EPI_BIAS_RES) full = full && (p.ldr % 4 == 0) && al16(p.R);
     if (EPI == EPI_EMBED) full = full && (p.ldtab % 4 == 0) && (p.ldtab0 % 4 == 0) && al16(p.tab) && al16(p.tab0);
     if (EPI == EPI_QKV) full = full && (p.qcols % 4 == 0);

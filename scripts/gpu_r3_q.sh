@@ -23,4 +23,5 @@ print('fp32 b32', round(d['value'], 2), d['unit'], 'frac', d['roofline']['frac']
 for k, v in list(d['roofline']['kernels'].items())[:8]:
     print('   ', k, v['avg_us'])
 PY
-timeout 600 python -m pytest tests/test_gpu_planes.py -x -q -p no:cacheprovider -k "one_tile" 2>&1 | tail -3
+timeout 300 python scripts/bench_trajnet.py 1 32 > $OUT/trajnet_loop.json 2> $OUT/trajnet_loop.err; python -c "
+import json; d=json.load(open('$OUT/trajnet_loop.json')); [print(k, {a: b for a, b in v.items() if a != 'kernels'}) for k, v in d.items()]"
