@@ -422,8 +422,9 @@ def extras(args):
     labels = {
         'fp16x3': ('opt-in ROHM_GEMM_PRECISION=fp16x3: every fp32 product of the four encoder Linears emulated by three fp16 MFMA products of '
                    'two fp16 planes (h = fp16(x), l = fp16((x - h) 2^11); cross terms in a second accumulator of weight 2^-11), fp32 '
-                   'accumulation; ~2^-22 per product; held to the fp32 parity bars by tests/test_gpu_precision_ladder.py (whole PoseNet '
-                   'suite); NEVER the headline (narrower arithmetic than the reference)'),
+                   'accumulation; ~2^-22 per product; LayerNorm folded into the GEMMs around it (ROHM_PP_LNFOLD, default on in the two-plane modes); '
+                   'held to the fp32 parity bars by tests/test_gpu_precision_ladder.py (whole PoseNet suite); NEVER the headline (narrower '
+                   'arithmetic than the reference)'),
         'bf16x6': ('opt-in ROHM_GEMM_PRECISION=bf16x6: six bf16 MFMA products of three exact truncation planes per fp32 product, fp32 '
                    'accumulation; held to the fp32 parity bars by the same suite; NEVER the headline'),
     }

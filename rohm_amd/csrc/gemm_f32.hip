@@ -337,12 +337,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // and store.
     struct ColOps { f32x4 bias, c4, g4, b4; };      // what depends on the column group only
     // (not where it would spill: the 384-wide tile keeps 216 accumulators per lane; its QKV form fits, 475 VGPRs)
-    constexpr bool PRE = EPI != EPI_EMBED && !(BN >= 384 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RES));
+    constexpr bool PRE = !(BN >= 384 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_EMBED));
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto load_col = [&](int nb) __attribute__((always_inline)) {
         ColOps o{zero4, zero4, zero4, zero4};
         if (!FULL && nb >= p.N) return o;
-        if constexpr (FULL) {
+        if constexpr (EPI == EPI_EMBED) {
+            // no bias operand: it is part of the table rows (load_res)
+        } else if constexpr (FULL) {
             o.bias = *reinterpret_cast<const f32x4*>(p.bias + nb);        // the launcher proved bias != null
         } else if (p.bias) {
 #pragma unroll
@@ -365,6 +367,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     };
     auto load_res = [&](int m, int nb) __attribute__((always_inline)) {
         f32x4 rr = zero4;
+        if constexpr (EPI == EPI_EMBED) {      // the row of the positional / timestep table this unit adds
+            if (!FULL && (m >= p.M || nb >= p.N)) return rr;
+            const int bidx = m / p.S, tok = m % p.S;
+            const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb : p.tab + (size_t)tok * p.ldtab + nb;
+            if constexpr (FULL) {
+                rr = *reinterpret_cast<const f32x4*>(tp);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (nb + q < p.N) rr[q] = tp[q];
+            }
+        }
         if constexpr (EPI == EPI_BIAS_RES) {
             if (!FULL && (m >= p.M || nb >= p.N)) return rr;
             const float* rp = p.R + (size_t)m * p.ldr + nb;
@@ -425,17 +439,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             }
         }
         if constexpr (EPI == EPI_EMBED) {
-            const int bidx = m / p.S, tok = m % p.S;
-            const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb
-                                         : p.tab + (size_t)tok * p.ldtab + nb;
-            if constexpr (FULL) {
-                const f32x4 tt = *reinterpret_cast<const f32x4*>(tp);
+            const int tok = m % p.S;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tt[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + tp[q];
-            }
+            for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + rr[q];
         }
         const size_t crow = CONV ? (size_t)m * (p.orow_mul_m1 + 1) + p.orow_add : (size_t)m;
         float* cp = p.C + crow * p.ldc + nb + ((CONV && p.ncol_split && nb >= p.ncol_split) ? p.ncol_jump : 0);
@@ -475,10 +481,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     };
     // EARLY: the operands are requested at the top of the LAST chunk's iteration and land under its MFMAs (2 us of them); the
     // 384-wide tile has no registers to spare during the loop and requests them behind it.
+    constexpr bool HAS_RES = (EPI == EPI_BIAS_RES || EPI == EPI_EMBED);      // a per-unit operand besides the column operands
     constexpr bool PEEL = BN <= 256;
-    constexpr bool EARLY = PRE && PEEL && FULL && EPI != EPI_OUT_T && !(BN >= 256 && EPI == EPI_BIAS_RES);
+    constexpr bool EARLY = PRE && PEEL && FULL && EPI != EPI_OUT_T && !(BN >= 256 && HAS_RES);
     ColOps col[PRE ? NCG : 1];
-    f32x4 res[(PRE && EPI == EPI_BIAS_RES) ? NUNIT : 1];
+    f32x4 res[(PRE && HAS_RES) ? NUNIT : 1];
     auto request_ops = [&]() __attribute__((always_inline)) {
         if constexpr (M32) {
 #pragma unroll
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int c = 0; c < NCB; ++c) col[c] = load_col(nw + c * 16 + lg * 4);
         }
-        if constexpr (EPI == EPI_BIAS_RES)
+        if constexpr (HAS_RES)
             for_units([&](int i, int, int m, int nb, f32x4, int) __attribute__((always_inline)) { res[i] = load_res(m, nb); });
     };
     // every wave issues exactly PIECES loads per chunk (the statistics loads above are younger: waiting for
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         // masks and only 16-byte accesses.
         if constexpr (PRE) {
             if constexpr (!EARLY) request_ops();
-            if constexpr (EPI == EPI_BIAS_RES)
+            if constexpr (HAS_RES)
                 for_units([&](int i, int cg, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, col[cg], res[i]); });
             else
                 for_units([&](int, int cg, int m, int nb, f32x4 a, int sl) __attribute__((always_inline)) { finish(m, nb, a, sl, col[cg], zero4); });
@@ -768,7 +775,7 @@ static inline bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 
 template <int BN, int EPI, int VAR = 0>
 static int launch_t(const GemmParams& p, hipStream_t s) {
-    bool full = (p.M % BM == 0) && (p.N % BN == 0) && (p.ldc % 4 == 0) && al16(p.C) && al16(p.bias) && p.bias;
+    bool full = (p.M % BM == 0) && (p.N % BN == 0) && (p.ldc % 4 == 0) && al16(p.C) && al16(p.bias) && (p.bias || EPI == EPI_EMBED);
     if (p.ln_stats || p.r_stats || p.out_stats) full = false;      // LayerNorm folding: general instantiation only
     if (EPI == EPI_BIAS_RES) full = full && (p.ldr % 4 == 0) && al16(p.R);
     if (EPI == EPI_EMBED) full = full && (p.ldtab % 4 == 0) && (p.ldtab0 % 4 == 0) && al16(p.tab) && al16(p.tab0);
