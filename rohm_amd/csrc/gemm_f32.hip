@@ -291,6 +291,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int nk = nk_all / ksplit + (split < nk_all % ksplit ? 1 : 0);
     const int kc0 = split * (nk_all / ksplit) + (split < nk_all % ksplit ? split : nk_all % ksplit);
     const int kbase = kc0 * BK;
+    // 384-wide tile (QKV): no registers to keep 18 column groups of bias during the loop, and a global load behind the loop is a
+    // round trip in front of 54 stores per lane -- the tile's bias row goes through LDS instead (an LDS read is not ordered
+    // against the stores to C): two LDS-DMA pieces of wave 0 in front of chunk 0's (older, so the prologue's counted wait covers
+    // them; through registers the ds_write drew a vmcnt(0) that drained chunk 1 as well)
+    constexpr bool COL_LDS = FULL && !CONV && BN >= 384 && EPI != EPI_EMBED && EPI != EPI_OUT_T;
+    float* const bias_s = lds_dummy + 512;          // the row-statistics zone of the general instantiation (unused here), 4.5 KiB
+    if constexpr (COL_LDS) {
+        if (wave == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int unit = h * 64 + lane;                               // 16-byte unit of the tile's bias row (BN / 4 of them)
+                const float* src = p.bias + n0 + (unit < BN / 4 ? unit : BN / 4 - 1) * 4;      // the tail re-reads the last one
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(bias_s + h * 256), 16, 0, 0);
+            }
+        }
+    }
     dma(0, kbase);
     if (nk > 1) dma(1, kbase + BK);
     // ---- LayerNorm folding (common.h): row statistics, fetched under the prologue's DMA latency ----------------------
@@ -344,6 +361,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if (!FULL && nb >= p.N) return o;
         if constexpr (EPI == EPI_EMBED) {
             // no bias operand: it is part of the table rows (load_res)
+        } else if constexpr (COL_LDS) {
+            o.bias = *reinterpret_cast<const f32x4*>(bias_s + (nb - n0));
         } else if constexpr (FULL) {
             o.bias = *reinterpret_cast<const f32x4*>(p.bias + nb);        // the launcher proved bias != null
         } else if (p.bias) {
