@@ -30,6 +30,11 @@
 //     predicated) and sched_group_barrier spreads every non-MFMA instruction between MFMAs: with one wave per
 //     SIMD a clustered non-MFMA issue slot is an MFMA-pipe bubble.
 //   * XCD-aware tile order: each XCD gets a contiguous run of tiles sharing A panels.
+//   * epilogue: the operands a unit needs from memory (bias, residual, embed-table row) are read for ALL units before the first store
+//     -- GemmParams members cannot be restrict, so behind a store to C the compiler must re-read them, one vmcnt(0) round trip per
+//     unit -- and, for tiles up to 256 wide, already at the top of the peeled last K chunk (they land under its MFMAs); the 384-wide
+//     tile takes its bias row through LDS.  The FULL instantiation has no conditional operand loads (LayerNorm folding lives in the
+//     general one).
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>

@@ -9,6 +9,7 @@
 // buffers that the producers write into directly, and GroupNorm + Mish + time bias + residual (+ control
 // residual) are one fused kernel per conv block.  Everything that depends on the timestep only -- the
 // sinusoid -> MLP embedding and the per-block time biases -- is one small launch per step.
+// In the TrajControl sample loop the ControlNet branch (timestep-dependent, x_t-independent) runs on a second stream, one step ahead.
 #include <math.h>
 #include <algorithm>
 #include <string.h>
