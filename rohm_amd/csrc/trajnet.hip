@@ -820,8 +820,8 @@ struct SideStream {
     int device = -1;
 };
 static SideStream* side_stream(int device) {
-    static const bool on = [] { const char* e = getenv("ROHM_TRAJ_CTRL_STREAM"); return !(e && e[0] == '0'); }();
-    if (!on) return nullptr;
+    const char* e = getenv("ROHM_TRAJ_CTRL_STREAM");      // read per loop call (once per 100 steps): tests flip it
+    if (e && e[0] == '0') return nullptr;
     static thread_local SideStream ss;
     if (ss.s2 && ss.device == device) return &ss;
     if (ss.s2) return nullptr;                  // a host thread that drives two devices keeps the one-stream order on the second

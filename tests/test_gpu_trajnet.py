@@ -137,6 +137,27 @@ def test_graph_replay_loop_is_bit_identical(monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_control_side_stream_is_bit_identical(monkeypatch):
+    """The ControlNet branch of the TrajControl loop runs on a second stream, one step ahead of the U-Net (two sets of residual
+    buffers, events): ROHM_TRAJ_CTRL_STREAM=0 (everything on the caller's stream, in the reference's order) must give the same bits,
+    run after run (a missing event would show up as a race)."""
+    net, _ = make_trajnet(82, True)
+    B = 3
+    cond, cc = seeded(15, B, 144, 13), seeded(16, B, 144, 272)
+    x_T, noises = cpu_noise_sequence(18, (B, 144, 13), 100)
+    outs = []
+    for flag in ('1', '0', '1', '1'):
+        monkeypatch.setenv('ROHM_TRAJ_CTRL_STREAM', flag)
+        diff = make_diffusion()
+        diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+        _, y = diff.eval_losses(model=net, batch={'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}, shape=[B, 144, 13],
+                                progress=False, clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
+                                compute_loss=False)
+        outs.append(y.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert torch.isfinite(outs[0]).all()
+
+
 def test_shape_errors_are_raised_before_the_c_abi():
     """cond / control_cond of the wrong shape must raise (the C ABI takes raw pointers)."""
     from rohm_amd.model.trajnet import TrajNet
