@@ -126,6 +126,24 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 #ifdef __HIPCC__
+// All-lanes sum of a 64-wide wave, bit-identical to the xor butterfly  for (o = 32; o; o >>= 1) v += __shfl_xor(v, o)  -- but on the
+// VALU: __shfl_xor compiles to ds_bpermute_b32 (the LDS crossbar, ~100 cycles and an lgkmcnt wait per step; twelve of them in a row
+// were ~0.7 us of the LayerNorm kernel's latency chain).  Steps 32 / 16 exchange lane halves / rows with v_permlane32/16_swap (own +
+// partner: addition commutes, so which of the two results is "own" does not matter); after them every lane of a column holds the
+// same value, and a row rotation by 8 / 4 / 2 / 1 (DPP) delivers a value of exactly the class lane ^ 8 / 4 / 2 / 1 would.
+__device__ __forceinline__ float wave_sum64(float v) {
+    typedef unsigned rohm_u2 __attribute__((ext_vector_type(2)));
+    rohm_u2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+    s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, true));      // row_ror:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, true));      // row_ror:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xf, 0xf, true));      // row_ror:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xf, 0xf, true));      // row_ror:1
+    return v;
+}
+
 // erf-form GELU (activation="gelu", model/posenet.py:67; NOT the tanh approximation).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <=
 // 1.5e-7, i.e. at fp32 resolution of the 1 + erf term) -- branch-free, one rcp + one exp, ~3x cheaper than the
 // library erff in a 72-element-per-lane epilogue.

@@ -23,8 +23,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
         v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum64(s);
     const float mean = s * (1.0f / D);
     float q = 0.f;
 #pragma unroll
@@ -34,8 +33,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
             const float d = v[i][j] - mean;
             q += d * d;
         }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_sum64(q);
     const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-5f);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -88,8 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(float* __restrict
             v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = wave_sum64(s);
         const float mean = s * (1.0f / D);
         float q = 0.f;
 #pragma unroll
@@ -99,8 +96,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(float* __restrict
                 const float d = v[i][j] - mean;
                 q += d * d;
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        q = wave_sum64(q);
         const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-5f);
 #pragma unroll
         for (int i = 0; i < V; ++i) {

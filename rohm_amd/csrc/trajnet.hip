@@ -153,8 +153,7 @@ struct GnArgs {
 constexpr int kGnMaxPerThread = 16;      // scalar units per thread: groups of up to 4096 values (T <= 512 at 8 channels per group)
 constexpr int kGnVecPerThread = 4;       // 16-byte units per thread: the same 4096 values
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum64(v);
     const int w = threadIdx.x >> 6;
     __syncthreads();                    // sh may still be read from the previous call
     if ((threadIdx.x & 63) == 0) sh[w] = v;
