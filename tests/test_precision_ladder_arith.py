@@ -104,3 +104,33 @@ def test_fp16_two_plane_split_is_fp32_class_with_three_products():
     e32 = np.abs((a @ w.T).astype(np.float64) - exact).max() / scale
     assert e16 < 2.0 ** -20, e16
     assert e16 < 8 * max(e32, 2.0 ** -24)
+
+
+def test_layernorm_fold_algebra_and_statistics_layout():
+    """The LayerNorm fold of the two-plane modes (gemm_pp.hip, posenet.hip): with c_n = sum_k gamma_k W_nk and
+    d_n = b_n + sum_k beta_k W_nk,  (x W_gamma^T - mu c) rstd + d  ==  LN(x) W^T + b,  where (mu, rstd) come from the partial
+    (sum, sum of squares) pairs per 16 columns that a producer GEMM writes in the layout [row / 16][D / 16][row % 16][2]."""
+    rng = np.random.default_rng(3)
+    M, D, N = 48, 512, 96
+    x = (rng.standard_normal((M, D)) * 1.5 + 0.5)
+    w, b = rng.standard_normal((N, D)) / np.sqrt(D), rng.standard_normal(N)
+    gam, bet = 1.0 + 0.2 * rng.standard_normal(D), 0.1 * rng.standard_normal(D)
+    mu, var = x.mean(-1, keepdims=True), x.var(-1, keepdims=True)
+    want = ((x - mu) / np.sqrt(var + 1e-5) * gam + bet) @ w.T + b
+    # the producer's statistics: per row and 16-column part, in the kernel's layout
+    parts = x.reshape(M // 16, 16, D // 16, 16)
+    stats = np.stack([parts.sum(-1), (parts ** 2).sum(-1)], -1).transpose(0, 2, 1, 3)        # [M/16][D/16][16][2]
+    assert stats.shape == (M // 16, D // 16, 16, 2)
+    su = stats[..., 0].sum(1).reshape(M)          # over the parts: [M/16][16] -> rows in order
+    sq = stats[..., 1].sum(1).reshape(M)
+    mu_k = su / D
+    rstd_k = 1.0 / np.sqrt(np.maximum(sq / D - mu_k ** 2, 0.0) + 1e-5)      # biased variance, eps inside the root, clamp as the kernel does
+    assert np.allclose(mu_k, mu[:, 0], rtol=0, atol=1e-12) and np.allclose(rstd_k, 1.0 / np.sqrt(var[:, 0] + 1e-5), rtol=1e-10)
+    wg = w * gam
+    c, d = wg.sum(1), b + w @ bet
+    got = ((x @ wg.T) - mu_k[:, None] * c) * rstd_k[:, None] + d
+    assert np.abs(got - want).max() < 1e-11
+    # in float32 the cancellation (acc - mu c) costs about |mu| / sigma ulps of the accumulator: the GPU test allows twice the plain bar
+    x32, wg32 = x.astype(np.float32), wg.astype(np.float32)
+    got32 = ((x32 @ wg32.T) - mu_k.astype(np.float32)[:, None] * c.astype(np.float32)) * rstd_k.astype(np.float32)[:, None] + d.astype(np.float32)
+    assert np.abs(got32 - want).max() < 4e-5 * np.sqrt(D / 32)
