@@ -308,6 +308,30 @@ def digest(t, n_proj=6):
     return np.concatenate([[x.size, x.sum(), np.abs(x).sum()], g.standard_normal((n_proj, x.size)) @ x])
 
 
+def exact_hash(t):
+    """sha256 of the float32 bytes (with -0.0 folded onto +0.0): for regions that are bit-exact COPIES / masks of the inputs
+    on every platform (channels 22.. of PoseNet's cond, control_cond, the un-touched channels of motion_repr_noisy)."""
+    import hashlib
+    x = np.ascontiguousarray((t.detach().cpu().float() + 0.0).numpy() if torch.is_tensor(t) else np.asarray(t, np.float32) + 0.0)
+    return hashlib.sha256(x.tobytes()).hexdigest()
+
+
+def scheme_full_entries(prefix, key, v):
+    """What scheme.npz stores per tensor besides its digest (a digest is blind to one slightly wrong
+    element): COMPUTED parts in full (TrajNet's cond; channels 0..21 of PoseNet's cond = the re-derived trajectory), COPIED
+    parts as an exact hash."""
+    out = {}
+    v = v.detach().cpu()
+    if key == 'control_cond':
+        out[prefix + '_sha'] = exact_hash(v)
+    elif v.dim() == 4:                                   # PoseNet cond [bs, 294, 1, T]
+        out[prefix + '_full_traj'] = v[:, 0:22].numpy().astype(np.float32)
+        out[prefix + '_sha_rest'] = exact_hash(v[:, 22:])
+    else:                                                # TrajNet cond [bs, T, tfd]
+        out[prefix + '_full'] = v.numpy().astype(np.float32)
+    return out
+
+
 def golden_scheme(ref):
     """The drivers' inference-iteration loops, EXECUTED from the reference scripts' own text (test_amass_full.py:217-384,
     test_prox_egobody.py:214-324; the scripts cannot be imported -- configargparse / datasets / checkpoints at module
@@ -359,7 +383,9 @@ def golden_scheme(ref):
             for kk, v in tens.items():
                 out[pre + f'call{k}_{kk}'] = digest(v)
                 out[pre + f'call{k}_{kk}_shape'] = np.asarray(v.shape)
+                out.update(scheme_full_entries(pre + f'call{k}_{kk}', kk, v))
         out[pre + 'traj_rec_full'] = digest(ns['traj_rec_full'])
+        out[pre + 'traj_rec_full_full'] = ns['traj_rec_full'].numpy()            # float64, as the script holds it
         if args.full_seed is not None:
             # the script draws `torch.FloatTensor(bs).uniform_(0, clip_len - 1).long()` once per masked iteration and
             # nothing else touches the generator: replay the draws
@@ -372,11 +398,148 @@ def golden_scheme(ref):
         tb, pb = ns['test_batch_traj'], ns['test_batch_pose']
         out[pre + 'after_traj_noisy'] = digest(tb['motion_repr_noisy'])
         out[pre + 'after_traj_cond'] = digest(tb['cond'])
+        out[pre + 'after_traj_cond_full'] = tb['cond'].numpy().astype(np.float32)
+        out[pre + 'after_traj_noisy_sha'] = exact_hash(tb['motion_repr_noisy'])
         out[pre + 'after_pose_noisy_shape'] = np.asarray(pb['motion_repr_noisy'].shape)
         out[pre + 'after_pose_clean_shape'] = np.asarray(pb['motion_repr_clean'].shape)
         print('scheme case', ci, kind, kw, [n for n, _, _ in log])
     np.savez_compressed(os.path.join(OUT, 'scheme.npz'), n_cases=len(SCHEME_CASES), **out)
     print('scheme.npz', os.path.getsize(os.path.join(OUT, 'scheme.npz')))
+
+
+SCHEME_REAL_HEAD_T = (103, 102, 101, 100, 99)
+# (driver, args overrides, PoseNet stage): an int = the reference's own sampler on its own N-step cosine schedule
+# (free-running, un-guided: chaos is no excuse there); 'head' = the reference's own p_sample_with_grad over the guided head
+# t = 103 .. 99 of the 1000-step schedule at the reference's weights (3e5 / 1e5): three un-guided steps, then the first two
+# guided ones (2-D term + skating term each).  The stage starts from th.randn like every PoseNet stage; from that start the reference and its fp32
+# restatement are 3e-4 / 4e-3 / 6e-2 / 5e-1 apart in x after t = 100 / 99 / 98 / 97 (|x| jumps from 4 to 43 at the first
+# guided step with B = 2: the 2-D term is a batch MEAN of L1 terms, its per-clip gradient scales as 1 / B) and the returned
+# pred_xstart 7e-6 apart at t = 99, 1e-4 at t = 98, 4e-3 at t = 97 -- measured in the build container
+# (profiles/r4_scheme_head_chaos.txt); inside the scheme the second head stage multiplies what the first one left.
+SCHEME_REAL_CASES = (
+    ('amass', dict(mask_scheme='lower', cond_fn_with_grad=False), 50),                 # BASELINE configs[2] shape
+    ('prox', dict(sample_iter=3, cond_fn_with_grad=False, early_stop=True), 40),       # configs[4] shape, un-guided
+    ('prox', dict(sample_iter=2, cond_fn_with_grad=True, early_stop=True), 'head'),    # configs[3]/[4] guidance
+)
+SCHEME_REAL_SEEDS = dict(trajnet=71, control=72, posenet=73, noise=3100)
+# dataset.cam_t of the guided case: the camera 12 m behind the canonical origin along its axis -- the trajectory this PoseNet
+# stage is conditioned on is the output of a random-weight TrajNet, so the body may stand anywhere within a few metres of the
+# origin; with synth.SYNTH_CAM_T it crosses the camera plane and the pinhole division sends the first guided step to |x| ~ 1e8
+SCHEME_REAL_CAM_T = [[0.1, -0.2, -12.0]]
+
+
+def scheme_real_case(ci, B=2):
+    """Inputs of one free-running real-network case (shared by the generator and the tests)."""
+    kind, kw, pose_steps = SCHEME_REAL_CASES[ci]
+    args, tfd, body_t, s_traj, s_pose, bt, bp, _, _ = scheme_case(kind, kw, B=B)
+    cam = synth.synthetic_camera_batch(4, B) if pose_steps == 'head' else {}
+    # order and length of the reference's draws from the global generator: per stage one randn(*shape) + one randn_like
+    # per step (gaussian_diffusion_posenet.py:613,458)
+    n_pose = len(SCHEME_REAL_HEAD_T) if pose_steps == 'head' else pose_steps
+    plan = []
+    for it in range(args.sample_iter):
+        plan.append(('traj', (B, 144, tfd), 100))
+        plan.append(('pose', (B, 294, 1, 143), n_pose))
+    return args, tfd, body_t, s_traj, s_pose, bt, bp, cam, pose_steps, plan
+
+
+def golden_scheme_real(ref):
+    """The drivers' inference-iteration loops, EXECUTED from the reference scripts' own text (test_amass_full.py:217-384,
+    test_prox_egobody.py:214-324) with the REFERENCE'S OWN networks and samplers, free-running end to end on CPU:
+    TrajNet (100 steps) -> the script's host re-derivation -> PoseNet -> TrajControl (100 steps) -> PoseNet [-> ...], B = 2,
+    noise from one `torch.manual_seed`.  Stored: the final tensors, traj_rec_full and every stage's output."""
+    import textwrap
+    import types
+    from oracle import geometry as G
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    refload.set_body_model(body)
+    src = {'amass': (open(os.path.join(refload.REF_ROOT, 'test_amass_full.py')).read().split('\n'), 216, 384),
+           'prox': (open(os.path.join(refload.REF_ROOT, 'test_prox_egobody.py')).read().split('\n'), 213, 324)}
+    sd_t = synth.trajnet_state_dict(SCHEME_REAL_SEEDS['trajnet'], trajcontrol=False)
+    sd_c = synth.trajnet_state_dict(SCHEME_REAL_SEEDS['control'], trajcontrol=True)
+    sd_p = synth.posenet_state_dict(SCHEME_REAL_SEEDS['posenet'])
+    out = {}
+    for ci, (kind, kw, pose_steps) in enumerate(SCHEME_REAL_CASES):
+        args, tfd, body_t, s_traj, s_pose, bt, bp, cam, _, plan = scheme_real_case(ci)
+        tds = types.SimpleNamespace(traj_feat_dim=tfd, pose_feat_dim=272, Mean=s_traj[0], Std=s_traj[1])
+        pds = types.SimpleNamespace(traj_feat_dim=22, pose_feat_dim=272, joints_num=22, Mean=s_pose[0], Std=s_pose[1],
+                                    cam_R=torch.tensor(synth.SYNTH_CAM_R), cam_t=torch.tensor(SCHEME_REAL_CAM_T))
+        tn = ref.trajnet.TrajNet(time_dim=32, mid_dim=512, cond_dim=tfd, traj_feat_dim=tfd, trajcontrol=False).eval()
+        tn.load_state_dict(sd_t, strict=True)
+        cn = ref.trajnet.TrajNet(time_dim=32, mid_dim=512, cond_dim=tfd, traj_feat_dim=tfd, trajcontrol=True).eval()
+        cn.load_state_dict(sd_c, strict=True)
+        pn = ref.posenet.PoseNet(pds, 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                                 device='cpu').eval()
+        pn.smplx_model = body
+        pn.load_state_dict(sd_p, strict=False)
+        mk = ref.model_util.create_gaussian_diffusion
+        d_t = mk(_Args, ref.gd_trajnet, ref.respace.SpacedDiffusionTrajNet, 100, '', device='cpu')
+        d_c = mk(_Args, ref.gd_trajnet, ref.respace.SpacedDiffusionTrajNet, 100, '', device='cpu')
+        stage_out = []
+
+        class Rec:           # the reference's sampler, with its result logged
+            def __init__(self, d, name):
+                self.d, self.name = d, name
+
+            def eval_losses(self, **kw2):
+                kw2['progress'] = False
+                r = self.d.eval_losses(**kw2)
+                stage_out.append((self.name, r[1].detach().clone()))
+                return r
+
+        class Head:          # the reference's own guided step, called step after step over the stable head
+            def __init__(self, d):
+                self.d = d
+
+            def eval_losses(self, model=None, batch=None, shape=None, clip_denoised=False, cond_fn_with_grad=False,
+                            grad_type=None, early_stop=False, **kw2):
+                assert cond_fn_with_grad and grad_type == 'prox'
+                img = torch.randn(*shape)
+                for i in SCHEME_REAL_HEAD_T:
+                    with torch.no_grad():
+                        o = self.d.p_sample_with_grad(model, batch, img, torch.tensor([i] * shape[0]),
+                                                      clip_denoised=clip_denoised, grad_type=grad_type)
+                    img = o['sample']
+                res = o['pred_xstart'] if early_stop else o['sample']      # p_sample_loop's return (:568-571)
+                stage_out.append(('pose', res.detach().clone()))
+                return None, res
+        if pose_steps == 'head':
+            d_p = Head(mk(_Args, ref.gd_posenet, ref.respace.SpacedDiffusionPoseNet, 1000, '', device='cpu'))
+        else:
+            d_p = Rec(mk(_Args, ref.gd_posenet, ref.respace.SpacedDiffusionPoseNet, pose_steps, '', device='cpu'), 'pose')
+        tbp = {k: v.clone() for k, v in bp.items()}
+        tbp.update({k: v.clone() for k, v in cam.items()})
+        lines, lo, hi = src[kind]
+        block = textwrap.dedent('\n'.join(lines[lo:hi]))
+        ns = {'np': np, 'torch': torch, 'print': lambda *a, **k: None, 'args': args,
+              'dist_util': types.SimpleNamespace(dev=lambda: torch.device('cpu')),
+              'test_batch_traj': {k: v.clone() for k, v in bt.items()}, 'test_batch_pose': tbp,
+              'test_traj_dataset': tds, 'test_pose_dataset': pds,
+              'diffusion_trajnet_eval': Rec(d_t, 'traj'), 'diffusion_trajnet_control_eval': Rec(d_c, 'traj'),
+              'diffusion_posenet_eval': d_p,
+              'model_trajnet': tn, 'model_trajnet_control': cn, 'model_posenet': pn, 'smplx_neutral': body,
+              'REPR_LIST': ref.other_utils.REPR_LIST, 'REPR_DIM_DICT': ref.other_utils.REPR_DIM_DICT,
+              'recover_from_repr_smpl': ref.motion_repr.recover_from_repr_smpl, 'get_repr_smplx': ref.motion_repr.get_repr_smplx,
+              'rot6d_to_rotmat': ref.quaternion.rot6d_to_rotmat, 'rotation_matrix_to_angle_axis': ref.konia.rotation_matrix_to_angle_axis}
+        import time
+        t0 = time.time()
+        torch.manual_seed(SCHEME_REAL_SEEDS['noise'] + ci)
+        exec(compile(block, f'{kind}[{lo + 1}:{hi}]', 'exec'), ns)
+        pre = f'case{ci}_'
+        final_pose = ns['val_output_pose' if kind == 'amass' else 'val_output_joint']
+        out[pre + 'pose'] = final_pose.numpy()
+        out[pre + 'traj'] = ns['val_output_traj'].numpy()
+        out[pre + 'traj_rec_full'] = ns['traj_rec_full'].numpy()
+        out[pre + 'n_stages'] = len(stage_out)
+        for k, (name, v) in enumerate(stage_out):
+            out[pre + f'stage{k}_name'] = name
+            out[pre + f'stage{k}_out'] = v.numpy()
+        assert [n for n, _ in stage_out] == [p[0] for p in plan]
+        print('scheme_real case', ci, kind, kw, pose_steps, [n for n, _ in stage_out], 'max|pose|', float(final_pose.abs().max()),
+              'max|traj|', float(ns['val_output_traj'].abs().max()), f'{time.time() - t0:.1f}s')
+    np.savez_compressed(os.path.join(OUT, 'scheme_real.npz'), n_cases=len(SCHEME_REAL_CASES),
+                        **{k + '_seed': v for k, v in SCHEME_REAL_SEEDS.items()}, **out)
+    print('scheme_real.npz', os.path.getsize(os.path.join(OUT, 'scheme_real.npz')))
 
 
 def frames_inputs(seed=0, N=40):
@@ -503,6 +666,10 @@ def main():
     if sys.argv[1:] == ['scheme']:
         warnings.filterwarnings('ignore')
         return golden_scheme(refload.load())
+    if sys.argv[1:] == ['scheme_real']:
+        warnings.filterwarnings('ignore')
+        torch.set_num_threads(8)
+        return golden_scheme_real(refload.load())
     if sys.argv[1:] == ['guided_step']:
         warnings.filterwarnings('ignore')
         return golden_guided_step(refload.load())
@@ -603,6 +770,7 @@ def main():
     golden_eval_losses(ref)
     golden_guided_step(ref)
     golden_scheme(ref)
+    golden_scheme_real(ref)
     golden_frames(ref)
     golden_control_loop(ref)
     golden_posenet_loop1000(ref)

@@ -59,11 +59,19 @@ def occlusion_mask(cond, scheme, traj_feat_dim, start=None, end=None):
     return cond
 
 
-def oracle_stages(sd_traj, sd_ctrl, sd_pose, tab_traj, tab_pose, idx_traj, idx_pose, stats_pose, body, args, noise):
+def oracle_stages(sd_traj, sd_ctrl, sd_pose, tab_traj, tab_pose, idx_traj, idx_pose, stats_pose, body, args, noise,
+                  grad_type='amass', camera=None):
     """Stage callables running the oracle networks + sampler: noise['traj'][it] / noise['pose'][it] =
-    (x_T, [step noises])."""
+    (x_T, [step noises]).  `grad_type` is what the driver passes to PoseNet's eval_losses ('amass':
+    test_amass_full.py:383, 'prox': test_prox_egobody.py:323); 'prox' needs `camera` = the batch entries
+    guide_2d_projection_with_smpl reads + cam_R / cam_t of the dataset.  `idx_pose` is the list of PoseNet timesteps as the
+    sampler would visit them; `early_stop` cuts it to its first 980 entries (gaussian_diffusion_posenet.py:625-626)."""
     mean_p, std_p = (torch.as_tensor(v) for v in stats_pose)
     guidance = {'skating': lambda x0, i: G.guide_skating(x0, mean_p, std_p, body)}
+    if camera is not None:
+        guidance['2d'] = lambda x0, i: G.guide_2d_projection(
+            x0, mean_p, std_p, body, camera['transf_matrix'], camera['focal_length'], camera['camera_center'],
+            camera['keypoints_2d'], torch.as_tensor(camera['cam_R']), torch.as_tensor(camera['cam_t']))
 
     def traj_stage(it, batch):
         cond, B = batch['cond'], batch['cond'].shape[0]
@@ -79,7 +87,7 @@ def oracle_stages(sd_traj, sd_ctrl, sd_pose, tab_traj, tab_pose, idx_traj, idx_p
         with torch.no_grad():
             return D.p_sample_loop(fn, noise['pose'][it][0], noise['pose'][it][1], tab_pose,
                                    idx_pose[:980] if args.early_stop else idx_pose, guidance=guidance,
-                                   grad_type='amass' if args.cond_fn_with_grad else None, early_stop=args.early_stop)
+                                   grad_type=grad_type if args.cond_fn_with_grad else None, early_stop=args.early_stop)
     return traj_stage, pose_stage
 
 

@@ -37,6 +37,25 @@ def cpu_noise_sequence(torch_seed, shape, steps, trajnet_layout=False):
     return x_T, out
 
 
+def cpu_noise_stream(torch_seed, plan):
+    """The draws of a whole free-running scheme from ONE seeded global generator, stage after stage, as the reference makes
+    them: `plan` = [(kind, shape, steps), ...] with kind 'traj' (TrajNet's permuted-view randn_like, see
+    cpu_noise_sequence) or 'pose'.  Returns {'traj': [(x_T, [noise]) per stage], 'pose': [...]}."""
+    torch.manual_seed(torch_seed)
+    runs = {'traj': [], 'pose': []}
+    for kind, shape, steps in plan:
+        x_T = torch.randn(*shape)
+        out = []
+        for k in range(steps):
+            if kind == 'traj' and k > 0:
+                B, T, Cc = shape
+                out.append(torch.randn_like(torch.empty(B, Cc, T).permute(0, 2, 1)))
+            else:
+                out.append(torch.randn(*shape))
+        runs[kind].append((x_T, out))
+    return runs
+
+
 class PoseDataset:
     """Minimal stand-in for the attributes PoseNet reads from its dataset (posenet.py:207,210,289,296)."""
     pose_feat_dim = 272

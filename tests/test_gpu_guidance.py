@@ -339,4 +339,6 @@ def test_free_running_guided_head_vs_reference_golden():
         t = torch.full((2,), i, device=DEV, dtype=torch.int64)
         xx = diff.p_sample_with_grad(net, batch, xx, t, clip_denoised=False, grad_type='prox')['sample']
     ref = torch.from_numpy(g['sample'])
-    assert max_abs(xx.cpu(), ref) < 2e-3 * float(ref.abs().max())
+    err = max_abs(xx.cpu(), ref)
+    print(f'\nfree-running guided head t = 103..97: max|HIP - reference| = {err:.3e} on max|x| = {float(ref.abs().max()):.1f}')
+    assert err < 2e-3 * float(ref.abs().max())

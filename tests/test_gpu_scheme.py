@@ -285,8 +285,8 @@ def test_glue_vs_reference_script_golden(ci):
     while test_amass_full.py:217-384 / test_prox_egobody.py:214-324 were executed with stub samplers): every tensor
     handed to a stage, the re-derived trajectory and the dict entries the scripts use afterwards."""
     from helpers import golden
-    from oracle.make_golden import SCHEME_CASES, digest, scheme_case
-    from test_scheme_oracle import close
+    from oracle.make_golden import SCHEME_CASES, digest, exact_hash, scheme_case
+    from test_scheme_oracle import check_full_entries, close
     from rohm_amd import inference as INF
     from rohm_amd.body_model import SMPLXLayer
     g = golden('scheme.npz')
@@ -309,14 +309,195 @@ def test_glue_vs_reference_script_golden(ci):
     else:
         _, _, recs = INF.run_prox_iterations(args, models, diffs, gbt, gbp, tds, pds, layer)
     assert len(glog) == int(g[pre + 'n_calls'])
+    from test_gpu_rederive import _close
+    body = G.BodyModel(body_t)
+    carrier = bt['motion_repr_clean' if kind == 'amass' else 'motion_repr_noisy']
+
+    def joints_of(it):           # joints of the representation iteration `it` re-derives its trajectory from
+        rec = OS.merge_traj(carrier, traj_out[it], args.repr_abs_only, tfd)
+        return G.joints_from_smplx(G.split_repr(torch.from_numpy((rec.numpy() * s_traj[1] + s_traj[0]).astype(np.float32))),
+                                   body).numpy()
+    n_pose = 0
     for k, (name, tens) in enumerate(glog):
         assert name == str(g[pre + f'call{k}_name'])
         assert set(tens) == {kk for kk in ('cond', 'control_cond') if pre + f'call{k}_{kk}' in g}, (k, name)
         for kk, v in tens.items():
             assert list(v.shape) == list(g[pre + f'call{k}_{kk}_shape']), (k, kk)
             assert close(digest(v), g[pre + f'call{k}_{kk}'], tol=2e-5), (k, name, kk)
+            # element-wise: computed parts in full (conditioning-aware on the facing channels), copies bit-exactly
+            untouched = kind == 'amass' and args.mask_scheme == 'lower' and not args.input_noise     # :333: traj not replaced
+            jt = None if untouched else joints_of(n_pose)
+            check_full_entries(g, pre + f'call{k}_{kk}', kk, v,
+                               traj_check=None if untouched else (lambda a, b, jt=jt: _close(a.numpy(), b.numpy(), jt)))
+        n_pose += name == 'pose'
     assert close(digest(recs[-1]), g[pre + 'traj_rec_full'], tol=2e-5)
+    _close(recs[-1].cpu().numpy(), g[pre + 'traj_rec_full_full'], joints_of(args.sample_iter - 1))
     assert close(digest(gbt['motion_repr_noisy']), g[pre + 'after_traj_noisy'], tol=2e-5)
+    assert exact_hash(gbt['motion_repr_noisy']) == str(g[pre + 'after_traj_noisy_sha'])
     assert close(digest(gbt['cond']), g[pre + 'after_traj_cond'], tol=2e-5)
+    assert max_abs(gbt['cond'].cpu(), torch.from_numpy(g[pre + 'after_traj_cond_full'])) == 0.0
     assert list(gbp['motion_repr_noisy'].shape) == list(g[pre + 'after_pose_noisy_shape'])
     assert list(gbp['motion_repr_clean'].shape) == list(g[pre + 'after_pose_clean_shape'])
+
+
+def _real_models(B, s_pose, body_t, seeds, cam_t=None):
+    """HIP TrajNet / TrajControl / PoseNet with the synthetic weights of `seeds` + their datasets."""
+    from test_gpu_trajnet import make_trajnet
+    from rohm_amd.body_model import SMPLXLayer
+    from rohm_amd.model.posenet import PoseNet
+    layer = SMPLXLayer.from_tensors(body_t).to(DEV)
+    tnet, sd_t = make_trajnet(seeds['trajnet'], False)
+    cnet, sd_c = make_trajnet(seeds['control'], True)
+    pds = PoseDataset(*s_pose)
+    pds.cam_R = torch.tensor(synth.SYNTH_CAM_R)
+    pds.cam_t = torch.tensor(cam_t if cam_t is not None else synth.SYNTH_CAM_T)
+    pnet = PoseNet(pds, 294, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, traj_feat_dim=22,
+                   body_model_path=layer, device=DEV)
+    sd_p = synth.posenet_state_dict(seeds['posenet'])
+    pnet.load_state_dict(sd_p, strict=False)
+    return layer, {'trajnet': tnet, 'trajnet_control': cnet, 'posenet': pnet.to(DEV).eval()}, (sd_t, sd_c, sd_p), pds
+
+
+def _diffusions(S_T, S_P, noise, log=None):
+    from test_gpu_trajnet import Args
+    from rohm_amd.diffusion import gaussian_diffusion_posenet as gdp
+    from rohm_amd.diffusion import gaussian_diffusion_trajnet as gdt
+    from rohm_amd.diffusion.respace import SpacedDiffusionPoseNet, SpacedDiffusionTrajNet
+    from rohm_amd.utils.model_util import create_gaussian_diffusion
+    d_t = create_gaussian_diffusion(Args, gdt, SpacedDiffusionTrajNet, S_T, '', device=DEV)
+    d_c = create_gaussian_diffusion(Args, gdt, SpacedDiffusionTrajNet, S_T, '', device=DEV)
+    d_p = create_gaussian_diffusion(Args, gdp, SpacedDiffusionPoseNet, S_P, '', device=DEV)
+    d_t.noise_source = NoiseFeed(noise['traj'][:1])
+    d_c.noise_source = NoiseFeed(noise['traj'][1:])
+    d_p.noise_source = NoiseFeed(noise['pose'])
+    if log is None:
+        return {'trajnet': d_t, 'trajnet_control': d_c, 'posenet': d_p}, d_p
+    return {'trajnet': Recording(d_t, log, 'traj'), 'trajnet_control': Recording(d_c, log, 'traj'),
+            'posenet': Recording(d_p, log, 'pose')}, d_p
+
+
+@pytest.mark.parametrize('ci', range(3))
+def test_free_running_scheme_vs_reference_golden(ci):
+    """BASELINE configs[2] / [4] end to end, FREE-RUNNING, against the reference itself: tests/golden/scheme_real.npz holds
+    what test_amass_full.py:217-384 / test_prox_egobody.py:214-324 (the scripts' own text) produced with the reference's own
+    TrajNet / TrajControl / PoseNet and samplers on CPU (B = 2; AMASS two iterations; PROX three iterations with the
+    visibility mask and early_stop; PROX two iterations whose PoseNet stage is the reference's guided step over t = 103..99
+    at its own weights).  Here rohm_amd.inference runs the same thing on the HIP networks with the same noise stream --
+    TrajNet -> rohm_traj_rederive -> PoseNet -> TrajControl -> PoseNet [...] without teacher forcing.  Bar: 1e-3 (north star)."""
+    from helpers import cpu_noise_stream, golden
+    from oracle.make_golden import (SCHEME_REAL_CAM_T, SCHEME_REAL_CASES, SCHEME_REAL_HEAD_T, SCHEME_REAL_SEEDS,
+                                    scheme_real_case)
+    from rohm_amd import inference as INF
+    g = golden('scheme_real.npz')
+    kind, kw, pose_steps = SCHEME_REAL_CASES[ci]
+    args, tfd, body_t, s_traj, s_pose, bt, bp, cam, _, plan = scheme_real_case(ci)
+    B = 2
+    noise = cpu_noise_stream(SCHEME_REAL_SEEDS['noise'] + ci, plan)
+    layer, models, _, pds = _real_models(B, s_pose, body_t, SCHEME_REAL_SEEDS, cam_t=SCHEME_REAL_CAM_T)
+    log = []
+    head = pose_steps == 'head'
+    diffs, d_p = _diffusions(100, 1000 if head else pose_steps, noise, log)
+    if head:
+        d_p._indices = lambda skip=0, early_stop=False: list(SCHEME_REAL_HEAD_T)
+    tds = TrajDataset(*s_traj)
+    gbp = _clone(bp, DEV)
+    gbp.update({k: v.to(DEV) for k, v in cam.items()})
+    fn = INF.run_amass_iterations if kind == 'amass' else INF.run_prox_iterations
+    pose, traj, recs = fn(args, models, diffs, _clone(bt, DEV), gbp, tds, pds, layer)
+    pre = f'case{ci}_'
+    assert len(log) == int(g[pre + 'n_stages'])
+    errs = [max_abs(o, torch.from_numpy(g[pre + f'stage{k}_out'])) for k, (_, _, o) in enumerate(log)]
+    e_pose, e_traj = max_abs(pose.cpu(), torch.from_numpy(g[pre + 'pose'])), max_abs(traj.cpu(), torch.from_numpy(g[pre + 'traj']))
+    e_rec = max_abs(recs[-1].cpu(), torch.from_numpy(g[pre + 'traj_rec_full']))
+    print(f'\nfree-running scheme case {ci} ({kind}, PoseNet {pose_steps}): per-stage max|HIP - reference| =',
+          ['%.2e' % e for e in errs], f'final pose {e_pose:.2e} traj {e_traj:.2e} traj_rec_full {e_rec:.2e}')
+    assert [n for n, _, _ in log] == [str(g[pre + f'stage{k}_name']) for k in range(len(log))]
+    assert e_traj < 1e-3 and e_rec < 1e-3 and e_pose < 1e-3, errs
+    # joints of the final result (the metric's "MPJPE vs ref"), through the oracle body model
+    den = lambda y: torch.from_numpy(y[:, :, 0].transpose(0, 2, 1) * s_pose[1] + s_pose[0])
+    body = G.BodyModel(body_t)
+    j_hip = G.joints_from_smplx(G.split_repr(den(pose.cpu().numpy())), body)
+    j_ref = G.joints_from_smplx(G.split_repr(den(g[pre + 'pose'])), body)
+    mpjpe_mm = float((j_hip - j_ref).norm(dim=-1).mean()) * 1000
+    print(f'MPJPE vs reference {mpjpe_mm:.5f} mm')
+    assert mpjpe_mm < 1.0
+
+
+def test_prox_real_networks_teacher_forced(monkeypatch):
+    """BASELINE configs[4] (test_prox_egobody.py:214-324) with the real HIP networks: sample_iter = 3 (TrajControl from
+    iteration 1), early_stop, 80 % visibility mask, grad_type = 'prox' with the 2-D and skating terms both live -- every
+    stage re-run by the oracle from the inputs the HIP stage received (1e-3), and the oracle glue fed with the HIP stages'
+    outputs must hand every stage the inputs the HIP run did.  Weights turned down on BOTH sides (see
+    test_real_networks_teacher_forced): this pins the composite's logic; the reference's own weights are pinned step by
+    step (guided_step.npz) and free-running over the stable head (scheme_real.npz case 2)."""
+    from oracle.make_golden import SCHEME_REAL_CAM_T, scheme_case
+    from rohm_amd import inference as INF
+    from rohm_amd.diffusion import ddpm
+    monkeypatch.setitem(ddpm.GUIDANCE, 'prox', (100, (('guide_2d_projection_with_smpl', 30.0), ('guide_skating_with_smpl', 1.0))))
+    monkeypatch.setitem(odiff.GUIDANCE, 'prox', (100, (('2d', 30.0), ('skating', 1.0))))
+    args, tfd, body_t, s_traj, s_pose, bt, bp, _, _ = scheme_case('prox', dict(sample_iter=3, cond_fn_with_grad=True))
+    assert args.early_stop and not args.iter2_cond_noisy_pose
+    B, S_T, S_P = 2, 100, 16
+    cam = synth.synthetic_camera_batch(4, B)
+    seeds = dict(trajnet=81, control=82, posenet=83)
+    layer, models, (sd_t, sd_c, sd_p), pds = _real_models(B, s_pose, body_t, seeds, cam_t=SCHEME_REAL_CAM_T)
+    nz_t = [cpu_noise_sequence(300 + i, (B, 144, 13), S_T) for i in range(3)]
+    nz_p = [cpu_noise_sequence(400 + i, (B, 294, 1, 143), S_P) for i in range(3)]
+    noise = {'traj': nz_t, 'pose': nz_p}
+    log = []
+    diffs, _ = _diffusions(S_T, S_P, noise, log)
+    # _diffusions feeds the first TrajNet run to 'trajnet' and the rest to 'trajnet_control'
+    gbp = _clone(bp, DEV)
+    gbp.update({k: v.to(DEV) for k, v in cam.items()})
+    pose, traj, recs = INF.run_prox_iterations(args, models, diffs, _clone(bt, DEV), gbp, TrajDataset(*s_traj), pds, layer)
+    assert [n for n, _, _ in log] == ['traj', 'pose'] * 3
+    assert torch.isfinite(pose).all() and pose.shape == (B, 294, 1, 143)
+    body = G.BodyModel(body_t)
+    camera = dict(cam, cam_R=synth.SYNTH_CAM_R, cam_t=SCHEME_REAL_CAM_T)
+    o_traj, o_pose = OS.oracle_stages(sd_t, sd_c, sd_p, odiff.tables(odiff.cosine_betas(S_T)),
+                                      odiff.tables(odiff.cosine_betas(S_P)), list(range(S_T))[::-1],
+                                      list(range(S_P))[::-1], s_pose, body, args, noise, grad_type='prox', camera=camera)
+    k = {'traj': 0, 'pose': 0}
+    errs = []
+    for name, rec_in, rec_out in log:
+        it = k[name]
+        k[name] += 1
+        ref = (o_traj if name == 'traj' else o_pose)(it, rec_in)
+        errs.append(max_abs(rec_out, ref))
+    print('\nprox composite, per-stage max|HIP - oracle| (teacher-forced) =', ['%.2e' % e for e in errs])
+    assert max(errs) < 1e-3, errs
+    # guidance really acted: the same PoseNet stage without guidance differs
+    args_free = types.SimpleNamespace(**{**vars(args), 'cond_fn_with_grad': False})
+    _, o_pose_free = OS.oracle_stages(sd_t, sd_c, sd_p, odiff.tables(odiff.cosine_betas(S_T)),
+                                      odiff.tables(odiff.cosine_betas(S_P)), list(range(S_T))[::-1],
+                                      list(range(S_P))[::-1], s_pose, body, args_free, noise)
+    assert max_abs(log[1][2], o_pose_free(0, log[1][1])) > 1e-2
+    # the glue
+    outs = {'traj': [o for n, _, o in log if n == 'traj'], 'pose': [o for n, _, o in log if n == 'pose']}
+    ins = {'traj': [], 'pose': []}
+
+    def f_traj(it, batch):
+        ins['traj'].append({kk: batch[kk].clone() for kk in ('cond', 'control_cond') if kk in batch})
+        return outs['traj'][it].clone()
+
+    def f_pose(it, batch):
+        ins['pose'].append({'cond': batch['cond'].clone()})
+        return outs['pose'][it].clone()
+    _, _, ref_recs = OS.prox_iterations(f_traj, f_pose, _clone(bt), _clone(bp), s_traj, s_pose, body, args)
+    from test_gpu_rederive import _close
+    k = {'traj': 0, 'pose': 0}
+    for name, rec_in, _ in log:
+        ref_in = ins[name][k[name]]
+        k[name] += 1
+        assert rec_in.keys() == ref_in.keys()
+        for kk in rec_in:
+            if name == 'pose':
+                a, b = rec_in[kk][:, :, 0].permute(0, 2, 1), ref_in[kk][:, :, 0].permute(0, 2, 1)
+                assert max_abs(a[:, :, 22:], b[:, :, 22:].float()) < 1e-6
+            else:
+                assert max_abs(rec_in[kk], ref_in[kk].float()) < 1e-6, (name, kk)
+    for it, (a, b) in enumerate(zip(recs, ref_recs)):
+        rec_repr = OS.merge_traj(bt['motion_repr_noisy'], outs['traj'][it], True, 13)     # same 13 channels every iteration
+        den = rec_repr.numpy() * s_traj[1] + s_traj[0]
+        joints = G.joints_from_smplx(G.split_repr(torch.from_numpy(den)), body).numpy()
+        _close(a.cpu().numpy(), b.numpy(), joints)
