@@ -76,6 +76,8 @@ enum GemmEpi {
     EPI_QKV = 3,         // C = (acc + bias[n]) * (n < qcols ? qscale : 1)
     EPI_EMBED = 4,       // token-major embed: tok = m % S; tok==0 ? tab0[m/S][n] : acc + tab[tok][n]
     EPI_OUT_T = 5,       // transposed store of the output head (see posenet.hip)
+    EPI_BIAS_RES_LN = 6, // C = LayerNorm(acc + bias[n] + R[m][n]) * gamma[n] + beta[n]: the row statistics are exchanged between the
+                         // column tiles of a row tile through L2 while the kernel runs (xln_* below)
 };
 
 struct GemmParams {
@@ -122,7 +124,21 @@ struct GemmParams {
     const float* r_stats; int r_parts; const float* r_gamma; const float* r_beta;
     float* out_stats; int out_parts;
     int ln_dim; float ln_eps;
+    // ---- LayerNorm INSIDE the producer (EPI_BIAS_RES_LN; post-norm nn.TransformerEncoderLayer, model/posenet.py:63-69:
+    // x = norm(x + sublayer(x))).  The N / BN column tiles of a row tile run at the same time on CUs of ONE XCD (the kernel's own
+    // block -> tile map), each writes its 144 per-row (sum, sum of squares) pairs to xln_stats[row tile][column tile][144][2],
+    // counts itself in xln_flags[row tile][0], waits until all column tiles have, sums the pairs in column-tile order (every tile
+    // gets bit-identical statistics), normalises its accumulators in registers and stores LN(x) once.  xln_flags ([tiles_m][2]
+    // arrive / depart counters) must be zero before the first launch (the last tile to leave resets them); *xln_err is set
+    // if a wait ran into its bound (never on a healthy device: the partner tiles are co-resident by construction).
+    const float* ln_gamma; const float* ln_beta;
+    float* xln_stats; unsigned* xln_flags; unsigned* xln_err;
 };
+// EPI_BIAS_RES_LN: can launch_gemm run (M, N, ...) with the in-kernel LayerNorm?  Scratch = stats + flags + error word.
+bool gemm_ln_supported(int M, int N, int K);
+size_t gemm_ln_scratch_bytes(int M, int N);
+size_t gemm_ln_zero_bytes(int M);                 // leading part of the scratch (error word + counters) to clear before first use
+void gemm_ln_bind(GemmParams& p, void* scratch);  // fills xln_* from a scratch block (p.M must be set)
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 #ifdef __HIPCC__

@@ -127,9 +127,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int tiles_m = (p.M + BM - 1) / BM;
     const int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
     const int split = (ksplit > 1) ? (int)(blockIdx.x % ksplit) : 0;
-    const int tile = xcd_remap(ksplit > 1 ? blockIdx.x / ksplit : blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
+    int m0, n0;
+    if constexpr (EPI == EPI_BIAS_RES_LN) {
+        // The tiles_n column tiles of a row tile exchange their row statistics while they run, so they must sit on ONE XCD (one
+        // L2: the exchange never leaves it) and be handed out back to back (co-resident: nobody waits for a tile that cannot
+        // start).  Hardware places block b on XCD b % 8 in block order, so the j-th block of XCD x takes column tile
+        // j % tiles_n of row tile (j / tiles_n) * 8 + x; the launch rounds tiles_m up to a multiple of 8, the surplus leaves.
+        const int x = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+        const int g = (j / tiles_n) * kNumXCD + x;
+        if (g >= tiles_m) return;
+        m0 = g * BM;
+        n0 = (j % tiles_n) * BN;
+    } else {
+        const int tile = xcd_remap(ksplit > 1 ? blockIdx.x / ksplit : blockIdx.x, tiles_m * tiles_n);
+        m0 = (tile / tiles_n) * BM;
+        n0 = (tile % tiles_n) * BN;
+    }
 
     // ---- global -> LDS staging by LDS-DMA ---------------------------------------------------------------------
     const float* a_src[A_ITERS];
@@ -359,7 +372,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // and store.
     struct ColOps { f32x4 bias, c4, g4, b4; };      // what depends on the column group only
     // (not where it would spill: the 384-wide tile keeps 216 accumulators per lane; its QKV form fits, 475 VGPRs)
-    constexpr bool PRE = !(BN >= 384 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_EMBED));
+    constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_LN);      // epilogues that add R[m][n]
+    constexpr bool PRE = !(BN >= 384 && (EPI == EPI_BIAS || RES || EPI == EPI_EMBED));
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto load_col = [&](int nb) __attribute__((always_inline)) {
         ColOps o{zero4, zero4, zero4, zero4};
@@ -387,6 +401,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     if (nb + q < p.N) { o.g4[q] = p.r_gamma[nb + q]; o.b4[q] = p.r_beta[nb + q]; }
             }
         }
+        if constexpr (EPI == EPI_BIAS_RES_LN) {      // FULL only: the affine part of the LayerNorm this epilogue applies
+            o.g4 = *reinterpret_cast<const f32x4*>(p.ln_gamma + nb);
+            o.b4 = *reinterpret_cast<const f32x4*>(p.ln_beta + nb);
+        }
         return o;
     };
     auto load_res = [&](int m, int nb) __attribute__((always_inline)) {
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     if (nb + q < p.N) rr[q] = tp[q];
             }
         }
-        if constexpr (EPI == EPI_BIAS_RES) {
+        if constexpr (RES) {
             if (!FULL && (m >= p.M || nb >= p.N)) return rr;
             const float* rp = p.R + (size_t)m * p.ldr + nb;
             if (FULL || (vec_ok && (p.ldr % 4 == 0) && (((uintptr_t)p.R & 15) == 0))) {
@@ -505,7 +523,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     };
     // EARLY: the operands are requested at the top of the LAST chunk's iteration and land under its MFMAs (2 us of them); the
     // 384-wide tile has no registers to spare during the loop and requests them behind it.
-    constexpr bool HAS_RES = (EPI == EPI_BIAS_RES || EPI == EPI_EMBED);      // a per-unit operand besides the column operands
+    constexpr bool HAS_RES = (RES || EPI == EPI_EMBED);      // a per-unit operand besides the column operands
     constexpr bool PEEL = BN <= 256;
     constexpr bool EARLY = PRE && PEEL && FULL && EPI != EPI_OUT_T && !(BN >= 256 && HAS_RES);
     ColOps col[PRE ? NCG : 1];
@@ -581,7 +599,108 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------------
-    if constexpr (EPI == EPI_OUT_T) {
+    if constexpr (EPI == EPI_BIAS_RES_LN) {
+        // C = LayerNorm(acc + bias + R): see GemmParams::xln_*.  FULL, 16x16 layouts (BN <= 128) only -- the launcher sees to it.
+        static_assert(!M32 && !CONV && FULL && PRE, "EPI_BIAS_RES_LN: 144 x 64 / 144 x 128 tiles of whole problems only");
+        if constexpr (!EARLY) request_ops();
+        // 1. x = (acc + bias) + R in the accumulator registers (the order of the un-fused path); per-row partial sums
+        float ps[NRB], pq[NRB];
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) { ps[r] = 0.f; pq[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int r = 0; r < NRB; ++r) {
+                f32x4& a = acc16[r * NCB + c];
+                const f32x4 rr = res[c * NRB + r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = (a[q] + col[c].bias[q]) + rr[q];
+                    ps[r] += a[q];
+                    pq[r] += a[q] * a[q];
+                }
+            }
+        // 2. a row's columns of this wave live in the 4 lanes li + 16 lg: two lane swaps (VALU, no LDS crossbar), then the 4 waves
+        //    meet in LDS
+        typedef unsigned rohm_u2 __attribute__((ext_vector_type(2)));
+        auto lg_sum = [](float v) __attribute__((always_inline)) {
+            rohm_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+            t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        };
+        float* part = lds_dummy + 512;                  // [4 waves][BM][2]; afterwards [BM][2] = (mu, rstd)
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const float a = lg_sum(ps[r]), b = lg_sum(pq[r]);
+            if (lg == 0) *reinterpret_cast<f32x2*>(part + (wave * BM + r * 16 + li) * 2) = f32x2{a, b};
+        }
+        __syncthreads();
+        const int g = m0 / BM, tn = n0 / BN;
+        float* const tile_stats = p.xln_stats + (size_t)g * tiles_n * (BM * 2);
+        if (tid < BM) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const f32x2 v = *reinterpret_cast<const f32x2*>(part + (w * BM + tid) * 2); a += v[0]; b += v[1]; }
+            *reinterpret_cast<f32x2*>(tile_stats + ((size_t)tn * BM + tid) * 2) = f32x2{a, b};
+        }
+        // 3. the statistics are in L2 (vmcnt(0) = acknowledged) before this tile counts itself; then wait for the partner tiles
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* const fl = p.xln_flags + 2 * g;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int it = 0;
+            while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_n) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++it > (1 << 19)) {                 // ~0.2 s: never on a healthy device; do not hang the GPU
+                    __hip_atomic_store(p.xln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        // 4. all column tiles' pairs of a row, summed in column-tile order (bit-identical in every tile); read past the L1
+        if (tid < BM) {
+            unsigned long long raw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                raw[k] = (k < tiles_n) ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(tile_stats + ((size_t)k * BM + tid) * 2),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0ull;
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sm += __uint_as_float((unsigned)(raw[k] & 0xffffffffull));
+                sq += __uint_as_float((unsigned)(raw[k] >> 32));
+            }
+            const float inv = 1.0f / (float)p.ln_dim;
+            const float mu = sm * inv;
+            const float var = fmaxf(sq * inv - mu * mu, 0.f);
+            *reinterpret_cast<f32x2*>(part + tid * 2) = f32x2{mu, 1.0f / sqrtf(var + p.ln_eps)};
+        }
+        __syncthreads();
+        if (tid == 0) {      // the last tile to have read the pairs re-arms the counters for the next launch on this stream
+            const unsigned old = __hip_atomic_fetch_add(fl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)tiles_n - 1u) {
+                __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // 5. normalise in registers, store LN(x) once
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const f32x2 mr = *reinterpret_cast<const f32x2*>(part + (r * 16 + li) * 2);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const f32x4 a = acc16[r * NCB + c];
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (a[q] - mr[0]) * mr[1] * col[c].g4[q] + col[c].b4[q];
+                *reinterpret_cast<f32x4*>(p.C + (size_t)(m0 + r * 16 + li) * p.ldc + nw + c * 16 + lg * 4) = v;
+            }
+        }
+    } else if constexpr (EPI == EPI_OUT_T) {
         // natural operand order: rows = output channels m, cols = tokens n; stored transposed into [B, C_total, 1, T]
         // LN fold: the normalised operand is the token (column) side; a lane's columns are fixed per column block
         constexpr int NCOL = M32 ? NCB32 + NCB : NCB;
@@ -743,7 +862,9 @@ static constexpr int gemm_variant() { return 0; }
 template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 static int launch_one(const GemmParams& p, hipStream_t s) {
     const int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * ksplit;
+    int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * ksplit;
+    if (EPI == EPI_BIAS_RES_LN)      // row tiles dealt round-robin to the XCDs, rounded up to a multiple of 8 (the kernel's own map)
+        tiles = (((p.M + BM - 1) / BM + kNumXCD - 1) / kNumXCD) * kNumXCD * ((p.N + BN - 1) / BN);
 #ifdef ROHM_GEMM_DIAGNOSTICS
     static const int lds_pad = diag_env_int("ROHM_GEMM_LDS_PAD", 0);
     static const bool occ2 = getenv("ROHM_GEMM_OCC2") != nullptr;      // allow two workgroups per CU
@@ -770,9 +891,9 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
         attr_set[dev] = true;
     }
     static const char* const kNames[] = {"gemm_bias", "gemm_bias_gelu", "gemm_bias_res", "gemm_qkv", "gemm_embed",
-                                         "gemm_out_t"};
+                                         "gemm_out_t", "gemm_bias_res_ln"};
     static const char* const kNames64[] = {"gemm_bias/64", "gemm_bias_gelu/64", "gemm_bias_res/64", "gemm_qkv/64",
-                                           "gemm_embed/64", "gemm_out_t/64"};
+                                           "gemm_embed/64", "gemm_out_t/64", "gemm_bias_res_ln/64"};
     const char* label = CONV ? (BN == 64 ? "conv_gemm/64" : "conv_gemm") : (BN == 64 ? kNames64[EPI] : kNames[EPI]);
     if (prof::detail()) {
         char buf[48];
@@ -884,6 +1005,46 @@ static int launch_bn(const GemmParams& p, hipStream_t s) {
     return launch_t<64, EPI>(p, s);
 }
 
+// ---- EPI_BIAS_RES_LN: LayerNorm inside the producer GEMM --------------------------------------------------------------------
+// Tile width: 144 x 128 while that still gives every CU a tile, else 144 x 64; the N / BN column tiles of a row tile exchange
+// statistics, so there may be 1, 2, 4 or 8 of them (a divisor of the 32 CUs of an XCD: partner tiles are dispatched back to back
+// onto one XCD and never straddle a round of workgroups).
+static int ln_tile_width(int tm, int N) {
+    auto ok = [&](int bn) { const int t = N / bn; return N % bn == 0 && t >= 1 && t <= 8 && 32 % t == 0; };
+    if (ok(128) && (long)tm * (N / 128) >= target_wgs()) return 128;
+    if (ok(64)) return 64;
+    if (ok(128)) return 128;
+    return 0;
+}
+
+bool gemm_ln_supported(int M, int N, int K) {
+    return M > 0 && M % BM == 0 && K > 0 && K % BK == 0 && N > 0 && ln_tile_width(M / BM, N) != 0;
+}
+
+// scratch layout: [error word, 64 B] [flags: tiles_m x 2 words, padded to 64 B] [statistics: tiles_m x 8 x 144 x 2 floats]
+static size_t ln_flag_bytes(int M) { return ((size_t)((M + BM - 1) / BM) * 2 * sizeof(unsigned) + 63) / 64 * 64; }
+size_t gemm_ln_zero_bytes(int M) { return 64 + ln_flag_bytes(M); }
+size_t gemm_ln_scratch_bytes(int M, int N) {
+    (void)N;
+    return gemm_ln_zero_bytes(M) + (size_t)((M + BM - 1) / BM) * 8 * BM * 2 * sizeof(float);
+}
+void gemm_ln_bind(GemmParams& p, void* scratch) {
+    char* c = static_cast<char*>(scratch);
+    p.xln_err = reinterpret_cast<unsigned*>(c);
+    p.xln_flags = reinterpret_cast<unsigned*>(c + 64);
+    p.xln_stats = reinterpret_cast<float*>(c + gemm_ln_zero_bytes(p.M));
+}
+
+static int launch_ln(const GemmParams& p, hipStream_t s) {
+    ROHM_ARG_CHECK(gemm_ln_supported(p.M, p.N, p.K), "gemm: shape (%d, %d, %d) has no in-kernel LayerNorm form", p.M, p.N, p.K);
+    ROHM_ARG_CHECK(p.bias && p.R && p.ln_gamma && p.ln_beta && p.xln_stats && p.xln_flags && p.xln_err, "gemm: LayerNorm epilogue: null operand");
+    ROHM_ARG_CHECK(p.ln_dim == p.N && p.ldc % 4 == 0 && p.ldr % 4 == 0 && al16(p.C) && al16(p.R) && al16(p.bias) && al16(p.ln_gamma) &&
+                       al16(p.ln_beta) && (((uintptr_t)p.xln_stats) & 15) == 0 && p.ksplit <= 1 && p.conv_taps == 0,
+                   "gemm: LayerNorm epilogue needs ln_dim == N and 16-byte aligned operands");
+    if (ln_tile_width(p.M / BM, p.N) == 128) return launch_one<128, EPI_BIAS_RES_LN, 0, true>(p, s);
+    return launch_one<64, EPI_BIAS_RES_LN, 0, true>(p, s);
+}
+
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     ROHM_ARG_CHECK(p.K > 0 && p.K % BK == 0, "gemm: K=%d must be a positive multiple of %d", p.K, BK);
     ROHM_ARG_CHECK(p.lda % 4 == 0 && p.ldw % 4 == 0, "gemm: lda/ldw must be multiples of 4 floats");
@@ -917,6 +1078,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
         case EPI_QKV: return launch_bn<EPI_QKV>(p, s);
         case EPI_EMBED: return launch_bn<EPI_EMBED>(p, s);
         case EPI_OUT_T: return launch_bn<EPI_OUT_T>(p, s);
+        case EPI_BIAS_RES_LN: return launch_ln(p, s);
     }
     set_error("gemm: unknown epilogue %d", epi);
     return ROHM_ERR_ARG;

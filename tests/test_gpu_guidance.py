@@ -323,7 +323,7 @@ def test_free_running_guided_head_vs_reference_golden():
     """A guided RUN at the reference's own weights, free-running: `p_sample_with_grad(grad_type='prox')` through the HIP kernels
     iterated on its own samples over t = 103 .. 97 (three un-guided steps, the first four guided ones with 3e5 / 1e5) against the
     reference's own free-running result (tests/golden/guided_head.npz).  The stretch ends where the reference and its restatement
-    part ways (profiles/r3_guided_chaos.txt); the samples grow from |x| ~ 5 to ~ 40 on the way, hence the relative bar."""
+    part ways (profiles/r3_guided_chaos.txt); the samples grow from |x| ~ 5 to ~ 40 on the way."""
     from oracle.make_golden import guided_step_inputs
     g = golden('guided_head.npz')
     net = _prox_net(g)
@@ -341,4 +341,4 @@ def test_free_running_guided_head_vs_reference_golden():
     ref = torch.from_numpy(g['sample'])
     err = max_abs(xx.cpu(), ref)
     print(f'\nfree-running guided head t = 103..97: max|HIP - reference| = {err:.3e} on max|x| = {float(ref.abs().max()):.1f}')
-    assert err < 2e-3 * float(ref.abs().max())
+    assert err < 5e-3          # measured 4.3e-4 on MI355X (profiles/r4_a_scheme_tests.txt); 10x that, absolute, on |x| ~ 40
