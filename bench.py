@@ -37,6 +37,9 @@ import os
 import sys
 import time
 
+# dmabuf IPC for RCCL on this driver: must be in the environment before the first HIP call of the process
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import numpy as np
 import torch
 
@@ -290,6 +293,10 @@ def scheme_bench(args, world, rank, dev, dist):
              'trajnet': create_gaussian_diffusion(_Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev),
              'trajnet_control': create_gaussian_diffusion(_Args, gdt, SpacedDiffusionTrajNet, 100, '', device=dev)}
     ego = args.workload == 'egobody'
+    if args.guidance_semantics == 'global' and dist is not None:
+        # the reference at the GLOBAL batch (model/posenet.py:231,243,309 normalise over every clip of the batch): mask counts
+        # all-reduced per guided step, the 2-D term scaled by B_local / B_global (known here: no collective for it)
+        sharding.use_global_batch_guidance(pnet, True, global_batch=world * B)
     abs_ch = [0, 2, 3, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18]
     clean_t = synth.walking_motion(1000 + rank, B, 144, *s_traj, body_t).to(dev)
     clean_p = synth.walking_motion(1000 + rank, B, 144, *s_pose, body_t).to(dev)
@@ -365,7 +372,8 @@ def scheme_bench(args, world, rank, dev, dist):
                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': wl, 'clips_per_gpu': B, 'ddpm_steps': S, 'finite_output': finite,
-                          'sharding': f'{world} x {B} independent clips' if world > 1 else 'single GPU'},
+                          'output_digest': [float(out.double().sum()), float(out.double().abs().sum())],      # rank 0's clips
+                          'sharding': sharding_note(args, world, B, dist)},
                'roofline': {'kernel': 'gemm_f32_kernel (all fp32-MFMA GEMM / conv-GEMM launches, sampled)', 'bound': 'mfma',
                             'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': None,
@@ -373,6 +381,17 @@ def scheme_bench(args, world, rank, dev, dist):
                             'kernels': kernels}}
         print(json.dumps(rec), flush=True)
     finish(world, dist)
+
+
+def sharding_note(args, world, B, dist):
+    """What `config.sharding` says: the split and WHICH guidance semantics the run had."""
+    base = f'{world} x {B} independent clips, all-gather of results only' if world > 1 else 'single GPU'
+    if args.workload == 'posenet':
+        return base
+    if args.guidance_semantics == 'global' and dist is not None:
+        return base + (f'; guidance = GLOBAL-batch semantics (the reference at batch {world * B}: skating mask counts all-reduced '
+                       'per guided step, 2-D term scaled by B_local / B_global)')
+    return base + f'; guidance = replica semantics (each rank = the reference at batch {B}, no communication)'
 
 
 def run_child(argv, env_extra=None, timeout=600):
@@ -416,9 +435,17 @@ def brief(d):
     return out
 
 
-def extras(args):
-    """`second_line` and `configs` of the N = 1 record (see the module docstring); headline first, these afterwards."""
+def extras(args, budget_s=420.0):
+    """`second_line` and `configs` of the N = 1 record (see the module docstring); headline first, these afterwards.  All children
+    together get `budget_s` of wall time: one that does not fit any more is reported as skipped, never waited for."""
     S = str(args.ddpm_steps)
+    t_start = time.perf_counter()
+
+    def child(argv, env=None):
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 20.0:
+            return {'error': f'skipped: the extras budget of {budget_s:.0f} s is spent', 'argv': list(argv)}
+        return run_child(argv, env, timeout=min(300.0, left))
     labels = {
         'fp16x3': ('opt-in ROHM_GEMM_PRECISION=fp16x3: every fp32 product of the four encoder Linears emulated by three fp16 MFMA products of '
                    'two fp16 planes (h = fp16(x), l = fp16((x - h) 2^11); cross terms in a second accumulator of weight 2^-11), fp32 '
@@ -430,8 +457,8 @@ def extras(args):
     }
 
     def line(mode):
-        sl = run_child(['--workload', 'posenet', '--batch', str(args.batch), '--ddpm-steps', S, '--steps', '2', '--warmup', '1',
-                        '--with-accuracy'], {'ROHM_GEMM_PRECISION': mode})
+        sl = child(['--workload', 'posenet', '--batch', str(args.batch), '--ddpm-steps', S, '--steps', '2', '--warmup', '1',
+                    '--with-accuracy'], {'ROHM_GEMM_PRECISION': mode})
         out = brief(sl)
         if 'error' not in sl:
             out['roofline'] = {k: sl['roofline'].get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'peak_note',
@@ -446,7 +473,7 @@ def extras(args):
     cfg = {}
     for key, argv in (('b32', ['--workload', 'posenet', '--batch', '32']), ('scheme_b32', ['--workload', 'scheme', '--batch', '32']),
                       ('prox_b32', ['--workload', 'prox', '--batch', '32']), ('egobody_b32', ['--workload', 'egobody', '--batch', '32'])):
-        cfg[key] = brief(run_child(argv + ['--ddpm-steps', S, '--steps', '1', '--warmup', '1']))
+        cfg[key] = brief(child(argv + ['--ddpm-steps', S, '--steps', '2', '--warmup', '1']))
     return second, cfg
 
 
@@ -584,6 +611,10 @@ def main(argv=None):
     ap.add_argument('--profile-stride', type=int, default=16)
     ap.add_argument('--no-extras', action='store_true', help='N = 1 only: skip the second_line / configs child measurements')
     ap.add_argument('--with-accuracy', action='store_true', help='attach the 1000-step accuracy record even without the CPU leg')
+    ap.add_argument('--guidance-semantics', choices=['replica', 'global'], default='replica',
+                    help="guided workloads under clip sharding (SURVEY.md §8(e)): 'replica' = every rank behaves like the reference at "
+                         "its LOCAL batch (no communication; default), 'global' = the reference at the GLOBAL batch (model/posenet.py:"
+                         "231,243,309): one 8-byte all-reduce of the skating mask counts per guided step")
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even at world size 1 and run barrier / all-reduce / all-gather '
                          'through it (the multi-GPU plumbing on a 1-GPU box)')
@@ -622,6 +653,9 @@ def main(argv=None):
                   body_model_path=body, device=dev)
     net.load_state_dict(synth.posenet_state_dict(0), strict=not prox)
     net = net.to(dev).eval()
+    from rohm_amd import sharding
+    if prox and args.guidance_semantics == 'global' and dist is not None:
+        sharding.use_global_batch_guidance(net, True, global_batch=world * B)
     diffusion = create_gaussian_diffusion(_Args, gdp, SpacedDiffusionPoseNet, S, '', device=dev)
     cond = synthetic_cond(B, dev, seed=1000 + rank)
     extra = {}
@@ -629,7 +663,6 @@ def main(argv=None):
         cond = synth.plausible_motion(1000 + rank, B, 143, ds.Mean, ds.Std).to(dev)
         extra = {k: v.to(dev) for k, v in synth.synthetic_camera_batch(rank, B).items()}
     torch.manual_seed(rank)
-    from rohm_amd import sharding
 
     def one_pass():
         batch = {'cond': cond, **extra}
@@ -680,12 +713,12 @@ def main(argv=None):
                                     f'[BASELINE.json configs[1]]'),
                        'guidance': 'prox [BASELINE.json configs[3]]: synthetic camera + OpenPose-style keypoints, weights as '
                                    f'the reference (3e5 / 1e5); finite_output={finite}' if prox else 'none',
-                       'clips_per_gpu': B, 'ddpm_steps': S, 'sharding': f'{world} x {B} independent clips, '
-                       'all-gather of results only' if world > 1 else 'single GPU', 'weights': 'random (seed 0)'},
+                       'clips_per_gpu': B, 'ddpm_steps': S, 'sharding': sharding_note(args, world, B, dist), 'weights': 'random (seed 0)'},
             'model_tflops': clips * S * POSENET_GFLOP_PER_CLIP_STEP * 1e-3 / elapsed,
             'roofline': {
-                'kernel': 'gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region, '
-                          f'sampled every {args.profile_stride}th denoising step)',
+                'kernel': ('gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region, ' if not _PRODUCTS else
+                           f'gemm_pp_stream_kernel / gemm_pp_kernel on {_PLANE_TYPE} planes + the fp32 embed / output-head GEMMs (all GEMM launches '
+                           'of the timed region, ') + f'sampled every {args.profile_stride}th denoising step)',
                 'bound': 'mfma', 'achieved': achieved,
                 'peak': PEAK_F32_MFMA_TFLOPS if not _PRODUCTS else PEAK_BF16_MFMA_TFLOPS / _PRODUCTS, 'unit': 'TFLOP/s',
                 'frac': (achieved / (PEAK_F32_MFMA_TFLOPS if not _PRODUCTS else PEAK_BF16_MFMA_TFLOPS / _PRODUCTS))
@@ -699,6 +732,8 @@ def main(argv=None):
                               'on random operands sustains 1.63-2.0 PFLOP/s (1.7-2.0 GHz under load, profiles/r3_g_mfma_bf16_chain_probe.txt)'),
                 'traffic': pmc_traffic()[0] if not _PRODUCTS else None, 'traffic_unit': 'bytes per launch (HBM side, PMC)',
                 'traffic_source': pmc_traffic()[1],
+                'traffic_note': 'ARCHIVED: from the most recent committed rocprofv3 PMC passes of this workload (separate, serialised runs of '
+                                'the build named by traffic_source), not collected by this run',
                 'mfma_busy_pmc': pmc_mfma(B),
                 # north_star: "... as fraction of the attention/GEMM roofline": the attention kernel by the same event timing
                 'attention': ({'achieved': prof['attention']['flops'] / (prof['attention']['total_ms'] * 1e-3) / 1e12,
@@ -720,6 +755,10 @@ def main(argv=None):
             rec['accuracy'] = accuracy_vs_reference(dev)
         if world == 1 and not args.no_extras and not prox and not _PRODUCTS:
             torch.cuda.synchronize(dev)
+            # safety copy of the headline on stderr before the child legs start (a slow or hung child can then cost the extras, never
+            # the measurement); stdout still carries exactly ONE JSON line, printed below
+            print('bench.py headline (extras follow): ' + json.dumps({k: rec[k] for k in ('metric', 'value', 'unit', 'ms_per_step')}),
+                  file=sys.stderr, flush=True)
             rec['second_line'], rec['configs'] = extras(args)
         print(json.dumps(rec), flush=True)
     finish(world, dist)

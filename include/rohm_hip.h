@@ -79,6 +79,18 @@ int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, in
 int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, int D,
                        rohm_stream_t stream);
 
+/* C = LayerNorm(A . W^T + bias + R) * gamma + beta in ONE launch -- the post-norm sublayer tail of nn.TransformerEncoderLayer
+ * (model/posenet.py:63-69: x = norm1(x + out_proj(attn)), x = norm2(x + linear2(...)); `norm_first=False`), eps inside the root,
+ * biased variance over the N columns.  The N / 64 or N / 128 column tiles of a 144-row tile exchange their per-row (sum, sum of
+ * squares) through L2 while the kernel runs (they are dispatched back to back onto one XCD), so LN(x) is stored once and the raw
+ * sum never reaches HBM.  Shapes: M % 144 == 0, K % 32 == 0, N / 64 or N / 128 in {1, 2, 4, 8} (else ROHM_ERR_UNSUPPORTED:
+ * use rohm_gemm_f32(epi 2) + rohm_layernorm_f32).  `scratch`: rohm_gemm_res_layernorm_scratch_bytes(M, N) bytes, 64-byte aligned,
+ * owned by the caller for the duration of the launch (counters + statistics; cleared by this call). */
+size_t rohm_gemm_res_layernorm_scratch_bytes(int M, int N);
+int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                                const float* bias, const float* R, int ldr, const float* gamma, const float* beta, float eps,
+                                void* scratch, size_t scratch_bytes, rohm_stream_t stream);
+
 /* Multi-head self-attention over n_tok tokens, head dim 64 or 128, for n_seq sequences:
  * qkv[n_seq*n_tok, 3*n_head*head_dim] (q | k | v blocks, q already scaled by head_dim^-1/2)
  * -> ctx[n_seq*n_tok, n_head*head_dim].  Replaces the scaled-dot-product inside

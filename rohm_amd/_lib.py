@@ -59,6 +59,10 @@ SIGNATURES = {
     'rohm_profile_detail': (C.c_int, [C.c_int]),
     'rohm_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'rohm_gemm_res_layernorm_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'rohm_gemm_res_layernorm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_layernorm_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'rohm_attention_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'rohm_planes_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

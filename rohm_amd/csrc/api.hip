@@ -119,6 +119,25 @@ int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, in
     return launch_gemm(g, epi, (hipStream_t)stream);
 }
 
+size_t rohm_gemm_res_layernorm_scratch_bytes(int M, int N) { return gemm_ln_supported(M, N, 32) ? gemm_ln_scratch_bytes(M, N) : 0; }
+
+int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                                const float* bias, const float* R, int ldr, const float* gamma, const float* beta, float eps,
+                                void* scratch, size_t scratch_bytes, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(A && W && C && bias && R && gamma && beta && scratch, "gemm_res_layernorm: null pointer");
+    if (!gemm_ln_supported(M, N, K)) {
+        set_error("gemm_res_layernorm: shape (%d, %d, %d) has no in-kernel LayerNorm form (M %% 144, K %% 32, N / 64 or N / 128 in 1, 2, 4, 8)", M, N, K);
+        return ROHM_ERR_UNSUPPORTED;
+    }
+    ROHM_ARG_CHECK(scratch_bytes >= gemm_ln_scratch_bytes(M, N) && (((uintptr_t)scratch) & 63) == 0, "gemm_res_layernorm: scratch too small / misaligned");
+    GemmParams g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.R = R; g.ldr = ldr; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_dim = N; g.ln_eps = eps;
+    gemm_ln_bind(g, scratch);
+    ROHM_HIP_CHECK(hipMemsetAsync(scratch, 0, gemm_ln_zero_bytes(M), (hipStream_t)stream));
+    return launch_gemm(g, EPI_BIAS_RES_LN, (hipStream_t)stream);
+}
+
 int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, int D, rohm_stream_t stream) {
     ROHM_ARG_CHECK(x && gamma && beta, "layernorm: null pointer");
     return launch_layernorm(x, gamma, beta, M, D, (hipStream_t)stream);

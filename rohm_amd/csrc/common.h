@@ -126,13 +126,14 @@ struct GemmParams {
     int ln_dim; float ln_eps;
     // ---- LayerNorm INSIDE the producer (EPI_BIAS_RES_LN; post-norm nn.TransformerEncoderLayer, model/posenet.py:63-69:
     // x = norm(x + sublayer(x))).  The N / BN column tiles of a row tile run at the same time on CUs of ONE XCD (the kernel's own
-    // block -> tile map), each writes its 144 per-row (sum, sum of squares) pairs to xln_stats[row tile][column tile][144][2],
-    // counts itself in xln_flags[row tile][0], waits until all column tiles have, sums the pairs in column-tile order (every tile
-    // gets bit-identical statistics), normalises its accumulators in registers and stores LN(x) once.  xln_flags ([tiles_m][2]
-    // arrive / depart counters) must be zero before the first launch (the last tile to leave resets them); *xln_err is set
-    // if a wait ran into its bound (never on a healthy device: the partner tiles are co-resident by construction).
+    // block -> tile map); each publishes its 144 per-row (sum, sum of squares) pairs in xln_stats[row tile][column tile][144][4]
+    // as (sum, tag, sum of squares, tag) with ONE 16-byte store per row, polls the partner tiles' slots until they carry this
+    // launch's tag (xln_epoch: unique per launch, set by launch_gemm), sums the pairs in column-tile order (every tile gets
+    // bit-identical statistics), normalises its accumulators in registers and stores LN(x) once.  *xln_err is set if a wait ran
+    // into its bound (never on a healthy device: the partner tiles are co-resident by construction).  Not for hipGraph capture
+    // (a replay would repeat the tag).
     const float* ln_gamma; const float* ln_beta;
-    float* xln_stats; unsigned* xln_flags; unsigned* xln_err;
+    float* xln_stats; unsigned* xln_err; unsigned xln_epoch;
 };
 // EPI_BIAS_RES_LN: can launch_gemm run (M, N, ...) with the in-kernel LayerNorm?  Scratch = stats + flags + error word.
 bool gemm_ln_supported(int M, int N, int K);

@@ -36,6 +36,7 @@
 //     tile takes its bias row through LDS.  The FULL instantiation has no conditional operand loads (LayerNorm folding lives in the
 //     general one).
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include <string.h>
 #include "common.h"
@@ -637,57 +638,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
         __syncthreads();
         const int g = m0 / BM, tn = n0 / BN;
-        float* const tile_stats = p.xln_stats + (size_t)g * tiles_n * (BM * 2);
+        // 3. publish this tile's pair of every row and collect the partner tiles' pairs.  A slot is 16 bytes (sum, tag, sum of
+        //    squares, tag) written by ONE store: each 8-byte half carries the launch's tag, so a reader that sees both tags has
+        //    the data (no separate flag, no wait for the store's acknowledgement, no counter to re-arm: three dependent trips to
+        //    L2 less than publish / count / poll).  Pairs are summed in column-tile order with the own pair taken from registers at
+        //    its place: every tile of the row gets bit-identical statistics whatever the arrival order.
+        float* const row_stats = p.xln_stats + ((size_t)g * tiles_n * BM) * 4;
+        const unsigned tag = p.xln_epoch;
         if (tid < BM) {
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { const f32x2 v = *reinterpret_cast<const f32x2*>(part + (w * BM + tid) * 2); a += v[0]; b += v[1]; }
-            *reinterpret_cast<f32x2*>(tile_stats + ((size_t)tn * BM + tid) * 2) = f32x2{a, b};
-        }
-        // 3. the statistics are in L2 (vmcnt(0) = acknowledged) before this tile counts itself; then wait for the partner tiles
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned* const fl = p.xln_flags + 2 * g;
-        if (tid == 0) {
-            __hip_atomic_fetch_add(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int it = 0;
-            while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_n) {
+            *reinterpret_cast<f32x4*>(row_stats + ((size_t)tn * BM + tid) * 4) = f32x4{a, __uint_as_float(tag), b, __uint_as_float(tag)};
+            float sm = 0.f, sq = 0.f;
+            for (int it = 0;; ++it) {
+                unsigned long long lo[8], hi[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    lo[k] = hi[k] = 0ull;
+                    if (k < tiles_n && k != tn) {          // past the L1: the partner's store went to L2
+                        const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(row_stats + ((size_t)k * BM + tid) * 4);
+                        lo[k] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[k] = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                bool ok = true;
+                sm = 0.f; sq = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k >= tiles_n) continue;
+                    if (k == tn) { sm += a; sq += b; continue; }
+                    ok = ok && (unsigned)(lo[k] >> 32) == tag && (unsigned)(hi[k] >> 32) == tag;
+                    sm += __uint_as_float((unsigned)lo[k]);
+                    sq += __uint_as_float((unsigned)hi[k]);
+                }
+                if (ok) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++it > (1 << 19)) {                 // ~0.2 s: never on a healthy device; do not hang the GPU
+                if (it > (1 << 19)) {                   // ~0.2 s: never on a healthy device (the partner tiles are co-resident); do not hang it
                     __hip_atomic_store(p.xln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }
-        }
-        __syncthreads();
-        // 4. all column tiles' pairs of a row, summed in column-tile order (bit-identical in every tile); read past the L1
-        if (tid < BM) {
-            unsigned long long raw[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                raw[k] = (k < tiles_n) ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(tile_stats + ((size_t)k * BM + tid) * 2),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                       : 0ull;
-            float sm = 0.f, sq = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                sm += __uint_as_float((unsigned)(raw[k] & 0xffffffffull));
-                sq += __uint_as_float((unsigned)(raw[k] >> 32));
-            }
             const float inv = 1.0f / (float)p.ln_dim;
             const float mu = sm * inv;
             const float var = fmaxf(sq * inv - mu * mu, 0.f);
-            *reinterpret_cast<f32x2*>(part + tid * 2) = f32x2{mu, 1.0f / sqrtf(var + p.ln_eps)};
+            *reinterpret_cast<f32x2*>(part + tid * 2) = f32x2{mu, 1.0f / sqrtf(var + p.ln_eps)};      // own row of wave 0's zone: read above
         }
         __syncthreads();
-        if (tid == 0) {      // the last tile to have read the pairs re-arms the counters for the next launch on this stream
-            const unsigned old = __hip_atomic_fetch_add(fl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)tiles_n - 1u) {
-                __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(fl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // 5. normalise in registers, store LN(x) once
+        // 4. normalise in registers, store LN(x) once
 #pragma unroll
         for (int r = 0; r < NRB; ++r) {
             const f32x2 mr = *reinterpret_cast<const f32x2*>(part + (r * 16 + li) * 2);
@@ -1021,28 +1019,31 @@ bool gemm_ln_supported(int M, int N, int K) {
     return M > 0 && M % BM == 0 && K > 0 && K % BK == 0 && N > 0 && ln_tile_width(M / BM, N) != 0;
 }
 
-// scratch layout: [error word, 64 B] [flags: tiles_m x 2 words, padded to 64 B] [statistics: tiles_m x 8 x 144 x 2 floats]
-static size_t ln_flag_bytes(int M) { return ((size_t)((M + BM - 1) / BM) * 2 * sizeof(unsigned) + 63) / 64 * 64; }
-size_t gemm_ln_zero_bytes(int M) { return 64 + ln_flag_bytes(M); }
+// scratch layout: [error word, 64 B] [statistics: tiles_m x 8 column tiles x 144 rows x (sum, tag, sum of squares, tag)]
+size_t gemm_ln_zero_bytes(int M) { (void)M; return 64; }
 size_t gemm_ln_scratch_bytes(int M, int N) {
     (void)N;
-    return gemm_ln_zero_bytes(M) + (size_t)((M + BM - 1) / BM) * 8 * BM * 2 * sizeof(float);
+    return 64 + (size_t)((M + BM - 1) / BM) * 8 * BM * 4 * sizeof(float);
 }
 void gemm_ln_bind(GemmParams& p, void* scratch) {
     char* c = static_cast<char*>(scratch);
     p.xln_err = reinterpret_cast<unsigned*>(c);
-    p.xln_flags = reinterpret_cast<unsigned*>(c + 64);
-    p.xln_stats = reinterpret_cast<float*>(c + gemm_ln_zero_bytes(p.M));
+    p.xln_stats = reinterpret_cast<float*>(c + 64);
 }
 
 static int launch_ln(const GemmParams& p, hipStream_t s) {
     ROHM_ARG_CHECK(gemm_ln_supported(p.M, p.N, p.K), "gemm: shape (%d, %d, %d) has no in-kernel LayerNorm form", p.M, p.N, p.K);
-    ROHM_ARG_CHECK(p.bias && p.R && p.ln_gamma && p.ln_beta && p.xln_stats && p.xln_flags && p.xln_err, "gemm: LayerNorm epilogue: null operand");
+    ROHM_ARG_CHECK(p.bias && p.R && p.ln_gamma && p.ln_beta && p.xln_stats && p.xln_err, "gemm: LayerNorm epilogue: null operand");
     ROHM_ARG_CHECK(p.ln_dim == p.N && p.ldc % 4 == 0 && p.ldr % 4 == 0 && al16(p.C) && al16(p.R) && al16(p.bias) && al16(p.ln_gamma) &&
                        al16(p.ln_beta) && (((uintptr_t)p.xln_stats) & 15) == 0 && p.ksplit <= 1 && p.conv_taps == 0,
                    "gemm: LayerNorm epilogue needs ln_dim == N and 16-byte aligned operands");
-    if (ln_tile_width(p.M / BM, p.N) == 128) return launch_one<128, EPI_BIAS_RES_LN, 0, true>(p, s);
-    return launch_one<64, EPI_BIAS_RES_LN, 0, true>(p, s);
+    // the tag of this launch's statistics slots: unique per launch in this process and never 0, so whatever an earlier launch (or
+    // nobody) left in the scratch is recognised as stale -- nothing to clear, nothing to re-arm
+    static std::atomic<unsigned> epoch{0};
+    GemmParams q = p;
+    do { q.xln_epoch = epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (q.xln_epoch == 0u);
+    if (ln_tile_width(p.M / BM, p.N) == 128) return launch_one<128, EPI_BIAS_RES_LN, 0, true>(q, s);
+    return launch_one<64, EPI_BIAS_RES_LN, 0, true>(q, s);
 }
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {

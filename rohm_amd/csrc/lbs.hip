@@ -7,11 +7,15 @@
 //
 //   lbs_pose_kernel   one thread per frame: Rodrigues, rest joints from the folded regressor, the 55-joint chain,
 //                     relative transforms A[m][j] = [G_j | P_j - G_j J_j] and the pose feature (R_j - I, j >= 1).
-//   gemm_f32_kernel   pose blendshapes as a fp32-MFMA GEMM: off[N, V*3] = pose_feature[N, 486] . posedirs
-//                     (30.5 MFLOP per frame -- the one dense contraction of the body model).
-//   lbs_skin_kernel   one thread per vertex x 8 frames: v_template + shapedirs.beta + off, blended transform
-//                     sum_j w[v][j] A[m][j] (A broadcast from LDS), + transl.  Algorithmic traffic 12 B read (off) + 12 B written
-//                     per vertex-frame; per-vertex constants are read once per 8 frames (weights stored [J, V]).
+//   gemm_f32_kernel   shape + pose blendshapes as ONE fp32-MFMA GEMM: v_posed[N, V*3] = [pose_feature(486) | beta(10) | 1] .
+//                     [posedirs ; shapedirs ; v_template]  (K = 497 -> 512; 30.5 + 0.7 MFLOP per frame).
+//   lbs_skin_mfma_kernel  DENSE skinning weights: the blend T = W[V, 55] . A[55, 12 F] is a dense contraction (13.8 MFLOP per
+//                     frame, 660 fma per vertex-frame on the VALU before) -- on the matrix core: a workgroup keeps the 12 x 16
+//                     transform rows of 16 frames in LDS, streams 144-vertex tiles of W through a double buffer, and applies
+//                     v = T [p; 1] + transl in the epilogue.  Algorithmic traffic 12 B read + 12 B written per vertex-frame.
+//   lbs_skin_ell_kernel   SPARSE skinning weights (a real SMPLX_NEUTRAL.npz: a handful of non-zero joints per vertex; chosen at
+//                     rohm_smplx_set_skinning when >= 75 % of lbs_weights are zero): per vertex an ELL row (joint index, weight) of
+//                     the widest vertex's length, one thread per vertex x 8 frames, transforms from LDS.
 // Expression coefficients are taken as zero (every reference call site passes zeros, :383-388).
 #include "common.h"
 #include "smplx_fk.h"
@@ -32,7 +36,9 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const float* __restrict__ 
     for (int k = 0; k < NBETA; ++k) beta[k] = betas[(size_t)n * NBETA + k];
     float* An = A + (size_t)n * J * 12;          // pass 1: (G_j [9], P_j [3]); pass 2: P_j -> P_j - G_j J_j
     float* fn = feat + (size_t)n * KP;
-    for (int k = (J - 1) * 9; k < KP; ++k) fn[k] = 0.f;
+    // columns (J-1)*9 .. +9: the shape coefficients, then a 1: the shape blend and v_template ride in the blendshape GEMM
+    // (their rows follow posedirs in d_pdT)
+    for (int k = (J - 1) * 9; k < KP; ++k) fn[k] = (k < (J - 1) * 9 + NBETA) ? beta[k - (J - 1) * 9] : (k == (J - 1) * 9 + NBETA ? 1.f : 0.f);
     auto rest = [&](int j, float* o) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -90,10 +96,19 @@ __global__ __launch_bounds__(64) void lbs_pose_kernel(const float* __restrict__ 
 }
 
 // joints out (posed + transl) and P_j -> t_j = P_j - G_j J_j; separate pass so children above read the parents' P_j
+// Row of the skinning GEMM's transform operand that holds component `comp` (0..11) of frame `f`: groups of 16 frames = 192 rows; inside
+// a group the row order makes one MFMA lane end up with all 12 components of ONE frame: wave w = f_in / 4 owns rows [48 w, 48 w + 48),
+// column block c = comp / 4, lane group lg = f_in % 4, q = comp % 4  (see lbs_skin_mfma_kernel).
+__host__ __device__ __forceinline__ size_t skin_row(int f, int comp) {
+    const int g = f >> 4, fi = f & 15;
+    return (size_t)g * 192 + (fi >> 2) * 48 + (comp >> 2) * 16 + (fi & 3) * 4 + (comp & 3);
+}
+constexpr int SKIN_K = 64;        // joints padded to two 32-wide K chunks (J <= 64)
+
 __global__ __launch_bounds__(64) void lbs_finish_pose_kernel(const float* __restrict__ betas, const float* __restrict__ transl,
                                                              const float* __restrict__ Jt, const float* __restrict__ Js,
-                                                             int J, float* __restrict__ A, float* __restrict__ joints,
-                                                             int n_joints_out, int N) {
+                                                             int J, float* __restrict__ A, float* __restrict__ Tm,
+                                                             float* __restrict__ joints, int n_joints_out, int N) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * J) return;
     const int n = idx / J, j = idx % J;
@@ -113,6 +128,10 @@ __global__ __launch_bounds__(64) void lbs_finish_pose_kernel(const float* __rest
     mat_vec(o, Jj, w);
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[9 + c] -= w[c];
+    if (Tm) {      // the same 12 numbers as rows of the skinning GEMM's operand [frames x 12 (permuted), 64 joints]
+#pragma unroll
+        for (int c = 0; c < 12; ++c) Tm[skin_row(n, c) * SKIN_K + j] = o[c];
+    }
 }
 
 // Skinning.  One thread per vertex, SKIN_F consecutive frames per block.  What belongs to the vertex -- its J skinning weights,

@@ -54,7 +54,8 @@ struct rohm_posenet {
     float* tok_table;  // [pe_len, D]  timestep token of every t (time MLP output + pe[0]), built once at create
     float *out_w, *out_b;                 // [Cout, D], [Cout]
     float *out_c;                         // LayerNorm folding of the last norm2 into the output head
-    bool ln_fold;                         // LayerNorm folded into the surrounding GEMMs (default) or run as a kernel
+    bool ln_fold;                         // LayerNorm folded into the CONSUMER GEMMs (opt-in, measured slower) or run as a kernel
+    bool ln_fused;                        // LayerNorm inside the PRODUCER GEMMs (EPI_BIAS_RES_LN; default on, ROHM_POSENET_LN_FUSED=0: kernel)
     int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2 / 16: split GEMMs on planes (bf16x6 / bf16x3 / fp16x3)
     char* wplanes;                        // one allocation holding the weight planes of every layer
     bool pp_fold;                         // plane modes: LayerNorm folded into the plane GEMMs (ROHM_PP_LNFOLD=1, two-plane modes)
@@ -215,6 +216,7 @@ struct Workspace {
     float *apack, *h, *y, *qkv, *ctx, *ff, *tab0, *x0, *tok_all;
     char *hP, *yP, *ctxP, *ffP;   // planes of h / y / ctx / ff (split-bf16 mode; ctx and ff then exist as planes only)
     float *stats_a, *stats_b;     // row (sum, sum of squares) partials of y / h: [M][D/64][2]
+    float* xln;                   // scratch of the LayerNorm-producing GEMMs (common.h gemm_ln_*): error word, counters, statistics
     int64_t* t_all;
     size_t floats;
 };
@@ -250,6 +252,7 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
     w.stats_a = take(M * (p->D / (p->nplane ? 16 : 64)) * 2);
     w.stats_b = take(M * (p->D / (p->nplane ? 16 : 64)) * 2);
     w.t_all = reinterpret_cast<int64_t*>(take(2 * (size_t)kLoopChunk));
+    w.xln = take(gemm_ln_scratch_bytes((int)M, p->D) / sizeof(float));
     w.floats = off;
     return w;
 }
@@ -334,6 +337,8 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         if (pf && (rc = launch_layernorm(h, p->layers[p->L - 1].n2_w, p->layers[p->L - 1].n2_b, M, D, s))) return rc;
     }
     const bool fold = p->ln_fold && !planes;
+    // LayerNorm inside the producer GEMMs (out-projection, FF2): whole clips of 144 tokens, widths whose column tiles pair up
+    const bool lnf = p->ln_fused && !fold && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F);
     const int parts = D / 64;
     auto ln_operand = [&](GemmParams& g, const float* stats, const float* c) {
         g.ln_stats = stats; g.ln_parts = parts; g.ln_c = c; g.ln_dim = D; g.ln_eps = 1e-5f;
@@ -357,8 +362,14 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
             if (l > 0) ln_residual(g, w.stats_b, p->layers[l - 1].n2_w, p->layers[l - 1].n2_b);
             g.out_stats = w.stats_a; g.out_parts = parts;
         }
-        if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
-        if (!fold && (rc = launch_layernorm(y, lw.n1_w, lw.n1_b, M, D, s))) return rc;
+        if (lnf) {      // y = norm1(h + out_proj(ctx)) in one launch
+            g.ln_gamma = lw.n1_w; g.ln_beta = lw.n1_b; g.ln_dim = D; g.ln_eps = 1e-5f;
+            gemm_ln_bind(g, w.xln);
+            if ((rc = launch_gemm(g, EPI_BIAS_RES_LN, s))) return rc;
+        } else {
+            if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
+            if (!fold && (rc = launch_layernorm(y, lw.n1_w, lw.n1_b, M, D, s))) return rc;
+        }
         g = GemmParams{};
         g.A = y; g.lda = D; g.W = lw.l1_w; g.ldw = D; g.C = w.ff; g.ldc = p->F; g.M = M; g.N = p->F; g.K = D;
         g.bias = lw.l1_b;
@@ -371,8 +382,14 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
             ln_residual(g, w.stats_a, lw.n1_w, lw.n1_b);
             g.out_stats = w.stats_b; g.out_parts = parts;
         }
-        if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
-        if (!fold && (rc = launch_layernorm(h, lw.n2_w, lw.n2_b, M, D, s))) return rc;
+        if (lnf) {      // h = norm2(y + linear2(gelu(linear1(y))))
+            g.ln_gamma = lw.n2_w; g.ln_beta = lw.n2_b; g.ln_dim = D; g.ln_eps = 1e-5f;
+            gemm_ln_bind(g, w.xln);
+            if ((rc = launch_gemm(g, EPI_BIAS_RES_LN, s))) return rc;
+        } else {
+            if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
+            if (!fold && (rc = launch_layernorm(h, lw.n2_w, lw.n2_b, M, D, s))) return rc;
+        }
     }
     {   // output head, transposed: rows = channels, cols = tokens
         GemmParams g{};
@@ -471,6 +488,11 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         // Opt-in for further tuning: ROHM_POSENET_LNFOLD=1.
         const char* e2 = getenv("ROHM_POSENET_LNFOLD");
         p->ln_fold = (e2 && atoi(e2) == 1) && d_model <= 512;       // 8 statistic slots of 64 columns
+        // Round 4: LayerNorm inside the PRODUCER (out-projection / FF2) instead -- the column tiles of a row tile exchange their
+        // row statistics through L2 while they run and store LN(x) once (gemm_f32.hip EPI_BIAS_RES_LN): 16 launches and one
+        // write + read of the residual stream per layer less.  Default on; ROHM_POSENET_LN_FUSED=0 keeps the LayerNorm kernel.
+        const char* e6 = getenv("ROHM_POSENET_LN_FUSED");
+        p->ln_fused = !(e6 && e6[0] == '0');
         // Opt-in precision ladder: ROHM_GEMM_PRECISION=bf16x6 | bf16x3 | fp16x3 runs the four Linears of every
         // encoder layer as split-bf16 GEMMs on planes (gemm_pp.hip).  The default -- and every headline number -- is exact fp32.
         const char* e3 = getenv("ROHM_GEMM_PRECISION");
@@ -658,6 +680,7 @@ int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float*
         set_error("posenet_forward: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
         return ROHM_ERR_WORKSPACE;
     }
+    if (h->ln_fused) ROHM_HIP_CHECK(hipMemsetAsync(w.xln, 0, gemm_ln_zero_bytes(B * (T + 1)), s));
     if ((rc = launch_pack(h, x_t, w.apack, B, T, 0, s))) return rc;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;
     if ((rc = run_network(h, w, t, 0, nullptr, x0_out, B, T, s))) return rc;
@@ -682,6 +705,7 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
     const size_t n = (size_t)B * h->Cin * T;
     ROHM_ARG_CHECK(n_steps <= kLoopChunk, "posenet_sample_loop: at most %d steps per call", kLoopChunk);
     if (n_steps == 0) return ROHM_OK;
+    if (h->ln_fused) ROHM_HIP_CHECK(hipMemsetAsync(w.xln, 0, gemm_ln_zero_bytes(B * (T + 1)), s));      // counters of the LayerNorm GEMMs
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;   // cond is constant over the loop
     // timestep tokens come from the table built at create (the embedder depends on t only, heads.py:145-146)
     for (int i = 0; i < n_steps; ++i) {

@@ -31,10 +31,17 @@ def _allreduce_sum(t, group):
     return t
 
 
-def global_batch(B, group, device):
-    """Total number of clips over the ranks of `group` (shards may be ragged)."""
-    n = torch.tensor([float(B)], device=device)
-    return float(_allreduce_sum(n, group).item())
+def global_batch(B, group, device, model=None):
+    """Total number of clips over the ranks of `group` (shards may be ragged).  Constant over a run: given by the caller of
+    `sharding.use_global_batch_guidance(..., global_batch=)` or all-reduced once and cached on the model (per local batch size) --
+    not an all-reduce + host sync on every guided step."""
+    cache = model.__dict__.setdefault('_rohm_global_batch', {}) if model is not None else {}
+    if 'fixed' in cache:
+        return cache['fixed']
+    if B not in cache:
+        n = torch.tensor([float(B)], device=device)
+        cache[B] = float(_allreduce_sum(n, group).item())
+    return cache[B]
 
 
 def _stats(model, device):
@@ -108,5 +115,5 @@ def guide_2d_projection(model, batch, out, denoise_t, compute_grad='x_t'):
     group = getattr(model, 'guidance_group', None)
     if group is not None:
         # loss_joints_2d.mean() runs over the whole batch (model/posenet.py:309): d/dx of a local clip scales as 1 / B_global
-        grad.mul_(B / float(global_batch(B, group, dev)))
+        grad.mul_(B / float(global_batch(B, group, dev, model)))
     return grad

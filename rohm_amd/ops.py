@@ -28,6 +28,24 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_BIAS, out=None):
     return out
 
 
+def gemm_res_layernorm(a, w, bias, residual, gamma, beta, eps=1e-5, out=None, return_scratch=False):
+    """out[M,N] = LayerNorm(a @ w^T + bias + residual) * gamma + beta in one launch (include/rohm_hip.h
+    rohm_gemm_res_layernorm_f32); raises RohmHipError(ROHM_ERR_UNSUPPORTED) for shapes without the in-kernel form."""
+    _lib.require_hip(a, w, bias, residual, gamma, beta)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    nbytes = lib().rohm_gemm_res_layernorm_scratch_bytes(M, N)
+    scratch = torch.empty(max(nbytes, 64) // 4 + 16, device=a.device, dtype=torch.int32)
+    off = (-scratch.data_ptr() % 64) // 4
+    scratch = scratch[off:]
+    check(lib().rohm_gemm_res_layernorm_f32(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K,
+                                            ptr(bias), ptr(residual), residual.stride(0), ptr(gamma), ptr(beta), eps,
+                                            ptr(scratch), nbytes, stream_ptr(a.device)), 'rohm_gemm_res_layernorm_f32')
+    return (out, scratch) if return_scratch else out
+
+
 def layernorm_(x, gamma, beta):
     _lib.require_hip(x)
     M, D = x.shape

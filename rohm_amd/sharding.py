@@ -74,11 +74,14 @@ def sharded_sample(sample_fn, batch, shape, group=None):
     return gather_clips(out, n, group)
 
 
-def use_global_batch_guidance(model, group=True):
+def use_global_batch_guidance(model, group=True, global_batch=None):
     """Make the test-time guidance of `model` (a PoseNet) reproduce the reference at the GLOBAL batch size when the
     clips are sharded over the ranks of `group` (default process group if True; None switches back to per-rank
-    semantics).  Costs one 8-byte all-reduce per guided step (the two skating mask counts, model/posenet.py:231,243)
-    and one per 2-D guided step for the batch size."""
+    semantics).  Costs one 8-byte all-reduce per guided step (the two skating mask counts, model/posenet.py:231,243).
+    The 2-D term needs the global batch size (its loss is a mean over the batch, :309): pass `global_batch` if the caller knows
+    it (no collective at all); otherwise it is all-reduced ONCE, at the first guided step, and cached per local batch size --
+    call this function again if the split changes."""
     raw = getattr(model, 'model', model)
     raw.guidance_group = group
+    raw.__dict__['_rohm_global_batch'] = {} if global_batch is None else {'fixed': float(global_batch)}
     return model

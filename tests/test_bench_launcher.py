@@ -36,6 +36,18 @@ def test_gpus_2_spawns_two_ranks():
     assert rec['data'] == 'selftest-stub' and rec['value'] == 0.0
 
 
+@pytest.mark.parametrize('world', [4, 8])
+def test_gpus_4_and_8_spawn_that_many_ranks(world):
+    """The world sizes of BASELINE configs[4] (4 x 32) and configs[2] (8 x 32) through the launcher: N ranks, N slices gathered."""
+    r = _run(['--gpus', str(world), '--backend', 'gloo', '--steps', '1', '--warmup', '1', '--batch', '2'],
+             {'ROHM_BENCH_SELFTEST': '1', 'OMP_NUM_THREADS': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json_line(r.stdout)
+    assert rec['n_gpus'] == world and rec['world_size'] == world and rec['ranks_seen'] == list(range(world))
+    assert rec['gathered_clips'] == 2 * world
+    assert rec['ms_per_step'] >= 10.0 * world - 1.0          # MAX over ranks: the last rank sleeps 10 ms x world per pass
+
+
 def test_single_rank_selftest_and_gloo_needs_the_switch():
     r = _run(['--gpus', '1', '--backend', 'gloo', '--steps', '1', '--warmup', '0', '--batch', '2'],
              {'ROHM_BENCH_SELFTEST': '1'})
@@ -104,6 +116,29 @@ def test_force_dist_runs_the_rccl_plumbing_on_one_gpu():
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])['process_group']['backend'] == 'nccl'
+
+
+@pytest.mark.gpu
+def test_scheme_workload_under_force_dist_with_global_batch_guidance():
+    """BASELINE configs[2]'s workload (`--workload scheme`: TrajNet -> PoseNet + skating guidance -> TrajControl -> PoseNet) through
+    the RCCL process group at world size 1, with `--guidance-semantics global`: the mask-count all-reduce of every guided step and
+    the result all-gather run over RCCL on the MI355X; at one rank the global batch IS the local batch, so the result must equal the
+    replica-semantics run bit for bit."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    recs = {}
+    for sem in ('global', 'replica'):
+        r = subprocess.run([sys.executable, BENCH, '--force-dist', '--workload', 'scheme', '--guidance-semantics', sem, '--steps', '1',
+                            '--warmup', '0', '--batch', '4', '--ddpm-steps', '60', '--no-cpu-baseline', '--no-extras'], env=env,
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        recs[sem] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert 'GLOBAL-batch semantics' in recs['global']['config']['sharding']
+    assert 'replica semantics' in recs['replica']['config']['sharding']
+    assert recs['global']['config']['finite_output'] and recs['global']['value'] > 0
+    assert recs['global']['config']['output_digest'] == recs['replica']['config']['output_digest']
 
 
 def test_force_dist_at_world_size_1_goes_through_the_process_group():

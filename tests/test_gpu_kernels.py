@@ -42,6 +42,44 @@ def test_gemm_identity_asymmetric():
     assert torch.equal(out.cpu(), w[:, :144].T.contiguous())
 
 
+@pytest.mark.parametrize('M,N,K', [(144 * 64, 512, 512), (144 * 64, 512, 1024),      # B = 64: 144 x 128 tiles, 4 partner tiles
+                                   (144 * 32, 512, 512), (144 * 32, 512, 1024),      # B = 32: 144 x 64 tiles, 8 partner tiles
+                                   (144 * 2, 512, 512), (144 * 13, 512, 1024),       # row tiles not a multiple of 8 (surplus workgroups leave)
+                                   (144 * 128, 512, 512),                            # two rounds of workgroups
+                                   (144 * 5, 256, 256), (144 * 3, 1024, 512)])       # other widths: 4 and 8 partner tiles of 64 / 128
+def test_gemm_res_layernorm(M, N, K):
+    """nn.TransformerEncoderLayer's post-norm tail x = norm(x + sublayer(x)) (model/posenet.py:63-69) as ONE launch: the column
+    tiles of a row tile exchange row statistics through L2 while the kernel runs (gemm_f32.hip EPI_BIAS_RES_LN)."""
+    from rohm_amd import ops
+    a, w = seeded(M + N, M, K), seeded(K + 7, N, K) / math.sqrt(K)
+    bias, res = seeded(3, N), seeded(4, M, N) * 2 + 0.3
+    g, b = seeded(5, N) * 0.5 + 1.0, seeded(6, N)
+    ref = nets.layer_norm(a.double() @ w.double().T + bias.double() + res.double(), g.double(), b.double())
+    d = _dev()
+    args = [t.to(d) for t in (a, w, bias, res, g, b)]
+    out, scratch = ops.gemm_res_layernorm(*args, return_scratch=True)
+    assert max_abs(out.cpu(), ref) < 2e-5 * math.sqrt(K / 32)
+    # the two-kernel path it replaces
+    two = ops.layernorm_(ops.gemm(args[0], args[1], args[2], args[3], 2), args[4], args[5])
+    assert max_abs(out.cpu(), two.cpu()) < 1e-5
+    torch.cuda.synchronize()
+    words = scratch.cpu()
+    assert int(words[0]) == 0, 'a partner wait ran into its bound'
+    # race screen: 50 launches, same bits (statistics summed in tile order whatever the arrival order)
+    for _ in range(50):
+        assert torch.equal(ops.gemm_res_layernorm(*args), out)
+
+
+def test_gemm_res_layernorm_refuses_other_shapes():
+    from rohm_amd import _lib, ops
+    d = _dev()
+    for M, N, K in ((100, 512, 512), (144, 320, 512), (144, 2048, 64)):
+        a, w = torch.zeros(M, K, device=d), torch.zeros(N, K, device=d)
+        with pytest.raises(_lib.RohmHipError):
+            ops.gemm_res_layernorm(a, w, torch.zeros(N, device=d), torch.zeros(M, N, device=d), torch.ones(N, device=d),
+                                   torch.zeros(N, device=d))
+
+
 @pytest.mark.parametrize('M', [4, 144, 1000])
 def test_layernorm(M):
     from rohm_amd import ops

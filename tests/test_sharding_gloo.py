@@ -20,8 +20,10 @@ def _free_port():
 
 
 def _fake_sampler(batch, shape):
-    # clip-wise (no cross-batch coupling), like the real denoiser
-    return batch['cond'] * 2.0 + batch['cond'].flatten(1).sum(1).view(-1, *([1] * (batch['cond'].dim() - 1)))
+    # clip-wise (no cross-batch coupling), like the real denoiser; element-wise only, so that a clip's result does not depend on
+    # how many clips share its tensor (a torch CPU reduction picks its summation order by shape)
+    c = batch['cond']
+    return c * 2.0 + c[:, 0:1, 0:1, 0:1] - 0.5 * c[:, 7:8, 0:1, 100:101]
 
 
 def _worker(rank, world, port, n_clips, q):
@@ -39,11 +41,11 @@ def _worker(rank, world, port, n_clips, q):
         dist.destroy_process_group()
 
 
-def _run(n_clips):
+def _run(n_clips, world=2):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -61,6 +63,40 @@ def test_even_split_world2():
 def test_ragged_split_world2():
     res = _run(5)            # 3 + 2 clips: gather must pad and trim
     assert [r[1] for r in res] == [True, True] and [r[2] for r in res] == [3, 2]
+
+
+def test_ragged_splits_world4_and_world8():
+    """The splits of BASELINE configs[2] / [4] (8 x 32 and 4 x 32 clips) and ragged ones at the same world sizes: every rank's
+    slice is sampled locally and the all-gather reassembles the single-process result."""
+    res = _run(10, world=4)      # 3 + 3 + 2 + 2
+    assert [r[1] for r in res] == [True] * 4 and [r[2] for r in res] == [3, 3, 2, 2]
+    res = _run(13, world=8)      # 2 x 5 + 1 x 3
+    assert [r[1] for r in res] == [True] * 8 and [r[2] for r in res] == [2] * 5 + [1] * 3
+    res = _run(16, world=8)
+    assert [r[1] for r in res] == [True] * 8 and [r[2] for r in res] == [2] * 8
+
+
+def test_global_batch_is_reduced_once_per_run_or_given_by_the_caller():
+    """the global batch size is constant over a run -- one all-reduce at the first guided step (cached per
+    local batch size), or none when the caller states it; never one collective + host sync per guided step."""
+    from rohm_amd import guidance
+
+    class M:
+        pass
+    calls = []
+
+    def group(t):
+        calls.append(int(t.numel()))
+        return t.mul_(4)                      # four ranks with the same local batch
+    m = sharding.use_global_batch_guidance(M(), group)
+    for _ in range(5):
+        assert guidance.global_batch(8, group, 'cpu', m) == 32.0
+    assert calls == [1]
+    assert guidance.global_batch(7, group, 'cpu', m) == 28.0 and calls == [1, 1]      # another local batch size: its own entry
+    sharding.use_global_batch_guidance(m, group)                                       # re-arming forgets the cache
+    assert guidance.global_batch(8, group, 'cpu', m) == 32.0 and calls == [1, 1, 1]
+    m = sharding.use_global_batch_guidance(M(), group, global_batch=256)
+    assert guidance.global_batch(32, group, 'cpu', m) == 256.0 and calls == [1, 1, 1]
 
 
 def test_slice_bounds_cover_everything():
