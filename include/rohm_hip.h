@@ -317,7 +317,12 @@ int rohm_guidance_proj2d_grad(const rohm_smplx_t* h, const float* x0, const floa
  * rohm_smplx_forward produces joints [N, n_joints_out, 3] (may be NULL) and verts [N, V, 3] (may be NULL: joints only)
  * from poses pose [N, n_pose, 3] (pose_kind 0: axis-angle) or [N, n_pose, 6] (pose_kind 1: the interleaved 6-D vectors
  * of the motion representation, quaternion.py:482-501); global orient first; joints >= n_pose unrotated; expression = 0;
- * betas [N,10], transl [N,3].  ws: rohm_smplx_lbs_workspace_bytes(h, N), 256-byte aligned.  N <= 65535 per call. */
+ * betas [N,10], transl [N,3].  ws: rohm_smplx_lbs_workspace_bytes(h, N), 256-byte aligned.  N <= 65535 per call.
+ * The shape and pose blendshapes are one fp32-MFMA GEMM; the skinning blend T = W . A runs on the matrix core too when
+ * lbs_weights is dense (mode 0), and over per-vertex ELL rows of the non-zero weights when >= 75 % of it is zero and no vertex
+ * has more than 16 non-zero joints -- what a released SMPLX_*.npz looks like (mode 1).  rohm_smplx_skinning_mode reports the
+ * choice made at rohm_smplx_set_skinning (-1: not set; 2: ELL rows of all joints, ROHM_LBS_SKIN=ell). */
+int rohm_smplx_skinning_mode(const rohm_smplx_t* h);
 int rohm_smplx_set_skinning(rohm_smplx_t* h, const float* v_template, const float* shapedirs, int n_shape_total,
                             const float* posedirs, int n_pose_feat, const float* lbs_weights);
 size_t rohm_smplx_lbs_workspace_bytes(const rohm_smplx_t* h, int N);

@@ -118,6 +118,7 @@ SIGNATURES = {
     'rohm_guidance_proj2d_grad': (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_size_t, C.c_void_p]),
     'rohm_smplx_set_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'rohm_smplx_skinning_mode': (C.c_int, [C.c_void_p]),
     'rohm_smplx_lbs_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'rohm_smplx_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -507,6 +507,10 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
             return ROHM_ERR_ARG;
         }
         if (d_model / n_head != 128 || d_model % 64 || d_ff % 64) p->nplane = 0;   // shapes the plane kernels do not cover
+        // ... and the widths their LayerNorm / fold forms exist for: launch_layernorm_planes knows D = 256 / 512 / 1024, and with the
+        // fold the QKV GEMM's dynamic LDS request passes the 160 KiB of a CU from d_model = 1024 on.  Such a handle runs exact
+        // fp32 (rohm_posenet_precision reports 0) instead of failing on every forward.
+        if (p->nplane && d_model != 256 && d_model != 512) p->nplane = 0;
         if (p->nplane) p->ln_fold = false;
         p->wplanes = nullptr;
         p->foldvec = nullptr;

@@ -589,6 +589,8 @@ void rohm_smplx_destroy(rohm_smplx_t* h) {
     if (h->d_sd) (void)hipFree(h->d_sd);
     if (h->d_pdT) (void)hipFree(h->d_pdT);
     if (h->d_wT) (void)hipFree(h->d_wT);
+    if (h->d_ell_j) (void)hipFree(h->d_ell_j);
+    if (h->d_ell_w) (void)hipFree(h->d_ell_w);
     delete h;
 }
 

@@ -26,7 +26,12 @@ struct rohm_smplx {
     float* d_vt;       // [V, 3]          v_template
     float* d_sd;       // [V, 3, 10]      shapedirs[:, :, :10]
     float* d_pdT;      // [NP, KP]        posedirs transposed (GEMM weight layout), zero padded
-    float* d_wT;       // [J, V]          lbs_weights transposed (coalesced per-vertex reads)
+    float* d_wT;       // [tiles_v * 144, 64]  lbs_weights, joints padded to 64, rows to whole 144-vertex tiles (MFMA skinning operand)
+    int tiles_v;       // 144-vertex tiles
+    int skin_mode;     // 0 = dense weights on the matrix core, 1 = sparse weights (ELL rows of the non-zeros), 2 = ELL rows of all joints
+    int ell_width;     // entries per ELL row
+    int* d_ell_j;      // [ell_width, V]  joint indices
+    float* d_ell_w;    // [ell_width, V]  weights (0 = padding)
 };
 
 namespace rohm {

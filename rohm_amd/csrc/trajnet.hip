@@ -1204,6 +1204,12 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
     ROHM_ARG_CHECK(!h->control || control_cond, "trajnet_sample_loop: TrajControl needs control_cond");
     ROHM_ARG_CHECK(((uintptr_t)ws % 256) == 0, "trajnet_sample_loop: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    // the side stream and its events belong to the handle's device: make it current for the duration of the call
+    struct DeviceGuard {
+        int prev = -1;
+        explicit DeviceGuard(int want) { if (hipGetDevice(&prev) != hipSuccess || prev == want || hipSetDevice(want) != hipSuccess) prev = -1; }
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } device_guard(h->device);
     TWs w = carve_t(h, B, T, (float*)ws);
     if (w.floats * sizeof(float) > ws_bytes) {
         set_error("trajnet_sample_loop: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
@@ -1232,6 +1238,13 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
     if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;     // x_T; the tail kernel keeps the padded copy current
     SideStream* ss = h->control ? side_stream(h->device) : nullptr;
     if (ss && (rc = run_control_pre(h, w, B, T, s))) return rc;           // control_zero_conv_0(control_cond): once per loop
+    // an early return must not leave side-stream work behind that still reads / writes the caller-owned workspace un-ordered
+    // against the caller's stream: join s2 into s first
+    auto fail = [&](int code) {
+        if (ss && hipEventRecord(ss->ev_in, ss->s2) == hipSuccess) (void)hipStreamWaitEvent(s, ss->ev_in, 0);
+        tl_splitk = w.splitk; tl_splitk_res = w.splitk_res;
+        return code;
+    };
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
         const float c1 = coef[3 * i], c2 = coef[3 * i + 1], sigma = coef[3 * i + 2];
@@ -1259,20 +1272,20 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
             tl_splitk = w.splitk_ctl; tl_splitk_res = w.splitk_res_ctl;
             rc = run_control(h, w, B, T, 0, tb_row, b ? w.ctrl_b : w.ctrl, b ? w.ctrl_mid_b : w.ctrl_mid, w.sc_ctl, ss->s2);
             tl_splitk = w.splitk; tl_splitk_res = w.splitk_res;
-            if (rc) return rc;
-            ROHM_HIP_CHECK(hipEventRecord(ss->ev_ctl[b], ss->s2));
+            if (rc) return fail(rc);
+            if (hipEventRecord(ss->ev_ctl[b], ss->s2) != hipSuccess) { set_error("trajnet_sample_loop: hipEventRecord failed"); return fail(ROHM_ERR_HIP); }
             CtrlRef cr{};
             for (int j = 0; j < 4; ++j) cr.ctrl[j] = b ? w.ctrl_b[j] : w.ctrl[j];
             cr.mid = b ? w.ctrl_mid_b : w.ctrl_mid;
             cr.ready = ss->ev_ctl[b]; cr.consumed = ss->ev_free[b];
-            if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s, tb_row, &cr))) return rc;
+            if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s, tb_row, &cr))) return fail(rc);
         } else if ((rc = run_denoiser(h, w, B, T, 0, nullptr, s, tb_row))) {
             return rc;
         }
         // head conv + ancestral update + padded copy for the next step: one launch (three before)
         if ((rc = run_tail(h, w, x, (x0_last && i == n_steps - 1) ? x0_last : nullptr, noise ? noise + (size_t)i * n : nullptr,
                            c1, c2, sigma, nullptr, nullptr, nullptr, M, s)))
-            return rc;
+            return fail(rc);
     }
     return ROHM_OK;
 }

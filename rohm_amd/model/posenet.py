@@ -163,11 +163,24 @@ class PoseNet(nn.Module):
         self._plist = None
         return super()._apply(fn, *args, **kwargs)
 
+    def load_state_dict(self, *args, **kwargs):     # assign=True re-binds Parameter objects
+        self._plist = None
+        return super().load_state_dict(*args, **kwargs)
+
     def _fingerprint(self, device):
         """(device, storage address and version counter of every parameter).  The parameter list is collected once (the
         module-tree walk is the expensive part of a per-forward check on the guided, step-wise path); in-place updates
         (load_state_dict, optimiser steps) move the version counters, re-allocation moves the addresses."""
         pl = getattr(self, '_plist', None)
+        # A re-bound Parameter object (`layer.weight = nn.Parameter(...)`, parametrizations) does not pass through _apply /
+        # load_state_dict: every 64th call the cached list is checked against a fresh walk (object identity), so a stale list
+        # lives for at most 64 forwards of the step-wise path instead of forever.
+        self._pl_age = getattr(self, '_pl_age', 0) + 1
+        if pl is not None and self._pl_age >= 64:
+            self._pl_age = 0
+            fresh = list(self.parameters(recurse=True))
+            if len(fresh) != len(pl) or any(a is not b for a, b in zip(fresh, pl)):
+                pl = None
         if pl is None:
             pl = self._plist = list(self.parameters(recurse=True))
         return (str(device), hash(tuple([(p.data_ptr(), p._version) for p in pl])))
@@ -243,6 +256,11 @@ class PoseNet(nn.Module):
                                       tuple(noise.shape[1:]) == tuple(x.shape)):
             raise ValueError(f'noise must be contiguous [>= {n}, {B}, {Cc}, 1, {T}], got {tuple(noise.shape)}')
         x0_last = torch.empty_like(x) if want_x0_last else None
+        if x_in_last is not None:        # the C side copies B * C * T floats into it
+            _lib.require_hip(x_in_last)
+            if not (tuple(x_in_last.shape) == tuple(x.shape) and x_in_last.dtype == torch.float32 and x_in_last.is_contiguous()
+                    and x_in_last.device == x.device):
+                raise ValueError(f'x_in_last must be a contiguous float32 tensor shaped like x {tuple(x.shape)} on {x.device}')
         if B == 0 or T == 0 or n == 0:
             return x0_last
         ws = nat.workspace(B, T)

@@ -246,6 +246,11 @@ class TrajNet(nn.Module):
         t_arr = np.ascontiguousarray(t_model, dtype=np.int64)
         c_arr = np.ascontiguousarray(coef, dtype=np.float32).reshape(-1)
         x0_last = torch.empty_like(x) if want_x0_last else None
+        if x_in_last is not None:        # the C side copies B * T * C floats into it
+            _lib.require_hip(x_in_last)
+            if not (tuple(x_in_last.shape) == tuple(x.shape) and x_in_last.dtype == torch.float32 and x_in_last.is_contiguous()
+                    and x_in_last.device == x.device):
+                raise ValueError(f'x_in_last must be a contiguous float32 tensor shaped like x {tuple(x.shape)} on {x.device}')
         if B == 0 or n == 0:
             return x0_last
         ws = nat.workspace(B, T)

@@ -21,14 +21,24 @@ PEAK_F32_TF, PEAK_HBM_TBS = 157.3, 8.0
 
 def main():
     n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    # model: 'dense' (the synthetic row-softmax weights: MFMA skinning unless ROHM_LBS_SKIN says otherwise) or 'sparse' (4 non-zero
+    # joints per vertex, like a released SMPLX_*.npz: ELL skinning)
+    model = sys.argv[2] if len(sys.argv) > 2 else 'dense'
     dev = torch.device('cuda', 0)
-    layer = SMPLXLayer.from_tensors(synth.synthetic_smplx_tensors(0)).to(dev)
+    t = synth.synthetic_smplx_tensors(0)
+    if model == 'sparse':
+        w = t['lbs_weights']
+        top = torch.topk(w, 4, dim=1)
+        sw = torch.zeros_like(w).scatter_(1, top.indices, top.values)
+        t['lbs_weights'] = sw / sw.sum(1, keepdim=True)
+    layer = SMPLXLayer.from_tensors(t).to(dev)
     nat = native_for(layer, dev)
     N = n_clips * 143
     g = torch.Generator().manual_seed(0)
     pose = (torch.randn(N, 22, 3, generator=g) * 0.4).to(dev)
     betas, transl = (torch.randn(N, 10, generator=g) * 0.5).to(dev), torch.randn(N, 3, generator=g).to(dev)
-    res = {'frames': N, 'vertices': nat.num_verts, 'joints': nat.num_joints}
+    res = {'frames': N, 'vertices': nat.num_verts, 'joints': nat.num_joints, 'model': model,
+           'skinning_mode': {0: 'mfma', 1: 'sparse-ell', 2: 'dense-ell (round-3 VALU form)'}[_lib.lib().rohm_smplx_skinning_mode(nat.handle)]}
     for want_verts in (True, False):
         for _ in range(3):
             lbs_forward(nat, pose, 0, betas, transl, want_verts)
@@ -46,7 +56,7 @@ def main():
         for name, r in rows.items():
             us = r['total_ms'] / r['launches'] * 1e3
             k = {'us': round(us, 1)}
-            if r['flops'] and name.startswith('gemm'):
+            if r['flops'] and (name.startswith('gemm') or name == 'lbs_skin_mfma'):
                 tf = r['flops'] / r['launches'] / (us * 1e-6) / 1e12
                 k.update(gflop=round(r['flops'] / r['launches'] / 1e9, 2), tflops=round(tf, 1), frac_f32_mfma=round(tf / PEAK_F32_TF, 3))
             if r['bytes']:

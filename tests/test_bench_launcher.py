@@ -131,7 +131,7 @@ def test_scheme_workload_under_force_dist_with_global_batch_guidance():
     recs = {}
     for sem in ('global', 'replica'):
         r = subprocess.run([sys.executable, BENCH, '--force-dist', '--workload', 'scheme', '--guidance-semantics', sem, '--steps', '1',
-                            '--warmup', '0', '--batch', '4', '--ddpm-steps', '60', '--no-cpu-baseline', '--no-extras'], env=env,
+                            '--warmup', '0', '--batch', '32', '--no-cpu-baseline', '--no-extras'], env=env,      # configs[2]'s per-GPU slice
                            capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         recs[sem] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])

@@ -173,6 +173,58 @@ def test_lbs_vertices_vs_oracle_with_face_and_hands():
     assert max_abs(out2.vertices.cpu(), ref2.vertices) < 2e-5
 
 
+def _sparse_model(t, keep=4):
+    """The synthetic body model with released-SMPL-X-like skinning weights: the `keep` largest weights of every vertex,
+    renormalised; everything else exactly zero (>= 75 % zeros -> the ELL path of rohm_smplx_set_skinning)."""
+    t = {k: v.clone() for k, v in t.items()}
+    w = t['lbs_weights']
+    top = torch.topk(w, keep, dim=1)
+    sw = torch.zeros_like(w).scatter_(1, top.indices, top.values)
+    t['lbs_weights'] = sw / sw.sum(1, keepdim=True)
+    return t
+
+
+@pytest.mark.parametrize('mode', ['mfma', 'sparse', 'ell'])
+@pytest.mark.parametrize('N', [1, 37, 143 * 2 + 5])
+def test_lbs_skinning_paths_vs_oracle(mode, N, monkeypatch):
+    """The three skinning kernels of rohm_smplx_forward against the oracle body model (smplx 0.1.28 `lbs` restated): dense
+    weights on the matrix core (T = W . A as an fp32-MFMA GEMM with the 12-fma apply in its epilogue), sparse weights through
+    per-vertex ELL rows (what a released SMPLX_*.npz looks like: chosen automatically at >= 75 % zeros), and the round-3 VALU form
+    (ROHM_LBS_SKIN=ell).  Frame counts that are not multiples of 16 / 8 exercise the partial groups."""
+    from rohm_amd._lib import lib
+    from rohm_amd.body_model import native_for
+    t = synth.synthetic_smplx_tensors(0)
+    if mode == 'sparse':
+        t = _sparse_model(t)
+        assert float((t['lbs_weights'] == 0).float().mean()) >= 0.75
+    if mode == 'ell':
+        monkeypatch.setenv('ROHM_LBS_SKIN', 'ell')
+    layer, body = _layer(t), G.BodyModel(t)
+    assert lib().rohm_smplx_skinning_mode(native_for(layer, torch.device(DEV)).handle) == {'mfma': 0, 'sparse': 1, 'ell': 2}[mode]
+    betas, go, bp, tr = seeded(11, N, 10), seeded(12, N, 3) * 0.8, seeded(13, N, 63) * 0.5, seeded(14, N, 3)
+    ref = body(betas=betas, global_orient=go, body_pose=bp, transl=tr, return_verts=True)
+    g = lambda a: a.to(DEV)
+    out = layer(betas=g(betas), global_orient=g(go), body_pose=g(bp), transl=g(tr), return_verts=True)
+    assert max_abs(out.vertices.cpu(), ref.vertices) < 2e-5
+    assert max_abs(out.joints[:, :55].cpu(), ref.joints[:, :55]) < 1e-5
+
+
+def test_lbs_zero_pose_invariants_on_the_sparse_path():
+    """with zero pose the body model reduces to its linear part -- vertices = v_template + shapedirs . beta
+    + transl and joints = J_regressor . v_shaped + transl -- for the sparse-weight path a real SMPLX_NEUTRAL.npz takes, so the
+    first machine with the real package only needs scripts/validate_smplx.py."""
+    t = _sparse_model(synth.synthetic_smplx_tensors(0))
+    layer = _layer(t)
+    N = 19
+    betas, tr = seeded(21, N, 10), seeded(22, N, 3)
+    z = torch.zeros(N, 3, device=DEV)
+    out = layer(betas=betas.to(DEV), global_orient=z, body_pose=torch.zeros(N, 63, device=DEV), transl=tr.to(DEV), return_verts=True)
+    v_shaped = t['v_template'][None].double() + torch.einsum('vck,nk->nvc', t['shapedirs'][:, :, :10].double(), betas.double())
+    assert max_abs(out.vertices.cpu(), v_shaped + tr[:, None].double()) < 5e-6
+    joints = torch.einsum('jv,nvc->njc', t['J_regressor'].double(), v_shaped) + tr[:, None].double()
+    assert max_abs(out.joints[:, :55].cpu(), joints) < 5e-6
+
+
 def test_repr_round_trip_on_the_device():
     """SURVEY §4 invariant (the author's debug note, dataloader_amass.py:230-236) through the HIP kernels: joints recovered
     by `rohm_repr_joints` from the representation that `get_repr_smplx` builds give the canonical joints back, for both
