@@ -417,6 +417,10 @@ int rohm_smplx_set_skinning(rohm_smplx_t* h, const float* v_template, const floa
     TRY(hipMalloc(&h->d_pdT, (size_t)h->NP * h->KP * sizeof(float)));
     if (h->d_wT) { (void)hipFree(h->d_wT); h->d_wT = nullptr; }       // [tiles_v * 144, 64]: the MFMA kernel's weight operand
     TRY(hipMalloc(&h->d_wT, (size_t)h->tiles_v * SKIN_BM * SKIN_K * sizeof(float)));
+    if (!h->d_zero_bias) {
+        TRY(hipMalloc(&h->d_zero_bias, (size_t)h->NP * sizeof(float)));
+        TRY(hipMemset(h->d_zero_bias, 0, (size_t)h->NP * sizeof(float)));
+    }
     if (h->d_ell_j) { (void)hipFree(h->d_ell_j); h->d_ell_j = nullptr; }
     if (h->d_ell_w) { (void)hipFree(h->d_ell_w); h->d_ell_w = nullptr; }
     TRY(hipMalloc(&h->d_ell_j, (size_t)h->ell_width * V * sizeof(int)));
@@ -457,7 +461,8 @@ int rohm_smplx_skinning_mode(const rohm_smplx_t* h) { return (h && h->d_pdT) ? h
 // [ceil(N / 16) * 192, 64] (MFMA mode)
 size_t rohm_smplx_lbs_workspace_bytes(const rohm_smplx_t* h, int N) {
     if (!h || N <= 0 || !h->d_pdT) return 0;
-    return (al64((size_t)N * h->KP) + al64((size_t)N * h->J * 12) + al64((size_t)N * h->NP) +
+    const size_t Np = (size_t)(N + 143) / 144 * 144;      // the blendshape GEMM runs on whole 144-row tiles (its hot instantiation)
+    return (al64(Np * h->KP) + al64((size_t)N * h->J * 12) + al64(Np * h->NP) +
             al64((size_t)((N + 15) / 16) * SKIN_BN * SKIN_K)) * sizeof(float);
 }
 
@@ -474,10 +479,11 @@ int rohm_smplx_forward(const rohm_smplx_t* h, const float* pose, int n_pose, int
     ROHM_ARG_CHECK(N <= 65535, "smplx_forward: at most 65535 frames per call (got %d)", N);
     ROHM_ARG_CHECK(ws_bytes >= rohm_smplx_lbs_workspace_bytes(h, N), "smplx_forward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    const size_t Np = (size_t)(N + 143) / 144 * 144;
     float* feat = (float*)ws;
-    float* A = feat + al64((size_t)N * h->KP);
+    float* A = feat + al64(Np * h->KP);
     float* vposed = A + al64((size_t)N * h->J * 12);
-    float* Tm = vposed + al64((size_t)N * h->NP);
+    float* Tm = vposed + al64(Np * h->NP);
     const int groups = (N + 15) / 16;
     const bool mfma = verts && h->skin_mode == 0;
     {
@@ -494,7 +500,9 @@ int rohm_smplx_forward(const rohm_smplx_t* h, const float* pose, int n_pose, int
     if (!verts) return ROHM_OK;
     GemmParams g{};      // v_posed = v_template + shapedirs . beta + posedirs . pose_feature
     g.A = feat; g.lda = h->KP; g.W = h->d_pdT; g.ldw = h->KP; g.C = vposed; g.ldc = h->NP;
-    g.M = N; g.N = h->NP; g.K = h->KP; g.bias = nullptr;
+    // whole tiles + a (zero) bias vector select the GEMM's hot instantiation (no edge masks, operands requested under the last K
+    // chunk); the pad rows of `feat` hold whatever the workspace held: they only produce pad rows of v_posed, which nobody reads
+    g.M = (int)Np; g.N = h->NP; g.K = h->KP; g.bias = h->d_zero_bias;
     int rc = launch_gemm(g, EPI_BIAS, s);
     if (rc) return rc;
     if (mfma) {

@@ -591,6 +591,7 @@ void rohm_smplx_destroy(rohm_smplx_t* h) {
     if (h->d_wT) (void)hipFree(h->d_wT);
     if (h->d_ell_j) (void)hipFree(h->d_ell_j);
     if (h->d_ell_w) (void)hipFree(h->d_ell_w);
+    if (h->d_zero_bias) (void)hipFree(h->d_zero_bias);
     delete h;
 }
 

@@ -32,6 +32,7 @@ struct rohm_smplx {
     int ell_width;     // entries per ELL row
     int* d_ell_j;      // [ell_width, V]  joint indices
     float* d_ell_w;    // [ell_width, V]  weights (0 = padding)
+    float* d_zero_bias; // [NP] zeros: the blendshape GEMM's bias operand
 };
 
 namespace rohm {
