@@ -743,6 +743,10 @@ def main(argv=None):
                               if prof.get('attention', {}).get('total_ms') else None),
                 'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
                 'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,
+                # round 4: the out-projection / FF2 launches (`gemm_bias_res_ln`) carry the LayerNorm that used to be 16 separate
+                # launches per step; their time counts here against the GEMM's 2 M N K flops only
+                'note': ('GEMM time includes the LayerNorm work fused into the out-projection / FF2 launches (gemm_bias_res_ln); rounds 1-3 '
+                         'timed LayerNorm as its own kernel outside this family') if any(k.startswith('gemm_bias_res_ln') for k in gemm) else None,
                 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
                 'kernels': kernels,
             },
