@@ -376,13 +376,15 @@ def _diffusions(S_T, S_P, noise, log=None):
             'posenet': Recording(d_p, log, 'pose')}, d_p
 
 
-@pytest.mark.parametrize('ci', range(3))
+@pytest.mark.parametrize('ci', range(5))
 def test_free_running_scheme_vs_reference_golden(ci):
     """BASELINE configs[2] / [4] end to end, FREE-RUNNING, against the reference itself: tests/golden/scheme_real.npz holds
     what test_amass_full.py:217-384 / test_prox_egobody.py:214-324 (the scripts' own text) produced with the reference's own
     TrajNet / TrajControl / PoseNet and samplers on CPU (B = 2; AMASS two iterations; PROX three iterations with the
     visibility mask and early_stop; PROX two iterations whose PoseNet stage is the reference's guided step over t = 103..99
-    at its own weights).  Here rohm_amd.inference runs the same thing on the HIP networks with the same noise stream --
+    at its own weights; and cases 3 / 4: the same AMASS / PROX schemes at the drivers' REAL step counts -- TrajNet 100, PoseNet 1000
+    (980 with early_stop) -- i.e. BASELINE configs[2] and [4] un-guided, 2200 / 3240 denoising steps free-running).
+    Here rohm_amd.inference runs the same thing on the HIP networks with the same noise stream --
     TrajNet -> rohm_traj_rederive -> PoseNet -> TrajControl -> PoseNet [...] without teacher forcing.  Bar: 1e-3 (north star)."""
     from helpers import cpu_noise_stream, golden
     from oracle.make_golden import (SCHEME_REAL_CAM_T, SCHEME_REAL_CASES, SCHEME_REAL_HEAD_T, SCHEME_REAL_SEEDS,
@@ -406,7 +408,8 @@ def test_free_running_scheme_vs_reference_golden(ci):
     pose, traj, recs = fn(args, models, diffs, _clone(bt, DEV), gbp, tds, pds, layer)
     pre = f'case{ci}_'
     assert len(log) == int(g[pre + 'n_stages'])
-    errs = [max_abs(o, torch.from_numpy(g[pre + f'stage{k}_out'])) for k, (_, _, o) in enumerate(log)]
+    errs = [max_abs(o, torch.from_numpy(g[pre + f'stage{k}_out'])) if pre + f'stage{k}_out' in g else float('nan')
+            for k, (_, _, o) in enumerate(log)]          # the long cases store the trajectory stages only
     e_pose, e_traj = max_abs(pose.cpu(), torch.from_numpy(g[pre + 'pose'])), max_abs(traj.cpu(), torch.from_numpy(g[pre + 'traj']))
     e_rec = max_abs(recs[-1].cpu(), torch.from_numpy(g[pre + 'traj_rec_full']))
     print(f'\nfree-running scheme case {ci} ({kind}, PoseNet {pose_steps}): per-stage max|HIP - reference| =',

@@ -42,7 +42,8 @@ def oracle_free_run(ci):
     return pose, traj, recs, outs
 
 
-@pytest.mark.parametrize('ci', range(len(SCHEME_REAL_CASES)))
+# cases 3, 4 (the drivers' real step counts, 2000-3000 PoseNet steps on the CPU oracle) are held by the GPU test only: minutes of CPU here
+@pytest.mark.parametrize('ci', range(3))
 def test_free_running_scheme_vs_reference(ci):
     g = golden('scheme_real.npz')
     assert int(g['n_cases']) == len(SCHEME_REAL_CASES)
