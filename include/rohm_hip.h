@@ -81,8 +81,8 @@ int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, i
 
 /* C = LayerNorm(A . W^T + bias + R) * gamma + beta in ONE launch -- the post-norm sublayer tail of nn.TransformerEncoderLayer
  * (model/posenet.py:63-69: x = norm1(x + out_proj(attn)), x = norm2(x + linear2(...)); `norm_first=False`), eps inside the root,
- * biased variance over the N columns.  The N / 64 or N / 128 column tiles of a 144-row tile exchange their per-row (sum, sum of
- * squares) through L2 while the kernel runs (they are dispatched back to back onto one XCD), so LN(x) is stored once and the raw
+ * biased variance over the N columns.  The N / 64 or N / 128 column tiles of a 144-row tile exchange their per-row (mean, M2)
+ * (merged pairwise by Chan's update: two-pass stability) through L2 while the kernel runs (they are dispatched back to back onto one XCD), so LN(x) is stored once and the raw
  * sum never reaches HBM.  Shapes: M % 144 == 0, K % 32 == 0, N / 64 or N / 128 in {1, 2, 4, 8} (else ROHM_ERR_UNSUPPORTED:
  * use rohm_gemm_f32(epi 2) + rohm_layernorm_f32).  `scratch`: rohm_gemm_res_layernorm_scratch_bytes(M, N) bytes, 64-byte aligned,
  * owned by the caller for the duration of the launch (counters + statistics; cleared by this call). */

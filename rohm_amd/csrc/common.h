@@ -126,9 +126,9 @@ struct GemmParams {
     int ln_dim; float ln_eps;
     // ---- LayerNorm INSIDE the producer (EPI_BIAS_RES_LN; post-norm nn.TransformerEncoderLayer, model/posenet.py:63-69:
     // x = norm(x + sublayer(x))).  The N / BN column tiles of a row tile run at the same time on CUs of ONE XCD (the kernel's own
-    // block -> tile map); each publishes its 144 per-row (sum, sum of squares) pairs in xln_stats[row tile][column tile][144][4]
-    // as (sum, tag, sum of squares, tag) with ONE 16-byte store per row, polls the partner tiles' slots until they carry this
-    // launch's tag (xln_epoch: unique per launch, set by launch_gemm), sums the pairs in column-tile order (every tile gets
+    // block -> tile map); each publishes its 144 per-row (mean, M2) pairs in xln_stats[row tile][column tile][144][4]
+    // as (mean, tag, M2, tag) with ONE 16-byte store per row, polls the partner tiles' slots until they carry this
+    // launch's tag (xln_epoch: unique per launch, set by launch_gemm), merges the pairs by Chan's update in a fixed tree over the tile index (every tile gets
     // bit-identical statistics), normalises its accumulators in registers and stores LN(x) once.  *xln_err is set if a wait ran
     // into its bound (never on a healthy device: the partner tiles are co-resident by construction).  Not for hipGraph capture
     // (a replay would repeat the tag).

@@ -604,10 +604,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         // C = LayerNorm(acc + bias + R): see GemmParams::xln_*.  FULL, 16x16 layouts (BN <= 128) only -- the launcher sees to it.
         static_assert(!M32 && !CONV && FULL && PRE, "EPI_BIAS_RES_LN: 144 x 64 / 144 x 128 tiles of whole problems only");
         if constexpr (!EARLY) request_ops();
-        // 1. x = (acc + bias) + R in the accumulator registers (the order of the un-fused path); per-row partial sums
-        float ps[NRB], pq[NRB];
-#pragma unroll
-        for (int r = 0; r < NRB; ++r) { ps[r] = 0.f; pq[r] = 0.f; }
+        // 1. x = (acc + bias) + R in the accumulator registers (the order of the un-fused path)
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
@@ -615,42 +612,67 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 f32x4& a = acc16[r * NCB + c];
                 const f32x4 rr = res[c * NRB + r];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    a[q] = (a[q] + col[c].bias[q]) + rr[q];
-                    ps[r] += a[q];
-                    pq[r] += a[q] * a[q];
-                }
+                for (int q = 0; q < 4; ++q) a[q] = (a[q] + col[c].bias[q]) + rr[q];
             }
-        // 2. a row's columns of this wave live in the 4 lanes li + 16 lg: two lane swaps (VALU, no LDS crossbar), then the 4 waves
-        //    meet in LDS
+        // 2. row statistics as (mean, M2 = sum of squares about that mean) of equal-sized parts, merged pairwise by Chan's update
+        //        mean = (m_a + m_b) / 2,   M2 = M2_a + M2_b + n (m_b - m_a)^2 / 2        (n = elements per part)
+        //    at every level: the lane's own 4 NCB columns (two-pass in registers), the 4 lanes li + 16 lg of a row (two lane swaps on
+        //    the VALU), the 4 waves (LDS), the partner tiles (L2).  As stable as nn.LayerNorm's own two-pass kernel -- no
+        //    E[x^2] - mu^2 cancellation for rows far from zero -- at the price of a few VALU operations, no extra barrier.
         typedef unsigned rohm_u2 __attribute__((ext_vector_type(2)));
-        auto lg_sum = [](float v) __attribute__((always_inline)) {
-            rohm_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-            v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-            t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-            return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        auto merge_swap = [](float& m, float& q2, float n, bool far) __attribute__((always_inline)) {
+            rohm_u2 tm, tq;
+            if (far) { tm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                       tq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q2), __float_as_uint(q2), false, false); }
+            else     { tm = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                       tq = __builtin_amdgcn_permlane16_swap(__float_as_uint(q2), __float_as_uint(q2), false, false); }
+            const float ma = __uint_as_float(tm[0]), mb = __uint_as_float(tm[1]);
+            const float d = mb - ma;
+            m = 0.5f * (ma + mb);
+            q2 = (__uint_as_float(tq[0]) + __uint_as_float(tq[1])) + 0.5f * n * d * d;
         };
-        float* part = lds_dummy + 512;                  // [4 waves][BM][2]; afterwards [BM][2] = (mu, rstd)
+        float* const part = lds_dummy + 512;            // [4 waves][BM][2] (mean, M2) of a wave's columns; afterwards [BM][2] = (mu, rstd)
+        constexpr float kLane = (float)(4 * NCB);       // elements per lane and row
 #pragma unroll
         for (int r = 0; r < NRB; ++r) {
-            const float a = lg_sum(ps[r]), b = lg_sum(pq[r]);
-            if (lg == 0) *reinterpret_cast<f32x2*>(part + (wave * BM + r * 16 + li) * 2) = f32x2{a, b};
+            float sm = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sm += acc16[r * NCB + c][k];
+            float m = sm * (1.0f / kLane), q2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float d = acc16[r * NCB + c][k] - m; q2 += d * d; }
+            merge_swap(m, q2, kLane, true);             // lanes l and l ^ 32
+            merge_swap(m, q2, 2.0f * kLane, false);     // ... and l ^ 16: the wave's WN columns of the row
+            if (lg == 0) *reinterpret_cast<f32x2*>(part + (wave * BM + r * 16 + li) * 2) = f32x2{m, q2};
         }
         __syncthreads();
         const int g = m0 / BM, tn = n0 / BN;
-        // 3. publish this tile's pair of every row and collect the partner tiles' pairs.  A slot is 16 bytes (sum, tag, sum of
-        //    squares, tag) written by ONE store: each 8-byte half carries the launch's tag, so a reader that sees both tags has
-        //    the data (no separate flag, no wait for the store's acknowledgement, no counter to re-arm: three dependent trips to
-        //    L2 less than publish / count / poll).  Pairs are summed in column-tile order with the own pair taken from registers at
-        //    its place: every tile of the row gets bit-identical statistics whatever the arrival order.
+        // 3. publish this tile's (mean, M2) of every row and collect the partner tiles'.  A slot is 16 bytes (mean, tag, M2, tag)
+        //    written by ONE store: each 8-byte half carries the launch's tag, so a reader that sees both tags has the data (no
+        //    separate flag, no wait for the store's acknowledgement, no counter to re-arm: three dependent trips to L2 less than
+        //    publish / count / poll).  Tiles are merged in a fixed tree over the column-tile index with the own pair taken from
+        //    registers at its place: every tile of the row gets bit-identical statistics whatever the arrival order.
         float* const row_stats = p.xln_stats + ((size_t)g * tiles_n * BM) * 4;
         const unsigned tag = p.xln_epoch;
         if (tid < BM) {
-            float a = 0.f, b = 0.f;
+            auto merge = [](float ma, float qa, float mb, float qb, float n, float& m, float& q2) __attribute__((always_inline)) {
+                const float d = mb - ma;
+                m = 0.5f * (ma + mb);
+                q2 = (qa + qb) + 0.5f * n * d * d;
+            };
+            f32x2 w4[4];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { const f32x2 v = *reinterpret_cast<const f32x2*>(part + (w * BM + tid) * 2); a += v[0]; b += v[1]; }
+            for (int w = 0; w < 4; ++w) w4[w] = *reinterpret_cast<const f32x2*>(part + (w * BM + tid) * 2);
+            float m01, q01, m23, q23, a, b;
+            merge(w4[0][0], w4[0][1], w4[1][0], w4[1][1], (float)WN, m01, q01);
+            merge(w4[2][0], w4[2][1], w4[3][0], w4[3][1], (float)WN, m23, q23);
+            merge(m01, q01, m23, q23, 2.0f * (float)WN, a, b);                     // this tile's BN columns of row tid
             *reinterpret_cast<f32x4*>(row_stats + ((size_t)tn * BM + tid) * 4) = f32x4{a, __uint_as_float(tag), b, __uint_as_float(tag)};
-            float sm = 0.f, sq = 0.f;
+            float mk[8], qk[8];
             for (int it = 0;; ++it) {
                 unsigned long long lo[8], hi[8];
 #pragma unroll
@@ -663,14 +685,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     }
                 }
                 bool ok = true;
-                sm = 0.f; sq = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
+                    mk[k] = 0.f; qk[k] = 0.f;
                     if (k >= tiles_n) continue;
-                    if (k == tn) { sm += a; sq += b; continue; }
+                    if (k == tn) { mk[k] = a; qk[k] = b; continue; }
                     ok = ok && (unsigned)(lo[k] >> 32) == tag && (unsigned)(hi[k] >> 32) == tag;
-                    sm += __uint_as_float((unsigned)lo[k]);
-                    sq += __uint_as_float((unsigned)hi[k]);
+                    mk[k] = __uint_as_float((unsigned)lo[k]);
+                    qk[k] = __uint_as_float((unsigned)hi[k]);
                 }
                 if (ok) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -679,22 +701,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     break;
                 }
             }
-            const float inv = 1.0f / (float)p.ln_dim;
-            const float mu = sm * inv;
-            const float var = fmaxf(sq * inv - mu * mu, 0.f);
+            // tiles_n is 1, 2, 4 or 8: a balanced tree over the tile index (static indices: the arrays stay in registers)
+            constexpr float kT = (float)BN;
+            if (tiles_n > 1) {
+                merge(mk[0], qk[0], mk[1], qk[1], kT, mk[0], qk[0]);
+                if (tiles_n > 2) merge(mk[2], qk[2], mk[3], qk[3], kT, mk[2], qk[2]);
+                if (tiles_n > 4) { merge(mk[4], qk[4], mk[5], qk[5], kT, mk[4], qk[4]); merge(mk[6], qk[6], mk[7], qk[7], kT, mk[6], qk[6]); }
+            }
+            if (tiles_n > 2) {
+                merge(mk[0], qk[0], mk[2], qk[2], 2.0f * kT, mk[0], qk[0]);
+                if (tiles_n > 4) merge(mk[4], qk[4], mk[6], qk[6], 2.0f * kT, mk[4], qk[4]);
+            }
+            if (tiles_n > 4) merge(mk[0], qk[0], mk[4], qk[4], 4.0f * kT, mk[0], qk[0]);
+            const float mu = mk[0];
+            const float var = qk[0] / (float)p.ln_dim;
             *reinterpret_cast<f32x2*>(part + tid * 2) = f32x2{mu, 1.0f / sqrtf(var + p.ln_eps)};      // own row of wave 0's zone: read above
         }
         __syncthreads();
         // 4. normalise in registers, store LN(x) once
 #pragma unroll
         for (int r = 0; r < NRB; ++r) {
-            const f32x2 mr = *reinterpret_cast<const f32x2*>(part + (r * 16 + li) * 2);
+            const f32x2 mrv = *reinterpret_cast<const f32x2*>(part + (r * 16 + li) * 2);
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
                 const f32x4 a = acc16[r * NCB + c];
                 f32x4 v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (a[q] - mr[0]) * mr[1] * col[c].g4[q] + col[c].b4[q];
+                for (int q = 0; q < 4; ++q) v[q] = (a[q] - mrv[0]) * mrv[1] * col[c].g4[q] + col[c].b4[q];
                 *reinterpret_cast<f32x4*>(p.C + (size_t)(m0 + r * 16 + li) * p.ldc + nw + c * 16 + lg * 4) = v;
             }
         }
@@ -876,7 +909,7 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     // 160 KiB LDS pins the residency to one.
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float) + lds_pad;
     lds += 2048;                           // landing zone of the dummy DMA pieces
-    lds += 4 * BM * 2 * sizeof(float);     // row-stat exchange of the LayerNorm-producing epilogue
+    lds += 4 * BM * 2 * sizeof(float);     // row-stat exchange of the LayerNorm-producing epilogues
     const size_t lds_need = lds;
     if (lds < 84 * 1024 && !occ2 && p.wg_per_cu < 2) lds = 84 * 1024;
     static bool attr_set[64] = {};

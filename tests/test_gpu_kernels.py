@@ -70,6 +70,25 @@ def test_gemm_res_layernorm(M, N, K):
         assert torch.equal(ops.gemm_res_layernorm(*args), out)
 
 
+@pytest.mark.parametrize('M', [144 * 64, 144 * 32])
+def test_gemm_res_layernorm_rows_far_from_zero(M):
+    """Rows whose mean is hundreds of standard deviations away from zero: the fused statistics are two-pass per tile and combined by
+    Chan's update across the partner tiles, so they are as stable as nn.LayerNorm's own kernel -- a one-pass E[x^2] - mu^2 over fp32
+    sums would lose the variance here."""
+    from rohm_amd import ops
+    N, K = 512, 512
+    a, w = seeded(M + 1, M, K), seeded(K + 8, N, K) / math.sqrt(K)
+    bias, g, b = seeded(3, N), seeded(5, N) * 0.5 + 1.0, seeded(6, N)
+    res = seeded(4, M, N) + (seeded(9, M, 1) * 150.0)              # per-row offsets of up to ~600
+    ref = nets.layer_norm(a.double() @ w.double().T + bias.double() + res.double(), g.double(), b.double())
+    d = _dev()
+    args = [t.to(d) for t in (a, w, bias, res, g, b)]
+    out = ops.gemm_res_layernorm(*args)
+    two = ops.layernorm_(ops.gemm(args[0], args[1], args[2], args[3], 2), args[4], args[5])
+    e_fused, e_two = max_abs(out.cpu(), ref), max_abs(two.cpu(), ref)
+    assert e_two < 5e-4 and e_fused < 5e-4, (e_fused, e_two)       # fp32 resolution of x ~ 600 is 6e-5: both paths sit at it
+
+
 def test_gemm_res_layernorm_refuses_other_shapes():
     from rohm_amd import _lib, ops
     d = _dev()
