@@ -117,6 +117,12 @@ def main():
         ok &= report('LBS path, joints[:, :55]', hv.joints.cpu()[:, :55], ref.joints[:, :55])
         ok &= report('LBS path, vertices', hv.vertices.cpu(), ref.vertices)
         checked += 3
+        from rohm_amd import _lib
+        from rohm_amd.body_model import native_for
+        mode = _lib.lib().rohm_smplx_skinning_mode(native_for(layer, torch.device('cuda', 0)).handle)
+        zeros_frac = float((tensors['lbs_weights'] == 0).float().mean())
+        print(f'  skinning path taken: {({0: "dense (MFMA)", 1: "sparse (ELL rows)", 2: "ELL rows of all joints"}).get(mode, mode)}; '
+              f'{zeros_frac:.1%} of lbs_weights are zero')
     else:
         print('no AMD GPU visible: the HIP kernels were not exercised')
     print(f'{checked} comparisons, {"all within" if ok else "NOT all within"} {TOL} m')
