@@ -1,4 +1,11 @@
-import sys, types, warnings; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+#!/usr/bin/env python
+"""Build container only (needs /root/reference): the reference's own p_sample_with_grad(grad_type='prox') against oracle/diffusion.py, both
+fp32 on the CPU, free-running from the same start and noise over the guided head t = 106 .. 95 -- once from a th.randn start (what a PoseNet
+stage of the drivers starts from) and once from a plausible motion.  Shows why the guided case of tests/golden/scheme_real.npz stops at
+t = 99 (profiles/r4_scheme_head_chaos.txt)."""
+import os, sys, types, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 warnings.filterwarnings('ignore')
 import torch, numpy as np
 from oracle import refload, geometry as G, diffusion as odiff, nets
