@@ -134,6 +134,7 @@ struct GemmParams {
     // (a replay would repeat the tag).
     const float* ln_gamma; const float* ln_beta;
     float* xln_stats; unsigned* xln_err; unsigned xln_epoch;
+    unsigned* xln_xcc;      // [tiles_m][8]: XCD id + 1 of the workgroup that ran each tile (diagnostic: the tests assert the co-location)
 };
 // EPI_BIAS_RES_LN: can launch_gemm run (M, N, ...) with the in-kernel LayerNorm?  Scratch = stats + flags + error word.
 bool gemm_ln_supported(int M, int N, int K);

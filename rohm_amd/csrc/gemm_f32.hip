@@ -651,6 +651,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
         __syncthreads();
         const int g = m0 / BM, tn = n0 / BN;
+        // (which XCD this tile ran on: the co-location the exchange relies on is checked by the tests, not assumed)
+        if (tid == 0) p.xln_xcc[g * 8 + tn] = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
         // 3. publish this tile's (mean, M2) of every row and collect the partner tiles'.  A slot is 16 bytes (mean, tag, M2, tag)
         //    written by ONE store: each 8-byte half carries the launch's tag, so a reader that sees both tags has the data (no
         //    separate flag, no wait for the store's acknowledgement, no counter to re-arm: three dependent trips to L2 less than
@@ -1052,16 +1054,19 @@ bool gemm_ln_supported(int M, int N, int K) {
     return M > 0 && M % BM == 0 && K > 0 && K % BK == 0 && N > 0 && ln_tile_width(M / BM, N) != 0;
 }
 
-// scratch layout: [error word, 64 B] [statistics: tiles_m x 8 column tiles x 144 rows x (sum, tag, sum of squares, tag)]
+// scratch layout: [error word, 64 B] [statistics: tiles_m x 8 column tiles x 144 rows x (mean, tag, M2, tag)] [XCD id + 1 of every tile:
+// tiles_m x 8 words]
 size_t gemm_ln_zero_bytes(int M) { (void)M; return 64; }
+static size_t ln_stats_bytes(int M) { return (size_t)((M + BM - 1) / BM) * 8 * BM * 4 * sizeof(float); }
 size_t gemm_ln_scratch_bytes(int M, int N) {
     (void)N;
-    return 64 + (size_t)((M + BM - 1) / BM) * 8 * BM * 4 * sizeof(float);
+    return 64 + ln_stats_bytes(M) + (size_t)((M + BM - 1) / BM) * 8 * sizeof(unsigned);
 }
 void gemm_ln_bind(GemmParams& p, void* scratch) {
     char* c = static_cast<char*>(scratch);
     p.xln_err = reinterpret_cast<unsigned*>(c);
     p.xln_stats = reinterpret_cast<float*>(c + 64);
+    p.xln_xcc = reinterpret_cast<unsigned*>(c + 64 + ln_stats_bytes(p.M));
 }
 
 static int launch_ln(const GemmParams& p, hipStream_t s) {

@@ -65,6 +65,16 @@ def test_gemm_res_layernorm(M, N, K):
     torch.cuda.synchronize()
     words = scratch.cpu()
     assert int(words[0]) == 0, 'a partner wait ran into its bound'
+    # the exchange goes through ONE L2: every column tile of a row tile must have run on the same XCD (the kernel's block -> tile
+    # map relies on the hardware placing block b on XCD b % 8); the kernel records where each tile ran
+    tm = M // 144
+    ok = lambda bn: N % bn == 0 and N // bn in (1, 2, 4, 8)
+    bn = 128 if (ok(128) and tm * (N // 128) >= 256) else (64 if ok(64) else 128)            # gemm_f32.hip ln_tile_width
+    tiles_n = N // bn
+    xcc = words[16 + tm * 8 * 144 * 4:16 + tm * 8 * 144 * 4 + tm * 8].view(tm, 8)[:, :tiles_n]
+    assert int(xcc.min()) >= 1 and bool((xcc == xcc[:, :1]).all()), 'partner tiles ran on different XCDs'
+    if tm >= 8:
+        assert len(set(xcc[:, 0].tolist())) == 8, 'row tiles should be spread over all 8 XCDs'
     # race screen: 50 launches, same bits (statistics summed in tile order whatever the arrival order)
     for _ in range(50):
         assert torch.equal(ops.gemm_res_layernorm(*args), out)
