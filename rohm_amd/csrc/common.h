@@ -113,6 +113,10 @@ struct GemmParams {
     int ksplit; float* partial; int ld_partial;
     int ksplit_defer;            // 1: leave the partial slabs un-reduced (the consumer sums them: trajnet.hip GroupNorm)
     int wg_per_cu;               // 2: let two workgroups share a CU (narrow tiles of latency-bound launches); else one is pinned
+    // fused [conv5 | 1x1 residual] launch (trajnet.hip): columns >= res_col0 are the residual conv, whose weight is zero outside the
+    // centre tap -- their tiles contract over the res_nk chunks starting at K offset res_k0 only, split res_ksplit ways (their slabs
+    // are slabs 0 .. res_ksplit - 1 of `partial`; res_ksplit <= 1: they finish in the launch and store to C).  0 = off.
+    int res_col0, res_ksplit, res_k0, res_nk;
     // ---- LayerNorm folded into the GEMMs around it (posenet.hip).  A producer (bias+residual epilogue) writes
     // per-row partial sums of its OUTPUT, one (sum, sum of squares) pair per column tile: out_stats[m][tile_n][2].
     // A consumer whose normalised operand is LN(x) = (x - mu) rstd gamma + beta runs on the RAW x with

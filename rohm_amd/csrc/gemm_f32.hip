@@ -126,10 +126,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     if constexpr (VAR == 7) ts_wall[0] = wall_clock64();
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
-    const int split = (ksplit > 1) ? (int)(blockIdx.x % ksplit) : 0;
+    int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
+    int split = (ksplit > 1) ? (int)(blockIdx.x % ksplit) : 0;
     int m0, n0;
-    if constexpr (EPI == EPI_BIAS_RES_LN) {
+    // chunks of K this launch's tiles contract over, and where they start: all of K -- except for the 1x1 residual columns of a
+    // fused [conv5 | residual] launch (trajnet.hip), whose weights are zero outside the centre tap: those tiles walk the centre
+    // tap's chunks only, with their own split count
+    int nk_all = p.K / BK, k_first = 0;
+    if (CONV && EPI == EPI_BIAS && p.res_col0 > 0) {
+        const int tiles_nc = p.res_col0 / BN, tiles_nr = tiles_n - tiles_nc;
+        const int wg_c = tiles_m * tiles_nc * ksplit;
+        if ((int)blockIdx.x < wg_c) {
+            const int tile = xcd_remap(blockIdx.x / ksplit, tiles_m * tiles_nc);
+            m0 = (tile / tiles_nc) * BM;
+            n0 = (tile % tiles_nc) * BN;
+        } else {
+            const int rb = (int)blockIdx.x - wg_c;
+            ksplit = p.res_ksplit > 1 ? p.res_ksplit : 1;
+            split = rb % ksplit;
+            const int tile = xcd_remap(rb / ksplit, tiles_m * tiles_nr);
+            m0 = (tile / tiles_nr) * BM;
+            n0 = (tiles_nc + tile % tiles_nr) * BN;
+            nk_all = p.res_nk;
+            k_first = p.res_k0;
+        }
+    } else if constexpr (EPI == EPI_BIAS_RES_LN) {
         // The tiles_n column tiles of a row tile exchange their row statistics while they run, so they must sit on ONE XCD (one
         // L2: the exchange never leaves it) and be handed out back to back (co-resident: nobody waits for a tile that cannot
         // start).  Hardware places block b on XCD b % 8 in block order, so the j-th block of XCD x takes column tile
@@ -306,10 +327,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // 7 = shipped schedule + per-workgroup phase timestamps written to p.R (scripts/gemm_timeline.py).
     // split-K: this workgroup owns chunks [kc0, kc0 + nk) of the K / BK chunks (the first K/BK % ksplit splits
     // take one more)
-    const int nk_all = p.K / BK;
     const int nk = nk_all / ksplit + (split < nk_all % ksplit ? 1 : 0);
     const int kc0 = split * (nk_all / ksplit) + (split < nk_all % ksplit ? split : nk_all % ksplit);
-    const int kbase = kc0 * BK;
+    const int kbase = k_first + kc0 * BK;
     // 384-wide tile (QKV): no registers to keep 18 column groups of bias during the loop, and a global load behind the loop is a
     // round trip in front of 54 stores per lane -- the tile's bias row goes through LDS instead (an LDS read is not ordered
     // against the stores to C): two LDS-DMA pieces of wave 0 in front of chunk 0's (older, so the prologue's counted wait covers
@@ -896,6 +916,8 @@ template <int BN, int EPI, int VAR = 0, bool FULL = false, bool CONV = false>
 static int launch_one(const GemmParams& p, hipStream_t s) {
     const int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
     int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * ksplit;
+    if (CONV && EPI == EPI_BIAS && p.res_col0 > 0)      // conv tiles x their splits, then the residual-column tiles x theirs
+        tiles = ((p.M + BM - 1) / BM) * ((p.res_col0 / BN) * ksplit + (((p.N + BN - 1) / BN) - p.res_col0 / BN) * (p.res_ksplit > 1 ? p.res_ksplit : 1));
     if (EPI == EPI_BIAS_RES_LN)      // row tiles dealt round-robin to the XCDs, rounded up to a multiple of 8 (the kernel's own map)
         tiles = (((p.M + BM - 1) / BM + kNumXCD - 1) / kNumXCD) * kNumXCD * ((p.N + BN - 1) / BN);
 #ifdef ROHM_GEMM_DIAGNOSTICS
@@ -938,7 +960,8 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_f32_kernel<BN, EPI, VAR, FULL, CONV>), dim3(tiles), dim3(256), lds, s, p);
     ROHM_LAUNCH_CHECK();
     }
-    if (ksplit > 1 && !p.ksplit_defer) {
+    if ((ksplit > 1 || (p.res_col0 > 0 && p.res_ksplit > 1)) && !p.ksplit_defer) {
+        if (p.res_col0 > 0) { set_error("gemm: a fused [conv | residual] launch must leave its split-K slabs to the consumer"); return ROHM_ERR_ARG; }
         prof::Scope pr("splitk_reduce", 0.0, 4.0 * ((double)ksplit + 1.0) * p.M * p.N, s);
         const long n = (long)p.M * ((p.N + 3) / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.partial, ksplit, p.M,
@@ -1102,6 +1125,11 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
                            (((uintptr_t)p.partial) & 15) == 0 && p.ksplit <= p.K / BK,
                        "gemm: bad split-K workspace (ksplit=%d, K chunks=%d)", p.ksplit, p.K / BK);
     }
+    if (p.res_col0 > 0)
+        ROHM_ARG_CHECK(epi == EPI_BIAS && p.conv_taps > 0 && p.res_col0 % 64 == 0 && p.res_col0 < p.N && p.res_nk > 0 && p.res_k0 % BK == 0 &&
+                           p.res_k0 + p.res_nk * BK <= p.K && (p.res_ksplit <= 1 || (p.res_ksplit <= p.res_nk && p.res_ksplit <= p.ksplit)) &&
+                           (long)((p.M + BM - 1) / BM) * ((p.N + 127) / 128) < 256,
+                       "gemm: bad fused-residual request");
     if (p.conv_taps > 0) {
         ROHM_ARG_CHECK(p.conv_taps <= 5 && p.conv_cin_pad % BK == 0 && p.K == p.conv_taps * p.conv_cin_pad,
                        "gemm: conv gather needs cin_pad %% 32 == 0 and K == taps * cin_pad");

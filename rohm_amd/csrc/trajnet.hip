@@ -456,9 +456,39 @@ static void plan_split(GemmParams& g, float* buf = nullptr, SplitInfo* defer = n
     }
 }
 
+// Split plan of a fused [conv5 | 1x1 residual] launch (res_block): the residual columns' weights are zero outside the centre tap, so
+// their tiles walk K / 5 chunks and the workgroup slots they do not need go to the conv tiles as extra splits.  Returns false (plain
+// plan_split) where the two column ranges share tiles (cout % 64) or nothing is split anyway.
+static std::atomic<int> g_res_centre_tap{1};      // ROHM_TRAJ_RES_TAP=0 (read at create) keeps the uniform plan
+static bool plan_fused_residual(GemmParams& g, int co, float* buf, SplitInfo* defer, SplitInfo* defer_res) {
+    if (!g_res_centre_tap.load(std::memory_order_relaxed) || !buf || !defer || !defer_res || co % 64 != 0 || g.conv_taps != 5) return false;
+    const int tm = (g.M + 143) / 144, t = tm * (co / 64);            // conv tiles = residual tiles = t (144 x 64 tiles)
+    const int slots = 256, nkr = g.conv_cin_pad / 32, nkc = g.K / 32, minc = g_split_min_chunks.load(std::memory_order_relaxed);
+    if (2 * t > slots / 2) return false;
+    // split counts that fill the slots and balance the chunks per workgroup of the two kinds of tile: smallest max(conv, residual) chunks
+    int Sr = 1, Sc = 0, best = 1 << 30;
+    for (int r = 1; r <= std::max(1, nkr / minc) && t * (r + 2) <= slots; ++r) {
+        const int c = std::min((slots - t * r) / t, nkc / minc);
+        if (c < 2 || c < r) continue;
+        const int cost = std::max((nkc + c - 1) / c, (nkr + r - 1) / r);
+        if (cost < best) { best = cost; Sr = r; Sc = c; }
+    }
+    if (Sc < 2) return false;
+    const int ldp = (g.N + 3) / 4 * 4;
+    if ((size_t)Sc * g.M * ldp > kSplitKFloats) return false;
+    g.wg_per_cu = 1;
+    g.ksplit = Sc; g.partial = buf; g.ld_partial = ldp; g.ksplit_defer = 1;
+    g.res_col0 = co; g.res_ksplit = Sr; g.res_k0 = 2 * g.conv_cin_pad; g.res_nk = nkr;
+    defer->S = Sc; defer->slab = (size_t)g.M * ldp; defer->ldp = ldp; defer->base = buf;
+    *defer_res = *defer;
+    defer_res->S = Sr;             // Sr == 1: the residual columns are final (bias added) in C, not in a slab
+    return true;
+}
+
 static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int tin, int tq,
                      int stride, const int* offs, float* out, int ldo, int orow_mul, int orow_add, hipStream_t s,
-                     SplitInfo* defer = nullptr, float* splitk_buf = nullptr, int ncol_split = 0, int ncol_jump = 0) {
+                     SplitInfo* defer = nullptr, float* splitk_buf = nullptr, int ncol_split = 0, int ncol_jump = 0,
+                     int fused_res_co = 0, SplitInfo* defer_res = nullptr) {
     GemmParams g{};
     g.A = x; g.lda = ldx; g.W = w.w; g.ldw = w.taps * w.cin_pad; g.C = out; g.ldc = ldo;
     g.M = B * tq; g.N = w.cout; g.K = w.taps * w.cin_pad; g.bias = w.b;
@@ -467,7 +497,10 @@ static int conv_gemm(const rohm_trajnet* h, const ConvW& w, const float* x, int 
     g.conv_off0 = offs[0]; g.conv_dstep = (w.taps > 1) ? offs[1] - offs[0] : 0;
     g.zero_page = h->zero_page; g.orow_mul_m1 = orow_mul - 1; g.orow_add = orow_add;
     g.ncol_split = ncol_split; g.ncol_jump = ncol_jump;
-    plan_split(g, splitk_buf, defer);
+    if (!(fused_res_co > 0 && plan_fused_residual(g, fused_res_co, splitk_buf ? splitk_buf : tl_splitk, defer, defer_res))) {
+        plan_split(g, splitk_buf, defer);
+        if (defer_res && defer) *defer_res = *defer;
+    }
     return launch_gemm(g, EPI_BIAS, s);
 }
 static int conv5(const rohm_trajnet* h, const ConvW& w, const float* x, int ldx, int B, int T, float* out, int ldo,
@@ -555,15 +588,16 @@ static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int l
     if (r.has_res && (size_t)B * T * co <= kFuseMaxWork) {
         // block-0 conv and the 1x1 residual conv in one launch: C = [conv5(x) | res(x)], 2 co columns.  Its split-K slabs go
         // to the residual buffer (they must outlive the second conv, which re-uses the other one).
-        SplitInfo sf;
+        // The residual columns walk the centre tap only and may be split fewer ways than the conv columns (plan_fused_residual): two views
+        SplitInfo sf, sfr;
         static const int offs[5] = {-2, -1, 0, 1, 2};
-        if ((rc = conv_gemm(h, r.b0res, x, ldx, B, T, T, 1, offs, sc.ya, 2 * co, 1, 0, s, &sf, tl_splitk_res))) return rc;
-        GnFused f0{sf, sc.ya, 2 * co};
+        if ((rc = conv_gemm(h, r.b0res, x, ldx, B, T, T, 1, offs, sc.ya, 2 * co, 1, 0, s, &sf, tl_splitk_res, 0, 0, co, &sfr))) return rc;
+        GnFused f0{sf, sc.ya, 2 * co}, fr{sfr, sc.ya, 2 * co};
         if ((rc = gn(r.b0, f0.y(0), f0.ld(), f0.split(0), B, T, tb, ldtb, nullptr, 0, none, nullptr, nullptr, 0, sc.hb, co,
                      nullptr, 0, s)))
             return rc;
         if ((rc = conv5(h, r.b1.conv, sc.hb, co, B, T, sc.rc, co, s, &s1))) return rc;
-        return gn(r.b1, sc.rc, co, s1, B, T, nullptr, 0, f0.y(co), f0.ld(), f0.split(co), r.b0res.b + co, add2, ldadd2, dst,
+        return gn(r.b1, sc.rc, co, s1, B, T, nullptr, 0, fr.y(co), fr.ld(), fr.split(co), r.b0res.b + co, add2, ldadd2, dst,
                   lddst, dst2, lddst2, s);
     }
     if ((rc = conv5(h, r.b0.conv, x, ldx, B, T, sc.ya, co, s, &s0))) return rc;
@@ -1183,6 +1217,7 @@ int rohm_trajnet_forward(const rohm_trajnet_t* h, const float* x_t, const float*
     }
     tl_splitk = w.splitk;
     tl_splitk_res = w.splitk_res;
+    { const char* e = getenv("ROHM_TRAJ_RES_TAP"); g_res_centre_tap.store(!(e && e[0] == '0'), std::memory_order_relaxed); }
     const size_t M = (size_t)B * T;
     if ((rc = pad_rows(x_t, w.xin, M, h->ctraj, kPadC, s))) return rc;
     if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;
@@ -1217,6 +1252,7 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
     }
     tl_splitk = w.splitk;
     tl_splitk_res = w.splitk_res;
+    { const char* e = getenv("ROHM_TRAJ_RES_TAP"); g_res_centre_tap.store(!(e && e[0] == '0'), std::memory_order_relaxed); }
     const size_t M = (size_t)B * T, n = M * h->ctraj;
     // cond / control_cond do not change over the loop: pad them and run the (time-free) cond encoder once
     if ((rc = pad_rows(cond, w.cin, M, h->ctraj, kPadC, s))) return rc;
