@@ -35,6 +35,7 @@ extern "C" {
 #define ROHM_ERR_HIP (-2)
 #define ROHM_ERR_WORKSPACE (-3)
 #define ROHM_ERR_UNSUPPORTED (-4)
+#define ROHM_ERR_EXCHANGE (-5)   /* an in-kernel exchange between workgroups failed: results since the last status check are invalid */
 
 typedef void* rohm_stream_t; /* hipStream_t */
 
@@ -183,6 +184,18 @@ typedef struct {
     const rohm_posenet_layer_weights* layers; /* [n_layer] */
 } rohm_posenet_weights;
 
+/* OutputProcess.forward (model/heads.py:171-176): poseFinal Linear D -> C_out of every token, stored the way PoseNet.forward returns
+ * it (model/posenet.py:94-96).  h [B * (T + 1), D] token-major (row b * (T + 1) + tok; the reference's [T + 1, B, D] with the two
+ * leading axes exchanged; token 0 is the timestep token and has no output), w [C_out, D], b [C_out] ->
+ * out[b][ch_off + c][0][tok - 1] of a [B, C_total, 1, T] tensor (the other channels are not touched).
+ * `scratch` (optional, rohm_output_process_scratch_bytes() bytes, 256-byte aligned): lets shapes whose 144 x 64 tiles would need a
+ * part-filled extra round of the 256 CUs (B = 64: 288 tiles) run as a stream-K launch -- the (tile, K chunk) units are dealt out
+ * evenly, a tile cut in two is finished by the workgroup holding its tail.  Its first word is the exchange's error word (0 = fine;
+ * cleared by this call).  NULL: plain tiling.  D % 32 == 0. */
+size_t rohm_output_process_scratch_bytes(void);
+int rohm_output_process_f32(const float* h, const float* w, const float* b, float* out, int B, int T, int D, int C_out,
+                            int ch_off, int C_total, void* scratch, size_t scratch_bytes, rohm_stream_t stream);
+
 /* Weight pointers may be host or device memory (copied with hipMemcpyDefault). */
 int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int d_model, int n_head,
                         int d_ff, int n_layer, int c_in, int c_out, int traj_dim, int device);
@@ -196,6 +209,18 @@ int rohm_posenet_precision(const rohm_posenet_t* h);
  * -> x0_out [B, C_in, 1, T] (channels < traj_dim copied from cond, the C_out others predicted). */
 int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float* cond, const int64_t* t,
                          float* x0_out, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
+
+/* Status of the in-kernel exchanges of the forwards / loops run on workspace `ws` since the last call of this function.  Two of
+ * PoseNet's kernels let workgroups of ONE launch hand data to each other through L2 (the LayerNorm inside the out-projection / FF2
+ * GEMMs: rohm_gemm_res_layernorm_f32 above; the stream-K output head: rohm_output_process_f32 below).  Their waits are bounded; a
+ * wait that runs into its bound (or partners found on different XCDs) sets a word in `ws` that stays set.  This call
+ * synchronises `stream`, returns ROHM_ERR_EXCHANGE (and clears the word) if it is set, ROHM_OK otherwise.  Never expected on a
+ * healthy device -- the partner workgroups are co-resident by construction -- but a wrong result must not pass silently: the
+ * Python loops call it once at the end of every sampling loop (no synchronisation per step). */
+int rohm_posenet_exchange_status(const rohm_posenet_t* h, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
+/* Byte offset of the two status words inside a workspace of this shape: [0] the error word (0 fine, 1 a bounded wait expired,
+ * 2 partners on different XCDs), [1] 0x524f484d once a call has armed the workspace.  Diagnostics and tests. */
+size_t rohm_posenet_status_offset(const rohm_posenet_t* h, int B, int T);
 
 /* Device-resident DDPM loop without guidance: p_sample_loop over `n_steps` descending timesteps
  * (diffusion/gaussian_diffusion_posenet.py:578-662, 388-434).

@@ -87,6 +87,11 @@ SIGNATURES = {
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'rohm_posenet_destroy': (None, [C.c_void_p]),
     'rohm_posenet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'rohm_posenet_exchange_status': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'rohm_posenet_status_offset': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'rohm_output_process_scratch_bytes': (C.c_size_t, []),
+    'rohm_output_process_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_posenet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_posenet_sample_loop': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p, C.c_void_p,

@@ -138,6 +138,24 @@ int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw
     return launch_gemm(g, EPI_BIAS_RES_LN, (hipStream_t)stream);
 }
 
+size_t rohm_output_process_scratch_bytes(void) { return 256 + gemm_sk_scratch_bytes(); }
+
+int rohm_output_process_f32(const float* h, const float* w, const float* b, float* out, int B, int T, int D, int C_out,
+                            int ch_off, int C_total, void* scratch, size_t scratch_bytes, rohm_stream_t stream) {
+    ROHM_ARG_CHECK(h && w && b && out, "output_process: null pointer");
+    ROHM_ARG_CHECK(B > 0 && T > 0 && D > 0 && C_out > 0 && ch_off >= 0 && ch_off + C_out <= C_total, "output_process: bad shape");
+    GemmParams g{};
+    g.A = w; g.lda = D; g.W = h; g.ldw = D; g.C = out; g.M = C_out; g.N = B * (T + 1); g.K = D;
+    g.bias = b; g.S = T + 1; g.ch_off = ch_off; g.C_total = C_total; g.T = T;
+    if (scratch) {
+        ROHM_ARG_CHECK(scratch_bytes >= rohm_output_process_scratch_bytes() && (((uintptr_t)scratch) & 255) == 0,
+                       "output_process: scratch too small / misaligned");
+        ROHM_HIP_CHECK(hipMemsetAsync(scratch, 0, 64, (hipStream_t)stream));
+        gemm_sk_bind(g, static_cast<char*>(scratch) + 256, static_cast<unsigned*>(scratch));
+    }
+    return launch_gemm(g, EPI_OUT_T, (hipStream_t)stream);
+}
+
 int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, int D, rohm_stream_t stream) {
     ROHM_ARG_CHECK(x && gamma && beta, "layernorm: null pointer");
     return launch_layernorm(x, gamma, beta, M, D, (hipStream_t)stream);

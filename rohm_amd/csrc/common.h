@@ -91,6 +91,7 @@ struct GemmParams {
     int qcols; float qscale;
     // EPI_EMBED
     int S; const float* tab; const float* tab0; int ldtab; int ldtab0;
+    int tab_by_row;              // 1: `tab` has one row per OUTPUT row m (a loop-invariant part of the sum computed once) instead of per token
     // EPI_OUT_T: rows = output channels (M = c_out), cols = tokens n -> (b = n / S, tok = n % S);
     // writes out[b][ch_off + m][tok-1] for tok >= 1 (T = S - 1 frames).
     int ch_off; int C_total; int T;
@@ -139,7 +140,19 @@ struct GemmParams {
     const float* ln_gamma; const float* ln_beta;
     float* xln_stats; unsigned* xln_err; unsigned xln_epoch;
     unsigned* xln_xcc;      // [tiles_m][8]: XCD id + 1 of the workgroup that ran each tile (diagnostic: the tests assert the co-location)
+    // ---- stream-K (EPI_OUT_T with 144 x 64 tiles: the output head, whose 288 tiles at B = 64 would take two rounds of 256 CUs with the
+    // second one 1/8 full).  launch_gemm fills sk_units / sk_tiles8 when `sk_part` is bound and the shape qualifies (gemm_sk_plan):
+    // 256 workgroups, each contracts sk_units consecutive (tile, K chunk) units of its XCD's sk_tiles8 tiles; a tile cut in two is
+    // finished by the workgroup holding its tail, which adds the raw accumulators the other one left in sk_part[block] (flag =
+    // (XCD id + 1) << 32 | xln_epoch in sk_flag[block]).  Same caveats as the LayerNorm exchange: *xln_err reports a wait that ran
+    // into its bound (1) or a partner on another XCD (2); not for hipGraph capture.
+    float* sk_part; unsigned long long* sk_flag; int sk_units, sk_tiles8;
 };
+// stream-K scratch for launch_gemm(EPI_OUT_T): [flags: 256 x 8 B][slots: 256 x 36 KiB]; the error word is the caller's (the LayerNorm
+// scratch's first word in posenet.hip).  gemm_sk_plan: does (M, N, K) run as stream-K, and with which split?
+size_t gemm_sk_scratch_bytes();
+void gemm_sk_bind(GemmParams& p, void* scratch, unsigned* err);
+bool gemm_sk_plan(int M, int N, int K, int* units, int* tiles8);
 // EPI_BIAS_RES_LN: can launch_gemm run (M, N, ...) with the in-kernel LayerNorm?  Scratch = stats + flags + error word.
 bool gemm_ln_supported(int M, int N, int K);
 size_t gemm_ln_scratch_bytes(int M, int N);

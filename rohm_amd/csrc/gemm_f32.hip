@@ -48,6 +48,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 144;
 constexpr int BK = 32;
 constexpr int NRB = BM / 16;        // 9 row blocks of 16 (BN = 64 path)
+constexpr int kSkWorkgroups = 256;  // stream-K launches: one workgroup per CU (32 per XCD)
 constexpr int A_UNITS = BM * 8;     // 16-byte units per A chunk (1152)
 constexpr int A_ITERS = (A_UNITS + 255) / 256;  // 5 (the last pass is half populated)
 
@@ -129,6 +130,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     int ksplit = (EPI == EPI_BIAS && p.ksplit > 1) ? p.ksplit : 1;
     int split = (ksplit > 1) ? (int)(blockIdx.x % ksplit) : 0;
     int m0, n0;
+    // ---- stream-K (GemmParams::sk_*; the output head at B = 64: 288 tiles of 16 chunks on 256 CUs) -------------------------------
+    // The (tile, chunk) units of the launch are dealt out evenly: XCD x owns tiles [x T8, (x + 1) T8) and its j-th workgroup
+    // (block 8 j + x) the units [j u, (j + 1) u) of them -- a workgroup's range is the TAIL of one tile, whole tiles, and the HEAD of
+    // another (or, when u < chunks per tile, a piece from the middle of one: B = 32, 144 tiles, u = 9); a workgroup produces at most
+    // one partial tile.  Segments are processed LAST first: a segment that does not reach its tile's last chunk leaves its raw
+    // accumulators in this workgroup's slot of `sk_part` (role 1: producer) early; the segment that does comes last, and its
+    // workgroup (role 2: owner) adds the slots of the blocks 8, 16, .. below it that hold the tile's earlier chunks -- same XCD,
+    // dispatched EARLIER, written long before -- and runs the epilogue.  Dependencies point to lower block indices only: no
+    // workgroup waits for one that may not have started.
+    constexpr bool SK = (EPI == EPI_OUT_T) && !FULL && !CONV && BN == 64 && VAR == 0;
+    int sk_lo = 0, sk_hi = 0, sk_role = -1;      // role of the current segment: 0 whole tile, 1 producer, 2 owner; -1 before the first
     // chunks of K this launch's tiles contract over, and where they start: all of K -- except for the 1x1 residual columns of a
     // fused [conv5 | residual] launch (trajnet.hip), whose weights are zero outside the centre tap: those tiles walk the centre
     // tap's chunks only, with their own split count
@@ -160,10 +172,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if (g >= tiles_m) return;
         m0 = g * BM;
         n0 = (j % tiles_n) * BN;
+    } else if (SK && p.sk_units > 0) {
+        m0 = n0 = 0;                       // set per segment below
+        sk_lo = (int)(blockIdx.x / kNumXCD) * p.sk_units;
+        sk_hi = sk_lo + p.sk_units;
     } else {
         const int tile = xcd_remap(ksplit > 1 ? blockIdx.x / ksplit : blockIdx.x, tiles_m * tiles_n);
         m0 = (tile / tiles_n) * BM;
         n0 = (tile % tiles_n) * BN;
+    }
+
+    // Everything below is the life of ONE (tile, K range).  A stream-K workgroup walks its segments through it, last segment first;
+    // every other launch passes once (the loop condition is a compile-time `false` for them).
+    do {
+    if constexpr (SK) {
+        if (p.sk_units > 0) {
+            if (sk_role >= 0) {            // not the first segment: the previous one's LDS reads and global stores are done
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            const int nkt = p.K / BK;                                // chunks per tile
+            const int t = (sk_hi - 1) / nkt;                         // this XCD's tile holding the last unit still to do
+            const int c_lo = sk_lo > t * nkt ? sk_lo - t * nkt : 0;  // ... and the chunks [c_lo, c_hi) of it that are this workgroup's
+            const int c_hi = sk_hi - t * nkt;
+            sk_role = c_hi < nkt ? 1 : (c_lo > 0 ? 2 : 0);
+            const int gt = (int)(blockIdx.x % kNumXCD) * p.sk_tiles8 + t;
+            m0 = (gt % tiles_m) * BM;      // the row tiles of one column tile are neighbours: its W rows are read once per L2
+            n0 = (gt / tiles_m) * BN;
+            nk_all = c_hi - c_lo;
+            k_first = c_lo * BK;
+            sk_hi = t * nkt + c_lo;
+        }
     }
 
     // ---- global -> LDS staging by LDS-DMA ---------------------------------------------------------------------
@@ -433,7 +472,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         if constexpr (EPI == EPI_EMBED) {      // the row of the positional / timestep table this unit adds
             if (!FULL && (m >= p.M || nb >= p.N)) return rr;
             const int bidx = m / p.S, tok = m % p.S;
-            const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb : p.tab + (size_t)tok * p.ldtab + nb;
+            const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb : p.tab + (size_t)(p.tab_by_row ? m : tok) * p.ldtab + nb;
             if constexpr (FULL) {
                 rr = *reinterpret_cast<const f32x4*>(tp);
             } else {
@@ -754,6 +793,63 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             }
         }
     } else if constexpr (EPI == EPI_OUT_T) {
+        if constexpr (SK) {
+            constexpr size_t kSlot = (size_t)N16 * 256 * 4;        // floats per workgroup slot: accumulator i of thread t at (i * 256 + t) * 4
+            if (sk_role == 1) {
+                // head of a tile: leave the raw accumulators for the tile's owner.  The stores are acknowledged by L2 (vmcnt) before
+                // the flag goes out; the owner sits on the same XCD, whose L2 is the point both meet at.
+                float* slot = p.sk_part + (size_t)blockIdx.x * kSlot;
+#pragma unroll
+                for (int i = 0; i < N16; ++i) *reinterpret_cast<f32x4*>(slot + ((size_t)i * 256 + tid) * 4) = acc16[i];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    const unsigned long long xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+                    __hip_atomic_store(p.sk_flag + blockIdx.x, (xcc << 32) | p.xln_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                continue;
+            }
+            if (sk_role == 2) {
+                // tail of a tile: add what the workgroups in front of us (8, 16, .. blocks below: same XCD) accumulated over the
+                // tile's earlier chunks -- nearest first, a fixed order.  With sk_units >= chunks per tile that is one workgroup.
+                const int tile_u0 = (n0 / BN * tiles_m + m0 / BM - (int)(blockIdx.x % kNumXCD) * p.sk_tiles8) * (p.K / BK);
+                for (int jb = (int)(blockIdx.x / kNumXCD) - 1; jb >= 0 && (jb + 1) * p.sk_units > tile_u0; --jb) {
+                    const unsigned src = (unsigned)jb * kNumXCD + blockIdx.x % kNumXCD;
+                    if (tid == 0) {
+                        const unsigned long long xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+                        for (int it = 0;; ++it) {
+                            const unsigned long long f = __hip_atomic_load(p.sk_flag + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)f == p.xln_epoch) {
+                                // a producer on another XCD would have left its partial in another L2: never with the hardware's
+                                // round-robin placement, and not survivable silently
+                                if ((f >> 32) != xcc) __hip_atomic_store(p.xln_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                            if (it > (1 << 19)) {                   // ~0.2 s: do not hang the device; the host reads the word
+                                __hip_atomic_store(p.xln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(p.sk_part + (size_t)src * kSlot);
+                    unsigned long long lo[N16], hi[N16];
+#pragma unroll
+                    for (int i = 0; i < N16; ++i) {                 // past the L1
+                        lo[i] = __hip_atomic_load(slot + ((size_t)i * 256 + tid) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[i] = __hip_atomic_load(slot + ((size_t)i * 256 + tid) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int i = 0; i < N16; ++i) {
+                        acc16[i][0] += __uint_as_float((unsigned)lo[i]);
+                        acc16[i][1] += __uint_as_float((unsigned)(lo[i] >> 32));
+                        acc16[i][2] += __uint_as_float((unsigned)hi[i]);
+                        acc16[i][3] += __uint_as_float((unsigned)(hi[i] >> 32));
+                    }
+                }
+            }
+        }
         // natural operand order: rows = output channels m, cols = tokens n; stored transposed into [B, C_total, 1, T]
         // LN fold: the normalised operand is the token (column) side; a lane's columns are fixed per column block
         constexpr int NCOL = M32 ? NCB32 + NCB : NCB;
@@ -868,6 +964,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             ts[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
         }
     }
+    } while (SK && sk_hi > sk_lo);
 }
 
 // Second pass of a split-K GEMM: C[crow(m)][n] = bias[n] + sum_s partial[s][m][n], splits added in index order
@@ -920,6 +1017,10 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
         tiles = ((p.M + BM - 1) / BM) * ((p.res_col0 / BN) * ksplit + (((p.N + BN - 1) / BN) - p.res_col0 / BN) * (p.res_ksplit > 1 ? p.res_ksplit : 1));
     if (EPI == EPI_BIAS_RES_LN)      // row tiles dealt round-robin to the XCDs, rounded up to a multiple of 8 (the kernel's own map)
         tiles = (((p.M + BM - 1) / BM + kNumXCD - 1) / kNumXCD) * kNumXCD * ((p.N + BN - 1) / BN);
+    if (EPI == EPI_OUT_T && p.sk_units > 0) {      // stream-K: one workgroup per CU, the units dealt out evenly
+        if (!(BN == 64 && !FULL && !CONV && VAR == 0)) { set_error("gemm: stream-K exists for the 144 x 64 output-head tiles only"); return ROHM_ERR_ARG; }
+        tiles = kSkWorkgroups;
+    }
 #ifdef ROHM_GEMM_DIAGNOSTICS
     static const int lds_pad = diag_env_int("ROHM_GEMM_LDS_PAD", 0);
     static const bool occ2 = getenv("ROHM_GEMM_OCC2") != nullptr;      // allow two workgroups per CU
@@ -1092,17 +1193,46 @@ void gemm_ln_bind(GemmParams& p, void* scratch) {
     p.xln_xcc = reinterpret_cast<unsigned*>(c + 64 + ln_stats_bytes(p.M));
 }
 
+// The tag of a launch's exchange slots (LayerNorm statistics, stream-K flags): unique per launch in this process and never 0, so
+// whatever an earlier launch (or nobody) left in the scratch is recognised as stale -- nothing to clear, nothing to re-arm.
+static unsigned gemm_next_epoch() {
+    static std::atomic<unsigned> epoch{0};
+    unsigned e;
+    do { e = epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (e == 0u);
+    return e;
+}
+
+// ---- stream-K for EPI_OUT_T ----------------------------------------------------------------------------------------------------
+constexpr size_t kSkSlotBytes = (size_t)NRB * 256 * 4 * sizeof(float);      // the 9 accumulator quads of 256 threads (144 x 64 tile)
+size_t gemm_sk_scratch_bytes() { return (size_t)kSkWorkgroups * 8 + (size_t)kSkWorkgroups * kSkSlotBytes; }
+void gemm_sk_bind(GemmParams& p, void* scratch, unsigned* err) {
+    p.sk_flag = static_cast<unsigned long long*>(scratch);
+    p.sk_part = reinterpret_cast<float*>(static_cast<char*>(scratch) + (size_t)kSkWorkgroups * 8);
+    p.xln_err = err;
+}
+// Possible when every XCD gets the same number of tiles and every workgroup the same number of units, with no tile in more than
+// three pieces (units per workgroup >= half the chunks of a tile); worth it when that is at least four chunks (~5 us) shorter than
+// the rounds of whole tiles it replaces: B = 64 (288 tiles): 18 units against 2 x 16; B = 32 (144 tiles on 256 CUs): 9 against 16.
+bool gemm_sk_plan(int M, int N, int K, int* units, int* tiles8) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + 63) / 64), nk = K / BK, per_xcd = kSkWorkgroups / kNumXCD;
+    if (tiles % kNumXCD != 0 || K % BK != 0 || nk < 2) return false;
+    const int t8 = tiles / kNumXCD;
+    if ((t8 * nk) % per_xcd != 0) return false;
+    const int u = (t8 * nk) / per_xcd, rounds = (tiles + kSkWorkgroups - 1) / kSkWorkgroups;
+    if (2 * u < nk || rounds * nk - u < 4) return false;
+    if (units) *units = u;
+    if (tiles8) *tiles8 = t8;
+    return true;
+}
+
 static int launch_ln(const GemmParams& p, hipStream_t s) {
     ROHM_ARG_CHECK(gemm_ln_supported(p.M, p.N, p.K), "gemm: shape (%d, %d, %d) has no in-kernel LayerNorm form", p.M, p.N, p.K);
     ROHM_ARG_CHECK(p.bias && p.R && p.ln_gamma && p.ln_beta && p.xln_stats && p.xln_err, "gemm: LayerNorm epilogue: null operand");
     ROHM_ARG_CHECK(p.ln_dim == p.N && p.ldc % 4 == 0 && p.ldr % 4 == 0 && al16(p.C) && al16(p.R) && al16(p.bias) && al16(p.ln_gamma) &&
                        al16(p.ln_beta) && (((uintptr_t)p.xln_stats) & 15) == 0 && p.ksplit <= 1 && p.conv_taps == 0,
                    "gemm: LayerNorm epilogue needs ln_dim == N and 16-byte aligned operands");
-    // the tag of this launch's statistics slots: unique per launch in this process and never 0, so whatever an earlier launch (or
-    // nobody) left in the scratch is recognised as stale -- nothing to clear, nothing to re-arm
-    static std::atomic<unsigned> epoch{0};
     GemmParams q = p;
-    do { q.xln_epoch = epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (q.xln_epoch == 0u);
+    q.xln_epoch = gemm_next_epoch();
     if (ln_tile_width(p.M / BM, p.N) == 128) return launch_one<128, EPI_BIAS_RES_LN, 0, true>(q, s);
     return launch_one<64, EPI_BIAS_RES_LN, 0, true>(q, s);
 }
@@ -1144,7 +1274,16 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
         case EPI_BIAS_RES: return launch_bn<EPI_BIAS_RES>(p, s);
         case EPI_QKV: return launch_bn<EPI_QKV>(p, s);
         case EPI_EMBED: return launch_bn<EPI_EMBED>(p, s);
-        case EPI_OUT_T: return launch_bn<EPI_OUT_T>(p, s);
+        case EPI_OUT_T: {
+            GemmParams q = p;
+            q.sk_units = q.sk_tiles8 = 0;
+            if (p.sk_part && gemm_sk_plan(p.M, p.N, p.K, &q.sk_units, &q.sk_tiles8)) {
+                ROHM_ARG_CHECK(p.sk_flag && p.xln_err && al16(p.sk_part) && p.bias, "gemm: stream-K: bad scratch / null bias");
+                q.xln_epoch = gemm_next_epoch();
+                return launch_t<64, EPI_OUT_T>(q, s);
+            }
+            return launch_bn<EPI_OUT_T>(q, s);
+        }
         case EPI_BIAS_RES_LN: return launch_ln(p, s);
     }
     set_error("gemm: unknown epilogue %d", epi);

@@ -47,6 +47,9 @@ struct rohm_posenet {
     int KP;            // padded K of the fused embed GEMM
     float* arena;      // one allocation holding every weight
     float* w_embed;    // [D, KP]   = [Wx | Wc | 0]
+    int KX;            // padded K of the x_t half alone
+    float* w_embed_x;  // [D, KX]   = [Wx | 0]: the per-step embed of the sampling loop, whose cond half is computed once per call
+    bool cond_hoist;   // (default on; ROHM_POSENET_COND_HOIST=0: the full [x_t | cond] contraction every step)
     float* tab;        // [kMaxTok, D]  pe[tok] + bx + bc
     float* pe;         // [pe_len, D]
     int pe_len;
@@ -56,6 +59,7 @@ struct rohm_posenet {
     float *out_c;                         // LayerNorm folding of the last norm2 into the output head
     bool ln_fold;                         // LayerNorm folded into the CONSUMER GEMMs (opt-in, measured slower) or run as a kernel
     bool ln_fused;                        // LayerNorm inside the PRODUCER GEMMs (EPI_BIAS_RES_LN; default on, ROHM_POSENET_LN_FUSED=0: kernel)
+    bool head_sk;                         // output head as a stream-K launch where the shape qualifies (default on, ROHM_POSENET_HEAD_SK=0: tiles)
     int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2 / 16: split GEMMs on planes (bf16x6 / bf16x3 / fp16x3)
     char* wplanes;                        // one allocation holding the weight planes of every layer
     bool pp_fold;                         // plane modes: LayerNorm folded into the plane GEMMs (ROHM_PP_LNFOLD=1, two-plane modes)
@@ -174,7 +178,7 @@ __global__ void build_embed_kernel(const float* __restrict__ wx, const float* __
         const int n = i / KP, k = i % KP;
         float v = 0.f;
         if (k < C) v = wx[(size_t)n * C + k];
-        else if (k < 2 * C) v = wc[(size_t)n * C + (k - C)];
+        else if (wc && k < 2 * C) v = wc[(size_t)n * C + (k - C)];      // wc == null: [Wx | 0]
         w_embed[i] = v;
     }
 }
@@ -216,7 +220,9 @@ struct Workspace {
     float *apack, *h, *y, *qkv, *ctx, *ff, *tab0, *x0, *tok_all;
     char *hP, *yP, *ctxP, *ffP;   // planes of h / y / ctx / ff (split-bf16 mode; ctx and ff then exist as planes only)
     float *stats_a, *stats_b;     // row (sum, sum of squares) partials of y / h: [M][D/64][2]
-    float* xln;                   // scratch of the LayerNorm-producing GEMMs (common.h gemm_ln_*): error word, counters, statistics
+    float* xln;                   // scratch of the LayerNorm-producing GEMMs (common.h gemm_ln_*): status words, statistics
+    float* sk;                    // scratch of the stream-K output head (common.h gemm_sk_*): flags, partial tiles
+    float* econd;                 // [M, D] cond half of the input embedding + positional table + biases (sampling loop)
     int64_t* t_all;
     size_t floats;
 };
@@ -253,8 +259,23 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
     w.stats_b = take(M * (p->D / (p->nplane ? 16 : 64)) * 2);
     w.t_all = reinterpret_cast<int64_t*>(take(2 * (size_t)kLoopChunk));
     w.xln = take(gemm_ln_scratch_bytes((int)M, p->D) / sizeof(float));
+    w.sk = take(gemm_sk_scratch_bytes() / sizeof(float));
+    w.econd = take(M * p->D);
     w.floats = off;
     return w;
+}
+
+// The first words of w.xln are the workspace's STATUS: [0] = error word of the in-kernel exchanges (LayerNorm statistics between
+// column tiles, stream-K partials of the output head: a wait that ran into its bound, a partner on the wrong XCD), [1] = a magic that
+// says [0] has been initialised.  Every entry point arms it -- clears [0] only on a workspace it sees for the first time -- so an
+// error stays until rohm_posenet_exchange_status() reads and clears it: no host synchronisation on the forward path, and no silent
+// wrong statistics either.
+constexpr unsigned kStatusMagic = 0x524f484du;
+__global__ void arm_status_kernel(unsigned* st) {
+    if (st[1] != kStatusMagic) { st[0] = 0u; st[1] = kStatusMagic; }
+}
+static void arm_status(const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(arm_status_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<unsigned*>(w.xln));
 }
 
 static int check_shape(const rohm_posenet* p, int B, int T) {
@@ -266,7 +287,7 @@ static int check_shape(const rohm_posenet* p, int B, int T) {
 
 // Network body: from packed input (w.apack complete) to x0 channels [traj, Cin) in `x0_out`.
 static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t* t_dev, int64_t t_host,
-                       const float* tok_pre, float* x0_out, int B, int T, hipStream_t s) {
+                       const float* tok_pre, float* x0_out, int B, int T, hipStream_t s, bool cond_done = false) {
     const int S = T + 1, D = p->D, M = B * S;
     // timestep token(s): per sample from device timesteps, or one precomputed row shared by the batch
     if (!tok_pre) {
@@ -285,6 +306,9 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         g.A = w.apack; g.lda = p->KP; g.W = p->w_embed; g.ldw = p->KP; g.C = w.h; g.ldc = D;
         g.M = M; g.N = D; g.K = p->KP; g.S = S; g.tab = p->tab; g.tab0 = tok_pre ? tok_pre : w.tab0; g.ldtab = D;
         g.ldtab0 = (t_dev && !tok_pre) ? D : 0;
+        if (cond_done) {      // w.econd = cond . Wc^T + bx + bc + pe[tok] already (embed_cond): contract x_t only and add it row by row
+            g.W = p->w_embed_x; g.ldw = p->KX; g.K = p->KX; g.tab = w.econd; g.tab_by_row = 1;
+        }
         if ((rc = launch_gemm(g, EPI_EMBED, s))) return rc;
     }
     float* h = w.h;
@@ -396,6 +420,8 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         g.A = p->out_w; g.lda = D; g.W = h; g.ldw = D; g.C = x0_out; g.M = p->Cout; g.N = M; g.K = D;
         g.bias = p->out_b; g.S = S; g.ch_off = p->Cin - p->Cout; g.C_total = p->Cin; g.T = T;
         if (fold) ln_operand(g, w.stats_b, p->out_c);
+        // B = 64: 2 x 144 tiles on 256 CUs -- dealt out as (tile, K chunk) units instead of a second, 1/8-full round (common.h sk_*)
+        if (p->head_sk) gemm_sk_bind(g, w.sk, reinterpret_cast<unsigned*>(w.xln));
         if ((rc = launch_gemm(g, EPI_OUT_T, s))) return rc;
     }
     return ROHM_OK;
@@ -447,7 +473,9 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
     const size_t D = d_model, F = d_ff;
     size_t total = 0;
     auto cnt = [&](size_t n) { size_t o = total; total += align_up(n, 64); return o; };
+    p->KX = (int)align_up((size_t)c_in, 32);
     const size_t o_embed = cnt(D * p->KP), o_tab = cnt((size_t)kMaxTok * D), o_pe = cnt((size_t)w->pe_len * D);
+    const size_t o_embed_x = cnt(D * p->KX);
     const size_t o_tok = cnt((size_t)w->pe_len * D);
     const size_t o_w0 = cnt(D * D), o_b0 = cnt(D), o_w2 = cnt(D * D), o_b2 = cnt(D);
     const size_t o_ow = cnt((size_t)c_out * D), o_ob = cnt(c_out), o_oc = cnt(c_out);
@@ -477,7 +505,7 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
             return ROHM_ERR_HIP;                                                        \
         }                                                                               \
     } while (0)
-    p->w_embed = a + o_embed; p->tab = a + o_tab; p->pe = a + o_pe; p->tok_table = a + o_tok;
+    p->w_embed = a + o_embed; p->w_embed_x = a + o_embed_x; p->tab = a + o_tab; p->pe = a + o_pe; p->tok_table = a + o_tok;
     p->t_w0T = a + o_w0; p->t_b0 = a + o_b0; p->t_w2T = a + o_w2; p->t_b2 = a + o_b2;
     p->out_w = a + o_ow; p->out_b = a + o_ob; p->out_c = a + o_oc;
     {
@@ -493,6 +521,12 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         // write + read of the residual stream per layer less.  Default on; ROHM_POSENET_LN_FUSED=0 keeps the LayerNorm kernel.
         const char* e6 = getenv("ROHM_POSENET_LN_FUSED");
         p->ln_fused = !(e6 && e6[0] == '0');
+        const char* e7 = getenv("ROHM_POSENET_HEAD_SK");
+        p->head_sk = !(e7 && e7[0] == '0');
+        // The cond half of the input embedding (InputProcess of batch['cond'], model/posenet.py:85-87) does not change over a sampling
+        // loop: rohm_posenet_sample_loop computes it once per call and each step contracts the x_t half only (K 608 -> 320).
+        const char* e8 = getenv("ROHM_POSENET_COND_HOIST");
+        p->cond_hoist = !(e8 && e8[0] == '0');
         // Opt-in precision ladder: ROHM_GEMM_PRECISION=bf16x6 | bf16x3 | fp16x3 runs the four Linears of every
         // encoder layer as split-bf16 GEMMs on planes (gemm_pp.hip).  The default -- and every headline number -- is exact fp32.
         const char* e3 = getenv("ROHM_GEMM_PRECISION");
@@ -540,6 +574,7 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
     PUT(bx, w->in_x_b, D);
     PUT(bc, w->in_c_b, D);
     hipLaunchKernelGGL(build_embed_kernel, dim3((unsigned)((D * p->KP + th - 1) / th)), dim3(th), 0, 0, wx, wc, p->w_embed, (int)D, c_in, p->KP);
+    hipLaunchKernelGGL(build_embed_kernel, dim3((unsigned)((D * p->KX + th - 1) / th)), dim3(th), 0, 0, wx, (const float*)nullptr, p->w_embed_x, (int)D, c_in, p->KX);
     hipLaunchKernelGGL(build_tab_kernel, dim3((unsigned)((kMaxTok * D + th - 1) / th)), dim3(th), 0, 0, p->pe, bx, bc, p->tab, kMaxTok, (int)D);
     // timestep tokens of every t in [0, pe_len)
     hipLaunchKernelGGL(timestep_token_kernel, dim3((unsigned)w->pe_len), dim3((unsigned)D), 2 * D * sizeof(float), 0, p->pe,
@@ -684,12 +719,35 @@ int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float*
         set_error("posenet_forward: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
         return ROHM_ERR_WORKSPACE;
     }
-    if (h->ln_fused) ROHM_HIP_CHECK(hipMemsetAsync(w.xln, 0, gemm_ln_zero_bytes(B * (T + 1)), s));
+    arm_status(w, s);
     if ((rc = launch_pack(h, x_t, w.apack, B, T, 0, s))) return rc;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;
     if ((rc = run_network(h, w, t, 0, nullptr, x0_out, B, T, s))) return rc;
     const size_t n = (size_t)B * h->Cin * T;
     return launch_finish(x0_out, cond, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, h->traj, h->Cin, T, n, s);
+}
+
+size_t rohm_posenet_status_offset(const rohm_posenet_t* h, int B, int T) {
+    if (!h || B <= 0 || T <= 0) return 0;
+    // carve() on a null base yields null pointers: carve on a dummy base and take the distance (nothing is dereferenced)
+    return (size_t)((char*)carve(h, B, T, (float*)256).xln - (char*)256);
+}
+
+int rohm_posenet_exchange_status(const rohm_posenet_t* h, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream) {
+    int rc = check_shape(h, B, T);
+    if (rc) return rc;
+    ROHM_ARG_CHECK(ws && ((uintptr_t)ws % 256) == 0, "posenet_exchange_status: null / misaligned workspace");
+    Workspace w = carve(h, B, T, (float*)ws);
+    ROHM_ARG_CHECK(w.floats * sizeof(float) <= ws_bytes, "posenet_exchange_status: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned st[2] = {0u, 0u};
+    ROHM_HIP_CHECK(hipMemcpyAsync(st, w.xln, sizeof(st), hipMemcpyDeviceToHost, s));
+    ROHM_HIP_CHECK(hipStreamSynchronize(s));
+    if (st[1] != kStatusMagic || st[0] == 0u) return ROHM_OK;      // never used, or clean
+    ROHM_HIP_CHECK(hipMemsetAsync(w.xln, 0, sizeof(unsigned), s));
+    set_error("posenet: an in-kernel exchange failed since the last check (%s): the outputs computed on this workspace since then are "
+              "not valid", st[0] == 2u ? "partner workgroups were placed on different XCDs" : "a wait for a partner workgroup ran into its bound");
+    return ROHM_ERR_EXCHANGE;
 }
 
 int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* cond, const int64_t* t_model,
@@ -709,8 +767,19 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
     const size_t n = (size_t)B * h->Cin * T;
     ROHM_ARG_CHECK(n_steps <= kLoopChunk, "posenet_sample_loop: at most %d steps per call", kLoopChunk);
     if (n_steps == 0) return ROHM_OK;
-    if (h->ln_fused) ROHM_HIP_CHECK(hipMemsetAsync(w.xln, 0, gemm_ln_zero_bytes(B * (T + 1)), s));      // counters of the LayerNorm GEMMs
+    arm_status(w, s);
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;   // cond is constant over the loop
+    // ... and so is its half of the input embedding: one [0 | cond] pass of the embed GEMM now, K = KX instead of KP in every step.
+    // (The steps' A rows still carry cond in columns C .. KX: w_embed_x is zero there.)
+    const bool hoist = h->cond_hoist && n_steps >= 4;
+    if (hoist) {
+        const int S = T + 1;
+        ROHM_HIP_CHECK(hipMemset2DAsync(w.apack, (size_t)h->KP * sizeof(float), 0, (size_t)h->Cin * sizeof(float), (size_t)B * S, s));
+        GemmParams g{};
+        g.A = w.apack; g.lda = h->KP; g.W = h->w_embed; g.ldw = h->KP; g.C = w.econd; g.ldc = h->D;
+        g.M = B * S; g.N = h->D; g.K = h->KP; g.S = S; g.tab = h->tab; g.tab0 = h->tok_table; g.ldtab = h->D; g.ldtab0 = 0;
+        if ((rc = launch_gemm(g, EPI_EMBED, s))) return rc;
+    }
     // timestep tokens come from the table built at create (the embedder depends on t only, heads.py:145-146)
     for (int i = 0; i < n_steps; ++i) {
         prof::set_step(i);
@@ -720,7 +789,7 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
             ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((rc = launch_pack(h, x, w.apack, B, T, 0, s))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
-        if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s))) return rc;
+        if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s, hoist))) return rc;
         if ((rc = launch_finish(x0, cond, x, noise ? noise + (size_t)i * n : nullptr, x, c1, c2, sigma, h->traj,
                                 h->Cin, T, n, s)))
             return rc;

@@ -222,6 +222,14 @@ class DDPMSampler:
     def _fused_ok(self, raw):
         return hasattr(raw, 'sample_loop_native') and not self.rescale_timesteps
 
+    @staticmethod
+    def _check_exchange(raw):
+        """End of a sampling run: ask the network whether one of its in-kernel exchanges failed on the way
+        (rohm_posenet_exchange_status: one stream synchronisation per RUN, raises instead of returning wrong samples)."""
+        fn = getattr(raw, 'check_exchange', None)
+        if fn is not None:
+            fn()
+
     def p_sample_loop(self, model, batch, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
                       randomize_class=False, cond_fn_with_grad=False, grad_type=None, early_stop=False,
@@ -245,15 +253,20 @@ class DDPMSampler:
                     xts.append(out['x_t'].clone())
                     tls.append(self.num_timesteps - k - 1)
             if dump_steps is not None:
+                self._check_exchange(raw)
                 return dump
             if save_intermediate_result:
                 # the reference appends the last step once more and returns the 4-tuple, early_stop or not (:570-574)
                 x0s.append(final['pred_xstart'].clone())
                 xts.append(final['x_t'].clone())
                 tls.append(self.num_timesteps - k - 1)
+                self._check_exchange(raw)
                 return final['sample'], x0s, xts, tls
+            self._check_exchange(raw)
             return final['pred_xstart'] if early_stop else final['sample']
-        return self._fused_loop(raw, batch, shape, noise, device, cond_fn_with_grad, grad_type, early_stop)
+        out = self._fused_loop(raw, batch, shape, noise, device, cond_fn_with_grad, grad_type, early_stop)
+        self._check_exchange(raw)
+        return out
 
     def _fused_loop(self, raw, batch, shape, noise, device, cond_fn_with_grad, grad_type, early_stop):
         """Device-resident runs of un-guided steps + per-step execution of the guided tail."""
@@ -370,6 +383,7 @@ class DDPMSampler:
                                        batch=batch)
                 pos += n
         batch['x_t'] = x
+        self._check_exchange(raw)
         return x
 
     # ------------------------------------------------------------------ entry point

@@ -100,6 +100,15 @@ class _NativePoseNet:
             self._ws[key] = ws
         return ws
 
+    def check_exchange(self):
+        """rohm_posenet_exchange_status on the workspace(s) of the current stream: synchronises it and raises RohmHipError
+        (ROHM_ERR_EXCHANGE) if an in-kernel exchange failed in a forward / loop since the last check."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for (B, T, st), ws in list(self._ws.items()):
+            if st == stream:
+                check(lib().rohm_posenet_exchange_status(self.handle, B, T, ptr(ws), ws.numel(), stream_ptr(self.device)),
+                      'rohm_posenet_exchange_status')
+
     def __del__(self):
         try:
             if self.handle:
@@ -206,6 +215,13 @@ class PoseNet(nn.Module):
             self._native = _NativePoseNet(self, device)
             self._native_key = key
         return self._native
+
+    def check_exchange(self):
+        """Raise if a forward / sampling loop since the last check saw one of its in-kernel exchanges fail (the LayerNorm inside
+        the out-projection / FF2 GEMMs, the stream-K output head: include/rohm_hip.h rohm_posenet_exchange_status).  Synchronises
+        the current stream; the diffusion loops call it once per run."""
+        if self._native is not None:
+            self._native.check_exchange()
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch, timesteps):

@@ -46,6 +46,27 @@ def gemm_res_layernorm(a, w, bias, residual, gamma, beta, eps=1e-5, out=None, re
     return (out, scratch) if return_scratch else out
 
 
+def output_process(h, w, b, B, T, ch_off=0, c_total=None, out=None, stream_k=True, return_scratch=False):
+    """OutputProcess.forward (model/heads.py:171-176) on token-major h [B * (T + 1), D]: out[b, ch_off + c, 0, tok - 1] of a
+    [B, c_total, 1, T] tensor (include/rohm_hip.h rohm_output_process_f32).  `stream_k=False` keeps plain tiling."""
+    _lib.require_hip(h, w, b)
+    D = h.shape[1]
+    c_out = w.shape[0]
+    if h.shape[0] != B * (T + 1) or w.shape[1] != D:
+        raise ValueError(f'h must be [{B * (T + 1)}, D] and w [C_out, D]; got {tuple(h.shape)} / {tuple(w.shape)}')
+    c_total = c_out + ch_off if c_total is None else c_total
+    if out is None:
+        out = torch.zeros(B, c_total, 1, T, device=h.device, dtype=torch.float32)
+    scratch, nbytes = None, 0
+    if stream_k:
+        nbytes = lib().rohm_output_process_scratch_bytes()
+        scratch = torch.empty(nbytes // 4 + 64, device=h.device, dtype=torch.int32)
+        scratch = scratch[(-scratch.data_ptr() % 256) // 4:]
+    check(lib().rohm_output_process_f32(ptr(h), ptr(w), ptr(b), ptr(out), B, T, D, c_out, ch_off, c_total, ptr(scratch), nbytes,
+                                        stream_ptr(h.device)), 'rohm_output_process_f32')
+    return (out, scratch) if return_scratch else out
+
+
 def layernorm_(x, gamma, beta):
     _lib.require_hip(x)
     M, D = x.shape

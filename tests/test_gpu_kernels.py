@@ -109,6 +109,63 @@ def test_gemm_res_layernorm_refuses_other_shapes():
                                    torch.zeros(N, device=d))
 
 
+def _sk_plan(B, T=143, D=512, c_out=272):
+    """gemm_f32.hip gemm_sk_plan: does the output head of this shape run as a stream-K launch?"""
+    tiles, nk = -(-c_out // 144) * -(-(B * (T + 1)) // 64), D // 32
+    if tiles % 8 or nk < 2 or (tiles // 8 * nk) % 32:
+        return False
+    u, rounds = tiles // 8 * nk // 32, -(-tiles // 256)
+    return 2 * u >= nk and rounds * nk - u >= 4
+
+
+@pytest.mark.parametrize('B', [64, 96, 128, 32, 80, 48, 3])      # stream-K: 64 (18 units per workgroup), 96 (27), 128 (36), 32 (9: tiles in up to three pieces); plain tiles: 80, 48, 3
+def test_output_process(B):
+    """OutputProcess.forward (model/heads.py:171-176) as PoseNet stores it (posenet.py:94-96): Linear 512 -> 272 of every frame token,
+    written to channels 22.. of [B, 294, 1, 143].  At B = 64 the 288 tiles run as ONE round of 256 workgroups, each contracting 18
+    consecutive (tile, K chunk) units; a tile cut in two is finished by the workgroup holding its tail (gemm_f32.hip stream-K)."""
+    from rohm_amd import ops
+    T, D, C, off, tot = 143, 512, 272, 22, 294
+    h, w, b = seeded(B, B * (T + 1), D) * 2 + 0.1, seeded(B + 1, C, D) / math.sqrt(D), seeded(B + 2, C)
+    ref = (h.double() @ w.double().T + b.double()).view(B, T + 1, C)[:, 1:].permute(0, 2, 1)          # [B, C, T]
+    d = _dev()
+    args = [t.to(d) for t in (h, w, b)]
+    assert _sk_plan(B) == (B in (64, 96, 128, 32))
+    outs, errs = {}, {}
+    for sk in (True, False):
+        out = torch.full((B, tot, 1, T), 7.5, device=d)
+        out, scratch = ops.output_process(*args, B, T, ch_off=off, c_total=tot, out=out, stream_k=sk, return_scratch=True)
+        torch.cuda.synchronize()
+        o = out.cpu()
+        errs[sk] = max_abs(o[:, off:, 0], ref)
+        assert errs[sk] < 2e-5 * math.sqrt(D / 32)
+        assert bool((o[:, :off] == 7.5).all()), 'the trajectory channels are not this operator\'s to write'
+        if sk:
+            assert int(scratch[0]) == 0, 'stream-K exchange error word'
+        outs[sk] = out
+    # the two launch shapes add the same products; a cut tile sums its two K ranges separately (|out| reaches ~10: one ulp is 1e-6)
+    both = max_abs(outs[True].cpu(), outs[False].cpu())
+    print(f'B={B}: stream-K {errs[True]:.2e}, tiles {errs[False]:.2e} vs fp64; between them {both:.2e}')
+    assert both < 4e-5
+    if not _sk_plan(B):
+        assert torch.equal(outs[True], outs[False])
+    for _ in range(50):      # race screen: every run the same bits (fixed owner, fixed order of the two partial sums)
+        assert torch.equal(ops.output_process(*args, B, T, ch_off=off, c_total=tot, out=torch.full((B, tot, 1, T), 7.5, device=d)),
+                           outs[True])
+
+
+def test_output_process_other_widths():
+    """Other head shapes (the class takes any latent_dim / feature count): ragged channel and token tiles, K of one chunk."""
+    from rohm_amd import ops
+    d = _dev()
+    for B, T, D, C in ((5, 47, 256, 100), (64, 143, 256, 272), (40, 143, 64, 300), (2, 10, 32, 3)):
+        h, w, b = seeded(B + T, B * (T + 1), D), seeded(C, C, D) / math.sqrt(D), seeded(D, C)
+        ref = (h.double() @ w.double().T + b.double()).view(B, T + 1, C)[:, 1:].permute(0, 2, 1)
+        out, scratch = ops.output_process(h.to(d), w.to(d), b.to(d), B, T, return_scratch=True)
+        torch.cuda.synchronize()
+        assert max_abs(out.cpu()[:, :, 0], ref) < 2e-5 * math.sqrt(max(D, 32) / 32), (B, T, D, C)
+        assert int(scratch[0]) == 0
+
+
 @pytest.mark.parametrize('M', [4, 144, 1000])
 def test_layernorm(M):
     from rohm_amd import ops

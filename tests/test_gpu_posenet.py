@@ -297,6 +297,59 @@ def test_headline_batch_is_clip_independent_and_meets_the_reference_golden():
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('hoist,head_sk', [('1', '1'), ('0', '1'), ('1', '0'), ('0', '0')])
+def test_loop8_variants_of_the_launch_plan_vs_reference_golden(hoist, head_sk, monkeypatch):
+    """Two launch-plan choices of the sampling loop, each against the reference's own 8-step run: the cond half of the input embedding
+    computed once per call (on: K = 320 per step + a row table; off: K = 608 every step), and the output head as a stream-K launch.
+    They change summation order only."""
+    monkeypatch.setenv('ROHM_POSENET_COND_HOIST', hoist)
+    monkeypatch.setenv('ROHM_POSENET_HEAD_SK', head_sk)
+    g = golden('posenet_loop8.npz')
+    net, _ = make_posenet(int(g['weight_seed']))
+    steps = int(g['steps'])
+    cond = seeded(int(g['cond_seed']), 2, 294, 1, 143)
+    x_T, noises = cpu_noise_sequence(int(g['torch_seed']), (2, 294, 1, 143), steps)
+    diff = make_diffusion(steps)
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    y = diff.p_sample_loop(net, {'cond': cond.to(DEV)}, [2, 294, 1, 143])          # one fused call of 8 steps
+    err = max_abs(y.cpu(), torch.from_numpy(g['y']))
+    print(f'hoist={hoist} head_sk={head_sk}: {err:.3e}')
+    assert err < 1e-4, err
+
+
+def test_exchange_status_is_sticky_and_raises_once():
+    """Two kernels of the forward hand data between workgroups of one launch (LayerNorm statistics, stream-K partials); their
+    bounded waits report into a status word of the workspace.  The word survives later calls on that workspace until
+    rohm_posenet_exchange_status reads it: a failed exchange raises at the end of the sampling run instead of returning wrong
+    samples.  (A real failure cannot be provoked on a healthy device: the word is poked by hand.)"""
+    from rohm_amd import _lib
+    lib = _lib.lib()
+    net, _ = make_posenet(5)
+    B, T = 2, 143
+    x, c = seeded(1, B, 294, 1, T).to(DEV), seeded(2, B, 294, 1, T).to(DEV)
+    t = torch.tensor([3, 700], device=DEV)
+    nat = net.native(torch.device(DEV))
+    ws = nat.workspace(B, T)
+    ws.fill_(0xAB)                                  # a workspace nobody initialised: the first call arms the status words
+    y0 = net({'x_t': x, 'cond': c}, t)
+    net.check_exchange()                            # clean
+    off = lib.rohm_posenet_status_offset(nat.handle, B, T)
+    word = ws[off:off + 8].view(torch.int32)
+    assert int(word[0]) == 0 and int(word[1]) == 0x524f484d
+    word[0] = 1                                     # "a wait ran into its bound"
+    y1 = net({'x_t': x, 'cond': c}, t)              # later calls do not clear it
+    assert torch.equal(y0, y1) and int(word[0]) == 1
+    with pytest.raises(_lib.RohmHipError, match='code -5'):
+        net.check_exchange()
+    net.check_exchange()                            # reported once, cleared
+    word[0] = 2
+    dif = make_diffusion(4)
+    with pytest.raises(_lib.RohmHipError, match='different XCDs'):      # the sampling loops check at their end
+        dif.p_sample_loop(net, {'cond': c}, [B, 294, 1, T])
+    net.check_exchange()
+    dif.p_sample_loop(net, {'cond': c}, [B, 294, 1, T])                # and pass when nothing happened
+
+
 def test_empty_batch_passes_through():
     """B = 0 (an empty shard of a ragged split): forward and the whole sampling run return empty tensors of the right shape,
     as the reference's torch modules do, without touching the C ABI (which rejects B <= 0)."""
