@@ -86,7 +86,10 @@ int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, i
  * (merged pairwise by Chan's update: two-pass stability) through L2 while the kernel runs (they are dispatched back to back onto one XCD), so LN(x) is stored once and the raw
  * sum never reaches HBM.  Shapes: M % 144 == 0, K % 32 == 0, N / 64 or N / 128 in {1, 2, 4, 8} (else ROHM_ERR_UNSUPPORTED:
  * use rohm_gemm_f32(epi 2) + rohm_layernorm_f32).  `scratch`: rohm_gemm_res_layernorm_scratch_bytes(M, N) bytes, 64-byte aligned,
- * owned by the caller for the duration of the launch (counters + statistics; cleared by this call). */
+ * owned by the caller for the duration of the launch (first word: the exchange's error word, 0 = fine; cleared by this call).
+ * The slots carry a per-launch tag that a hipGraph replay would repeat: on a stream that is being captured the call returns
+ * ROHM_ERR_UNSUPPORTED (rohm_posenet_forward switches to the GEMM + LayerNorm pair by itself, and the stream-K output head to
+ * plain tiles). */
 size_t rohm_gemm_res_layernorm_scratch_bytes(int M, int N);
 int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                                 const float* bias, const float* R, int ldr, const float* gamma, const float* beta, float eps,

@@ -136,7 +136,7 @@ struct GemmParams {
     // launch's tag (xln_epoch: unique per launch, set by launch_gemm), merges the pairs by Chan's update in a fixed tree over the tile index (every tile gets
     // bit-identical statistics), normalises its accumulators in registers and stores LN(x) once.  *xln_err is set if a wait ran
     // into its bound (never on a healthy device: the partner tiles are co-resident by construction).  Not for hipGraph capture
-    // (a replay would repeat the tag).
+    // (a replay would repeat the tag): launch_gemm refuses it on a capturing stream.
     const float* ln_gamma; const float* ln_beta;
     float* xln_stats; unsigned* xln_err; unsigned xln_epoch;
     unsigned* xln_xcc;      // [tiles_m][8]: XCD id + 1 of the workgroup that ran each tile (diagnostic: the tests assert the co-location)
@@ -145,7 +145,7 @@ struct GemmParams {
     // 256 workgroups, each contracts sk_units consecutive (tile, K chunk) units of its XCD's sk_tiles8 tiles; a tile cut in two is
     // finished by the workgroup holding its tail, which adds the raw accumulators the other one left in sk_part[block] (flag =
     // (XCD id + 1) << 32 | xln_epoch in sk_flag[block]).  Same caveats as the LayerNorm exchange: *xln_err reports a wait that ran
-    // into its bound (1) or a partner on another XCD (2); not for hipGraph capture.
+    // into its bound (1) or a partner on another XCD (2); on a capturing stream launch_gemm keeps plain tiles.
     float* sk_part; unsigned long long* sk_flag; int sk_units, sk_tiles8;
 };
 // stream-K scratch for launch_gemm(EPI_OUT_T): [flags: 256 x 8 B][slots: 256 x 36 KiB]; the error word is the caller's (the LayerNorm
@@ -160,6 +160,9 @@ size_t gemm_ln_zero_bytes(int M);                 // leading part of the scratch
 void gemm_ln_bind(GemmParams& p, void* scratch);  // fills xln_* from a scratch block (p.M must be set)
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
+// Is `s` recording a hipGraph?  The launches that exchange data between their workgroups tag it with a per-launch epoch a replay would
+// repeat, so they are not used under capture: launch_gemm refuses EPI_BIAS_RES_LN and runs EPI_OUT_T as plain tiles; posenet.hip asks first.
+bool stream_is_capturing(hipStream_t s);
 #ifdef __HIPCC__
 // All-lanes sum of a 64-wide wave, bit-identical to the xor butterfly  for (o = 32; o; o >>= 1) v += __shfl_xor(v, o)  -- but on the
 // VALU: __shfl_xor compiles to ds_bpermute_b32 (the LDS crossbar, ~100 cycles and an lgkmcnt wait per step; twelve of them in a row

@@ -1225,7 +1225,17 @@ bool gemm_sk_plan(int M, int N, int K, int* units, int* tiles8) {
     return true;
 }
 
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
 static int launch_ln(const GemmParams& p, hipStream_t s) {
+    if (stream_is_capturing(s)) {
+        set_error("gemm: the LayerNorm epilogue exchanges statistics under a per-launch tag and cannot be recorded into a hipGraph");
+        return ROHM_ERR_UNSUPPORTED;
+    }
     ROHM_ARG_CHECK(gemm_ln_supported(p.M, p.N, p.K), "gemm: shape (%d, %d, %d) has no in-kernel LayerNorm form", p.M, p.N, p.K);
     ROHM_ARG_CHECK(p.bias && p.R && p.ln_gamma && p.ln_beta && p.xln_stats && p.xln_err, "gemm: LayerNorm epilogue: null operand");
     ROHM_ARG_CHECK(p.ln_dim == p.N && p.ldc % 4 == 0 && p.ldr % 4 == 0 && al16(p.C) && al16(p.R) && al16(p.bias) && al16(p.ln_gamma) &&
@@ -1277,7 +1287,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
         case EPI_OUT_T: {
             GemmParams q = p;
             q.sk_units = q.sk_tiles8 = 0;
-            if (p.sk_part && gemm_sk_plan(p.M, p.N, p.K, &q.sk_units, &q.sk_tiles8)) {
+            if (p.sk_part && !stream_is_capturing(s) && gemm_sk_plan(p.M, p.N, p.K, &q.sk_units, &q.sk_tiles8)) {
                 ROHM_ARG_CHECK(p.sk_flag && p.xln_err && al16(p.sk_part) && p.bias, "gemm: stream-K: bad scratch / null bias");
                 q.xln_epoch = gemm_next_epoch();
                 return launch_t<64, EPI_OUT_T>(q, s);

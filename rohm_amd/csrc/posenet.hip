@@ -362,7 +362,8 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     }
     const bool fold = p->ln_fold && !planes;
     // LayerNorm inside the producer GEMMs (out-projection, FF2): whole clips of 144 tokens, widths whose column tiles pair up
-    const bool lnf = p->ln_fused && !fold && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F);
+    // (not while the stream records a hipGraph: the exchange's per-launch tag would be replayed -- the GEMM + LayerNorm pair then)
+    const bool lnf = p->ln_fused && !fold && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F) && !stream_is_capturing(s);
     const int parts = D / 64;
     auto ln_operand = [&](GemmParams& g, const float* stats, const float* c) {
         g.ln_stats = stats; g.ln_parts = parts; g.ln_c = c; g.ln_dim = D; g.ln_eps = 1e-5f;

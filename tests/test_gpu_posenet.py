@@ -317,6 +317,38 @@ def test_loop8_variants_of_the_launch_plan_vs_reference_golden(hoist, head_sk, m
     assert err < 1e-4, err
 
 
+def test_forward_recorded_into_a_graph_avoids_the_in_kernel_exchanges(monkeypatch):
+    """The LayerNorm-carrying GEMMs and the stream-K head tag their exchange slots with a per-launch epoch; a hipGraph replay would
+    repeat the tag and accept stale slots.  On a capturing stream the library therefore runs the GEMM + LayerNorm pair and plain
+    tiles instead, by itself: a recorded forward replays correctly on new inputs."""
+    B, T = 32, 143
+    x, c = seeded(1, B, 294, 1, T).to(DEV), seeded(2, B, 294, 1, T).to(DEV)
+    t = torch.tensor([(37 * i + 1) % 1000 for i in range(B)], device=DEV)
+    with monkeypatch.context() as m:           # first launches of the kernels the capture will fall back to (function attributes)
+        m.setenv('ROHM_POSENET_LN_FUSED', '0')
+        m.setenv('ROHM_POSENET_HEAD_SK', '0')
+        plain, _ = make_posenet(5)
+        ref_plain = plain({'x_t': x, 'cond': c}, t)
+    net, _ = make_posenet(5)
+    refs = [net({'x_t': x * k, 'cond': c}, t) for k in (1.0, 0.5)]          # eager: fused LayerNorm, stream-K head
+    assert max_abs(refs[0], ref_plain) < 2e-5
+    side = torch.cuda.Stream()
+    xs = x.clone()
+    with torch.cuda.stream(side):
+        net({'x_t': xs, 'cond': c}, t)                                      # this stream's workspace exists before the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        y = net({'x_t': xs, 'cond': c}, t)
+    for k, r in zip((1.0, 0.5, 1.0), (refs[0], refs[1], refs[0])):
+        xs.copy_(x * k)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert max_abs(y, r) < 2e-5, k
+    assert torch.equal(y, ref_plain)                                        # the recorded launches ARE the plain ones
+    net.check_exchange()
+
+
 def test_exchange_status_is_sticky_and_raises_once():
     """Two kernels of the forward hand data between workgroups of one launch (LayerNorm statistics, stream-K partials); their
     bounded waits report into a status word of the workspace.  The word survives later calls on that workspace until
