@@ -746,7 +746,10 @@ def main(argv=None):
                 # round 4: the out-projection / FF2 launches (`gemm_bias_res_ln`) carry the LayerNorm that used to be 16 separate
                 # launches per step; their time counts here against the GEMM's 2 M N K flops only
                 'note': ('GEMM time includes the LayerNorm work fused into the out-projection / FF2 launches (gemm_bias_res_ln); rounds 1-3 '
-                         'timed LayerNorm as its own kernel outside this family') if any(k.startswith('gemm_bias_res_ln') for k in gemm) else None,
+                         'timed LayerNorm as its own kernel outside this family.  Flops are the EXECUTED 2 M N K of each launch: the embed '
+                         'GEMM contracts the x_t half only (K = 320; the cond half is computed once per sampling loop), 0.9 % fewer flops per '
+                         'step than model_tflops credits (the reference\'s 5.298 GFLOP per clip-step)')
+                if any(k.startswith('gemm_bias_res_ln') for k in gemm) else None,
                 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
                 'kernels': kernels,
             },
