@@ -606,9 +606,13 @@ def main(argv=None):
                          "two-iteration RoHM scheme per clip (TrajNet 100 -> PoseNet 1000 + skating guidance -> "
                          "TrajControl 100 -> PoseNet 1000 + skating guidance); 'prox' = configs[3]: PoseNet with the PROX "
                          "test-time guidance (2-D re-projection + skating on t <= 100, early stop at 980 steps); 'egobody' = "
-                         "configs[4]: the PROX/EgoBody driver loop (run_prox_iterations) with sample_iter=3, a random 80 % "
+                         "configs[4]: the PROX/EgoBody driver loop (run_prox_iterations) with sample_iter=3, a random 80 %% "
                          "visibility mask and PROX guidance; all but 'posenet' are extra measurements, not the headline")
-    ap.add_argument('--profile-stride', type=int, default=16)
+    ap.add_argument('--profile-stride', type=int, default=100,
+                    help='the in-stream HIP events of the roofline record bracket every launch of every N-th denoising step.  Two event '
+                         'records around each of a step\'s 51 launches cost ~0.5 ms per sampled step: at N = 16 (rounds 1-4) that was 1 %% of '
+                         'the headline value and 2.7 %% of the scheme workloads; at N = 100 it is 0.16 %% and still times 160 launches of the '
+                         'dominant kernel per 1000-step pass')
     ap.add_argument('--no-extras', action='store_true', help='N = 1 only: skip the second_line / configs child measurements')
     ap.add_argument('--with-accuracy', action='store_true', help='attach the 1000-step accuracy record even without the CPU leg')
     ap.add_argument('--guidance-semantics', choices=['replica', 'global'], default='replica',
