@@ -196,6 +196,11 @@ typedef struct {
  * evenly, a tile cut in two is finished by the workgroup holding its tail.  Its first word is the exchange's error word (0 = fine;
  * cleared by this call).  NULL: plain tiling.  D % 32 == 0. */
 size_t rohm_output_process_scratch_bytes(void);
+/* Host-only: the launch plan rohm_output_process_f32 (with scratch) uses for this shape.  Returns 1 for a stream-K launch -- 256
+ * workgroups, 32 per XCD; XCD x owns tiles [x * tiles_per_xcd, (x + 1) * tiles_per_xcd) of the 144 x 64 tiling (row tiles of one column
+ * tile adjacent), its j-th workgroup (block 8 j + x) the (tile, 32-wide K chunk) units [j u, (j + 1) u) of them in tile-major order,
+ * u = units_per_workgroup -- and 0 for plain tiles (outputs set to 0).  tests/test_host_logic.py walks this schedule. */
+int rohm_output_process_plan(int B, int T, int D, int C_out, int* units_per_workgroup, int* tiles_per_xcd);
 int rohm_output_process_f32(const float* h, const float* w, const float* b, float* out, int B, int T, int D, int C_out,
                             int ch_off, int C_total, void* scratch, size_t scratch_bytes, rohm_stream_t stream);
 

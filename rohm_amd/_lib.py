@@ -90,6 +90,7 @@ SIGNATURES = {
     'rohm_posenet_exchange_status': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_posenet_status_offset': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'rohm_output_process_scratch_bytes': (C.c_size_t, []),
+    'rohm_output_process_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'rohm_output_process_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_posenet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

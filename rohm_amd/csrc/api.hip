@@ -140,6 +140,14 @@ int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw
 
 size_t rohm_output_process_scratch_bytes(void) { return 256 + gemm_sk_scratch_bytes(); }
 
+int rohm_output_process_plan(int B, int T, int D, int C_out, int* units_per_workgroup, int* tiles_per_xcd) {
+    int u = 0, t8 = 0;
+    const bool sk = B > 0 && T > 0 && D > 0 && C_out > 0 && gemm_sk_plan(C_out, B * (T + 1), D, &u, &t8);
+    if (units_per_workgroup) *units_per_workgroup = sk ? u : 0;
+    if (tiles_per_xcd) *tiles_per_xcd = sk ? t8 : 0;
+    return sk ? 1 : 0;
+}
+
 int rohm_output_process_f32(const float* h, const float* w, const float* b, float* out, int B, int T, int D, int C_out,
                             int ch_off, int C_total, void* scratch, size_t scratch_bytes, rohm_stream_t stream) {
     ROHM_ARG_CHECK(h && w && b && out, "output_process: null pointer");

@@ -105,3 +105,74 @@ def test_abi_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     lib.rohm_version.restype = ctypes.c_int
     assert lib.rohm_version() >= 100
+
+
+def _stream_k_walk(B, T=143, D=512, c_out=272):
+    """The segment walk of gemm_f32.hip's stream-K workgroups (csrc/gemm_f32.hip, `do { ... } while (SK && sk_hi > sk_lo)`) restated on
+    the host from the plan the library reports: yields (block, tile, chunk_lo, chunk_hi, role, sources) in processing order."""
+    import ctypes as C
+    from rohm_amd import _lib
+    u, t8 = C.c_int(), C.c_int()
+    if not _lib.lib().rohm_output_process_plan(B, T, D, c_out, C.byref(u), C.byref(t8)):
+        assert u.value == 0 and t8.value == 0
+        return None
+    u, t8, nk = u.value, t8.value, D // 32
+    out = []
+    for block in range(256):
+        x, j = block % 8, block // 8
+        lo, hi, role = j * u, (j + 1) * u, -1
+        while hi > lo:
+            t = (hi - 1) // nk
+            c_lo, c_hi = max(lo - t * nk, 0), hi - t * nk
+            role = 1 if c_hi < nk else (2 if c_lo > 0 else 0)
+            src = []
+            if role == 2:                              # the blocks in front that hold the tile's earlier chunks, nearest first
+                jb = j - 1
+                while jb >= 0 and (jb + 1) * u > t * nk:
+                    src.append(jb * 8 + x)
+                    jb -= 1
+            out.append((block, x * t8 + t, c_lo, c_hi, role, src))
+            hi = t * nk + c_lo
+    return u, t8, nk, out
+
+
+def test_stream_k_schedule_covers_every_unit_once_and_waits_only_downwards():
+    """Invariants the stream-K output head relies on, for every batch size the plan accepts: each (tile, K chunk) unit
+    is contracted exactly once; a workgroup produces at most one partial tile and does so BEFORE it owns one; an owner's sources are
+    lower-numbered blocks of its own XCD (dispatched earlier: no wait for a workgroup that may not have started) and together with its
+    own chunks they tile the whole K range in order; the tiling it replaces is only ever left when that saves at least four chunks."""
+    taken = 0
+    for B in list(range(1, 130)) + [160, 192, 256, 320, 512]:
+        plan = _stream_k_walk(B)
+        tiles = 2 * -(-(B * 144) // 64)
+        if plan is None:
+            continue
+        taken += 1
+        u, t8, nk, segs = plan
+        assert t8 * 8 == tiles and u * 32 == t8 * nk and 2 * u >= nk and -(-tiles // 256) * nk - u >= 4, B
+        seen = {}
+        produced = {}                                           # block -> (tile, lo, hi) of the partial it leaves
+        order = {}
+        for block, tile, lo, hi, role, src in segs:
+            for c in range(lo, hi):
+                assert (tile, c) not in seen, (B, tile, c)
+                seen[(tile, c)] = block
+            order.setdefault(block, []).append(role)
+            if role == 1:
+                assert block not in produced, 'one slot per workgroup'
+                produced[block] = (tile, lo, hi)
+        assert len(seen) == tiles * nk
+        for block, roles in order.items():                      # partial first, whole tiles, the owned (cut) tile last
+            assert roles == sorted(roles, key=lambda r: {1: 0, 0: 1, 2: 2}[r]), (B, block, roles)
+            assert roles.count(1) <= 1 and roles.count(2) <= 1
+        for block, tile, lo, hi, role, src in segs:
+            if role != 2:
+                continue
+            assert src and all(s < block and s % 8 == block % 8 for s in src), (B, block, src)
+            assert len(src) <= 2                                 # tiles in at most three pieces
+            pieces = sorted([produced[s] for s in src], key=lambda p: p[1])
+            assert all(p[0] == tile for p in pieces)
+            edges = [0] + [p[2] for p in pieces]
+            assert [p[1] for p in pieces] == edges[:-1] and edges[-1] == lo and hi == nk, (B, block, pieces, lo)
+    assert taken >= 6                                            # B = 32, 64, 96, 128, 192, 256, ...
+    assert _stream_k_walk(64)[0] == 18 and _stream_k_walk(32)[0] == 9
