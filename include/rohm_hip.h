@@ -17,8 +17,8 @@
  *     the caller may free its copies afterwards.
  *   - every launch goes on the caller-supplied hipStream_t (passed as void*);
  *     no hidden device synchronisation.
- *   - handles are immutable after create; calls are re-entrant across streams given
- *     distinct workspaces.  One handle per device.
+ *   - handles are immutable after create (one documented exception: rohm_posenet_set_exchange);
+ *     calls are re-entrant across streams given distinct workspaces.  One handle per device.
  */
 #ifndef ROHM_HIP_H
 #define ROHM_HIP_H
@@ -86,10 +86,12 @@ int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, i
  * (merged pairwise by Chan's update: two-pass stability) through L2 while the kernel runs (they are dispatched back to back onto one XCD), so LN(x) is stored once and the raw
  * sum never reaches HBM.  Shapes: M % 144 == 0, K % 32 == 0, N / 64 or N / 128 in {1, 2, 4, 8} (else ROHM_ERR_UNSUPPORTED:
  * use rohm_gemm_f32(epi 2) + rohm_layernorm_f32).  `scratch`: rohm_gemm_res_layernorm_scratch_bytes(M, N) bytes, 64-byte aligned,
- * owned by the caller for the duration of the launch (first word: the exchange's error word, 0 = fine; cleared by this call).
- * The slots carry a per-launch tag that a hipGraph replay would repeat: on a stream that is being captured the call returns
- * ROHM_ERR_UNSUPPORTED (rohm_posenet_forward switches to the GEMM + LayerNorm pair by itself, and the stream-K output head to
- * plain tiles). */
+ * owned by the caller for the duration of the launch.  Its first 64 bytes are the exchange header: [0] the error word (0 = fine, 1 a
+ * bounded wait expired, 2 partners on different XCDs; sticky -- the caller clears it), [1] a magic once armed, [2] a pass counter
+ * this call advances on the device.  A scratch the library has not seen (no magic: uninitialised or recycled memory) is zeroed by the
+ * call itself.  The slots are tagged with that device-side counter, so the launch may be recorded into a hipGraph: every replay
+ * draws a fresh tag.  The partner tiles must be co-resident on one XCD: on a device that is not a whole MI355X (partitioned, CU
+ * mask, probe launch failed -- see rohm_posenet_exchange_mode) the call returns ROHM_ERR_UNSUPPORTED. */
 size_t rohm_gemm_res_layernorm_scratch_bytes(int M, int N);
 int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                                 const float* bias, const float* R, int ldr, const float* gamma, const float* beta, float eps,
@@ -193,8 +195,8 @@ typedef struct {
  * out[b][ch_off + c][0][tok - 1] of a [B, C_total, 1, T] tensor (the other channels are not touched).
  * `scratch` (optional, rohm_output_process_scratch_bytes() bytes, 256-byte aligned): lets shapes whose 144 x 64 tiles would need a
  * part-filled extra round of the 256 CUs (B = 64: 288 tiles) run as a stream-K launch -- the (tile, K chunk) units are dealt out
- * evenly, a tile cut in two is finished by the workgroup holding its tail.  Its first word is the exchange's error word (0 = fine;
- * cleared by this call).  NULL: plain tiling.  D % 32 == 0. */
+ * evenly, a tile cut in two is finished by the workgroup holding its tail.  It starts with the same exchange header as above ([0] the
+ * error word, sticky).  NULL, or a device that fails the layout guard: plain tiling.  Recordable into a hipGraph.  D % 32 == 0. */
 size_t rohm_output_process_scratch_bytes(void);
 /* Host-only: the launch plan rohm_output_process_f32 (with scratch) uses for this shape.  Returns 1 for a stream-K launch -- 256
  * workgroups, 32 per XCD; XCD x owns tiles [x * tiles_per_xcd, (x + 1) * tiles_per_xcd) of the 144 x 64 tiling (row tiles of one column
@@ -223,12 +225,31 @@ int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float*
  * GEMMs: rohm_gemm_res_layernorm_f32 above; the stream-K output head: rohm_output_process_f32 below).  Their waits are bounded; a
  * wait that runs into its bound (or partners found on different XCDs) sets a word in `ws` that stays set.  This call
  * synchronises `stream`, returns ROHM_ERR_EXCHANGE (and clears the word) if it is set, ROHM_OK otherwise.  Never expected on a
- * healthy device -- the partner workgroups are co-resident by construction -- but a wrong result must not pass silently: the
- * Python loops call it once at the end of every sampling loop (no synchronisation per step). */
+ * whole, exclusively owned MI355X -- the partner workgroups are co-resident by construction, and rohm_posenet_create checks the
+ * device before it uses these launches -- but another tenant's long kernels can delay a partner past the bound, and a wrong result
+ * must not pass silently: the Python loops call it after every fused chunk of steps (one synchronisation per <= 50 steps) and after
+ * every step-wise forward, switch the handle to the exchange-free launches (rohm_posenet_set_exchange) and RE-RUN the chunk.
+ * Direct callers of rohm_posenet_forward must call it before they trust the output. */
 int rohm_posenet_exchange_status(const rohm_posenet_t* h, int B, int T, void* ws, size_t ws_bytes, rohm_stream_t stream);
-/* Byte offset of the two status words inside a workspace of this shape: [0] the error word (0 fine, 1 a bounded wait expired,
- * 2 partners on different XCDs), [1] 0x524f484d once a call has armed the workspace.  Diagnostics and tests. */
+/* Byte offset of the exchange header inside a workspace of this shape: [0] the error word (0 fine, 1 a bounded wait expired,
+ * 2 partners on different XCDs), [1] 0x524f484d once a call has armed the workspace, [2] the pass counter (advanced on the device by
+ * the first kernel of every network pass; the tags of a pass's exchanging launches derive from it).  Diagnostics and tests. */
 size_t rohm_posenet_status_offset(const rohm_posenet_t* h, int B, int T);
+/* Which launch forms this handle uses for the post-norm tails (model/posenet.py:63-69) and OutputProcess (model/heads.py:171-176):
+ * bit 0 LayerNorm inside the out-projection / FF2 GEMMs, bit 1 stream-K output head; bit 2: the environment asked for them but the
+ * layout guard refused at create (rohm_posenet_exchange_guard says why: < 256 CUs = a partitioned device, HSA_CU_MASK /
+ * ROC_GLOBAL_CU_MASK set, or the probe launch -- 256 one-per-CU workgroups that must be resident together, block b on XCD b % 8 --
+ * failed); bit 3: switched off after a failed exchange (rohm_posenet_set_exchange(h, 0)).  ROHM_EXCHANGE_GUARD=off skips the guard,
+ * =probe skips its environment shortcut. */
+int rohm_posenet_exchange_mode(const rohm_posenet_t* h);
+const char* rohm_posenet_exchange_guard(const rohm_posenet_t* h);
+/* on = 0: from now on this handle runs the exchange-free launches (GEMM + LayerNorm kernel pair, plain output-head tiles) -- what the
+ * sampling loops do, before re-running the chunk, when rohm_posenet_exchange_status reports a failure.  on = 1: back to what the
+ * environment asked for and the guard allowed.  Not to be called while launches of this handle are being issued by another thread. */
+int rohm_posenet_set_exchange(rohm_posenet_t* h, int on);
+/* Test hook: the next `n_launches` LayerNorm-carrying GEMM launches of this handle publish one column tile's statistics under a
+ * wrong tag, so its partners' waits expire (~0.2 s, once) and the error word is set -- a real failed exchange for the fallback tests. */
+int rohm_posenet_inject_exchange_fault(rohm_posenet_t* h, int n_launches);
 
 /* Device-resident DDPM loop without guidance: p_sample_loop over `n_steps` descending timesteps
  * (diffusion/gaussian_diffusion_posenet.py:578-662, 388-434).

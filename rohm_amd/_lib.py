@@ -21,6 +21,9 @@ class RohmHipError(RuntimeError):
     pass
 
 
+ROHM_ERR_EXCHANGE = -5      # include/rohm_hip.h
+
+
 class LayerWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b',
@@ -89,6 +92,10 @@ SIGNATURES = {
     'rohm_posenet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'rohm_posenet_exchange_status': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'rohm_posenet_status_offset': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'rohm_posenet_exchange_mode': (C.c_int, [C.c_void_p]),
+    'rohm_posenet_exchange_guard': (C.c_char_p, [C.c_void_p]),
+    'rohm_posenet_set_exchange': (C.c_int, [C.c_void_p, C.c_int]),
+    'rohm_posenet_inject_exchange_fault': (C.c_int, [C.c_void_p, C.c_int]),
     'rohm_output_process_scratch_bytes': (C.c_size_t, []),
     'rohm_output_process_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'rohm_output_process_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -133,8 +133,19 @@ int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw
     GemmParams g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.R = R; g.ldr = ldr; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_dim = N; g.ln_eps = eps;
+    // the column tiles meet in L2 while they run: only on a device laid out as the kernel's block -> tile map assumes (exchange.hip)
+    int dev = 0;
+    ROHM_HIP_CHECK(hipGetDevice(&dev));
+    const char* why = "";
+    if (!exchange_layout_ok(dev, &why)) {
+        set_error("gemm_res_layernorm: the in-kernel LayerNorm needs a whole MI355X (%s): use rohm_gemm_f32(epi 2) + rohm_layernorm_f32", why);
+        return ROHM_ERR_UNSUPPORTED;
+    }
     gemm_ln_bind(g, scratch);
-    ROHM_HIP_CHECK(hipMemsetAsync(scratch, 0, gemm_ln_zero_bytes(M), (hipStream_t)stream));
+    g.xln_epoch = 0x5a17c0u;      // + 64 x the scratch's pass counter, advanced by exchange_arm
+    int rc = exchange_arm(static_cast<unsigned*>(scratch), static_cast<char*>(scratch) + 64, gemm_ln_scratch_bytes(M, N) - 64, nullptr, 0, true,
+                          (hipStream_t)stream);
+    if (rc) return rc;
     return launch_gemm(g, EPI_BIAS_RES_LN, (hipStream_t)stream);
 }
 
@@ -158,8 +169,15 @@ int rohm_output_process_f32(const float* h, const float* w, const float* b, floa
     if (scratch) {
         ROHM_ARG_CHECK(scratch_bytes >= rohm_output_process_scratch_bytes() && (((uintptr_t)scratch) & 255) == 0,
                        "output_process: scratch too small / misaligned");
-        ROHM_HIP_CHECK(hipMemsetAsync(scratch, 0, 64, (hipStream_t)stream));
-        gemm_sk_bind(g, static_cast<char*>(scratch) + 256, static_cast<unsigned*>(scratch));
+        int dev = 0;
+        ROHM_HIP_CHECK(hipGetDevice(&dev));
+        if (exchange_layout_ok(dev, nullptr)) {      // else: plain tiles, like a call without scratch
+            gemm_sk_bind(g, static_cast<char*>(scratch) + 256, static_cast<unsigned*>(scratch));
+            g.xln_epoch = 0x5a17c0u + 1u;
+            int rc = exchange_arm(static_cast<unsigned*>(scratch), static_cast<char*>(scratch) + 256, 256 * sizeof(unsigned long long), nullptr, 0,
+                                  true, (hipStream_t)stream);
+            if (rc) return rc;
+        }
     }
     return launch_gemm(g, EPI_OUT_T, (hipStream_t)stream);
 }

@@ -133,19 +133,22 @@ struct GemmParams {
     // x = norm(x + sublayer(x))).  The N / BN column tiles of a row tile run at the same time on CUs of ONE XCD (the kernel's own
     // block -> tile map); each publishes its 144 per-row (mean, M2) pairs in xln_stats[row tile][column tile][144][4]
     // as (mean, tag, M2, tag) with ONE 16-byte store per row, polls the partner tiles' slots until they carry this
-    // launch's tag (xln_epoch: unique per launch, set by launch_gemm), merges the pairs by Chan's update in a fixed tree over the tile index (every tile gets
+    // launch's tag (unique per launch, below), merges the pairs by Chan's update in a fixed tree over the tile index (every tile gets
     // bit-identical statistics), normalises its accumulators in registers and stores LN(x) once.  *xln_err is set if a wait ran
-    // into its bound (never on a healthy device: the partner tiles are co-resident by construction).  Not for hipGraph capture
-    // (a replay would repeat the tag): launch_gemm refuses it on a capturing stream.
+    // into its bound (1) or a partner published from another XCD (2) -- never on a whole, exclusively owned MI355X (the partner tiles
+    // are co-resident by construction; the callers check that layout before they use these launches: exchange.hip).
+    // Tag of a launch = xln_epoch (host: salt + launch index within a pass) + 64 x *xln_pass (device word, incremented by the first
+    // kernel of every pass): recordable into a hipGraph, a replay draws fresh tags.  xln_fault != 0: test hook, column tile 0
+    // publishes under a wrong tag so that its partners' waits expire.
     const float* ln_gamma; const float* ln_beta;
-    float* xln_stats; unsigned* xln_err; unsigned xln_epoch;
+    float* xln_stats; unsigned* xln_err; unsigned xln_epoch; const unsigned* xln_pass; int xln_fault;
     unsigned* xln_xcc;      // [tiles_m][8]: XCD id + 1 of the workgroup that ran each tile (diagnostic: the tests assert the co-location)
     // ---- stream-K (EPI_OUT_T with 144 x 64 tiles: the output head, whose 288 tiles at B = 64 would take two rounds of 256 CUs with the
     // second one 1/8 full).  launch_gemm fills sk_units / sk_tiles8 when `sk_part` is bound and the shape qualifies (gemm_sk_plan):
     // 256 workgroups, each contracts sk_units consecutive (tile, K chunk) units of its XCD's sk_tiles8 tiles; a tile cut in two is
     // finished by the workgroup holding its tail, which adds the raw accumulators the other one left in sk_part[block] (flag =
-    // (XCD id + 1) << 32 | xln_epoch in sk_flag[block]).  Same caveats as the LayerNorm exchange: *xln_err reports a wait that ran
-    // into its bound (1) or a partner on another XCD (2); on a capturing stream launch_gemm keeps plain tiles.
+    // (XCD id + 1) << 32 | tag in sk_flag[block]).  Same tag and the same caveats as the LayerNorm exchange: *xln_err reports a wait
+    // that ran into its bound (1) or a partner on another XCD (2).
     float* sk_part; unsigned long long* sk_flag; int sk_units, sk_tiles8;
 };
 // stream-K scratch for launch_gemm(EPI_OUT_T): [flags: 256 x 8 B][slots: 256 x 36 KiB]; the error word is the caller's (the LayerNorm
@@ -156,12 +159,24 @@ bool gemm_sk_plan(int M, int N, int K, int* units, int* tiles8);
 // EPI_BIAS_RES_LN: can launch_gemm run (M, N, ...) with the in-kernel LayerNorm?  Scratch = stats + flags + error word.
 bool gemm_ln_supported(int M, int N, int K);
 size_t gemm_ln_scratch_bytes(int M, int N);
-size_t gemm_ln_zero_bytes(int M);                 // leading part of the scratch (error word + counters) to clear before first use
 void gemm_ln_bind(GemmParams& p, void* scratch);  // fills xln_* from a scratch block (p.M must be set)
 
+// ---- in-kernel exchanges: header words, first-use arming, layout guard (exchange.hip) -------------------------------------------
+// An exchange scratch starts with a 64-byte header: [0] error word (0 fine, 1 a bounded wait expired, 2 partners on different XCDs),
+// [1] kExchangeMagic once armed, [2] pass counter (the device part of the launch tags).  exchange_arm: on a scratch it sees for the
+// first time (magic missing: torch.empty memory, a recycled block) it zeroes the header AND the slot regions `za` / `zb` -- a tag is
+// never 0 in its XCD field, so zeroed slots are stale by construction, whatever the block held before -- and, with `bump`, advances
+// the pass counter (callers whose own first kernel does that pass bump = false).  Two tiny launches, no host synchronisation.
+constexpr unsigned kExchangeMagic = 0x524f484du;
+int exchange_arm(unsigned* header, void* za, size_t za_bytes, void* zb, size_t zb_bytes, bool bump, hipStream_t s);
+// Does this device look like what the exchanging launches assume -- 256 CUs all available to one launch, 8 XCDs, block b on XCD
+// b % 8 (a whole MI355X in SPX mode, no CU mask, nobody else's kernels resident)?  Queried once per device: properties, the CU-mask
+// environment variables and a probe launch (256 one-per-CU workgroups that must all be resident at once and report their XCD).
+// ROHM_EXCHANGE_GUARD=off trusts the device, =probe skips the environment shortcut.  `why` receives a static reason string.
+bool exchange_layout_ok(int device, const char** why);
+
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
-// Is `s` recording a hipGraph?  The launches that exchange data between their workgroups tag it with a per-launch epoch a replay would
-// repeat, so they are not used under capture: launch_gemm refuses EPI_BIAS_RES_LN and runs EPI_OUT_T as plain tiles; posenet.hip asks first.
+// Is `s` recording a hipGraph?
 bool stream_is_capturing(hipStream_t s);
 #ifdef __HIPCC__
 // All-lanes sum of a 64-wide wave, bit-identical to the xor butterfly  for (o = 32; o; o >>= 1) v += __shfl_xor(v, o)  -- but on the

@@ -36,7 +36,6 @@
 //     tile takes its bias row through LDS.  The FULL instantiation has no conditional operand loads (LayerNorm folding lives in the
 //     general one).
 #include <stdlib.h>
-#include <atomic>
 #include <type_traits>
 #include <string.h>
 #include "common.h"
@@ -141,6 +140,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // workgroup waits for one that may not have started.
     constexpr bool SK = (EPI == EPI_OUT_T) && !FULL && !CONV && BN == 64 && VAR == 0;
     int sk_lo = 0, sk_hi = 0, sk_role = -1;      // role of the current segment: 0 whole tile, 1 producer, 2 owner; -1 before the first
+    // Tag of this launch's exchange slots (LayerNorm statistics / stream-K flags): the host's part (a per-handle salt + the launch's
+    // index within a network pass) plus 64 x the workspace's pass counter, a DEVICE word that the first kernel of every pass
+    // increments -- so a launch recorded into a hipGraph carries a fresh tag on every replay (GemmParams::xln_pass).
+    unsigned xln_ep = 0;
+    if constexpr (EPI == EPI_BIAS_RES_LN || SK) {
+        xln_ep = p.xln_epoch;
+        if (p.xln_pass) xln_ep += 64u * *p.xln_pass;      // written by an EARLIER kernel of the stream: a plain (scalar) load
+    }
     // chunks of K this launch's tiles contract over, and where they start: all of K -- except for the 1x1 residual columns of a
     // fused [conv5 | residual] launch (trajnet.hip), whose weights are zero outside the centre tap: those tiles walk the centre
     // tap's chunks only, with their own split count
@@ -710,15 +717,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
         __syncthreads();
         const int g = m0 / BM, tn = n0 / BN;
-        // (which XCD this tile ran on: the co-location the exchange relies on is checked by the tests, not assumed)
-        if (tid == 0) p.xln_xcc[g * 8 + tn] = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+        // which XCD this tile ran on: recorded for the tests, and part of the tag -- a partner that publishes from another XCD is
+        // reported (status 2), not trusted silently
+        const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);      // 1 .. 8
+        if (tid == 0) p.xln_xcc[g * 8 + tn] = xcc1;
         // 3. publish this tile's (mean, M2) of every row and collect the partner tiles'.  A slot is 16 bytes (mean, tag, M2, tag)
         //    written by ONE store: each 8-byte half carries the launch's tag, so a reader that sees both tags has the data (no
         //    separate flag, no wait for the store's acknowledgement, no counter to re-arm: three dependent trips to L2 less than
-        //    publish / count / poll).  Tiles are merged in a fixed tree over the column-tile index with the own pair taken from
-        //    registers at its place: every tile of the row gets bit-identical statistics whatever the arrival order.
+        //    publish / count / poll).  tag = (epoch of the launch, 28 bits) << 4 | (XCD id + 1): never 0, so zeroed memory is stale.
+        //    Tiles are merged in a fixed tree over the column-tile index with the own pair taken from registers at its place: every
+        //    tile of the row gets bit-identical statistics whatever the arrival order.
         float* const row_stats = p.xln_stats + ((size_t)g * tiles_n * BM) * 4;
-        const unsigned tag = p.xln_epoch;
+        const unsigned ep28 = xln_ep & 0x0fffffffu;
+        const unsigned tag = (ep28 << 4) | xcc1;
         if (tid < BM) {
             auto merge = [](float ma, float qa, float mb, float qb, float n, float& m, float& q2) __attribute__((always_inline)) {
                 const float d = mb - ma;
@@ -732,7 +743,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             merge(w4[0][0], w4[0][1], w4[1][0], w4[1][1], (float)WN, m01, q01);
             merge(w4[2][0], w4[2][1], w4[3][0], w4[3][1], (float)WN, m23, q23);
             merge(m01, q01, m23, q23, 2.0f * (float)WN, a, b);                     // this tile's BN columns of row tid
-            *reinterpret_cast<f32x4*>(row_stats + ((size_t)tn * BM + tid) * 4) = f32x4{a, __uint_as_float(tag), b, __uint_as_float(tag)};
+            // (test hook, rohm_posenet_inject_exchange_fault: column tile 0 publishes under a tag nobody waits for)
+            const unsigned pub = (p.xln_fault && tn == 0) ? (tag ^ 0x80000000u) : tag;
+            *reinterpret_cast<f32x4*>(row_stats + ((size_t)tn * BM + tid) * 4) = f32x4{a, __uint_as_float(pub), b, __uint_as_float(pub)};
             float mk[8], qk[8];
             for (int it = 0;; ++it) {
                 unsigned long long lo[8], hi[8];
@@ -745,18 +758,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         hi[k] = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                bool ok = true;
+                bool ok = true, same_xcd = true;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     mk[k] = 0.f; qk[k] = 0.f;
                     if (k >= tiles_n) continue;
                     if (k == tn) { mk[k] = a; qk[k] = b; continue; }
-                    ok = ok && (unsigned)(lo[k] >> 32) == tag && (unsigned)(hi[k] >> 32) == tag;
+                    const unsigned tl = (unsigned)(lo[k] >> 32), th = (unsigned)(hi[k] >> 32);
+                    ok = ok && (tl >> 4) == ep28 && (th >> 4) == ep28 && (tl & 15u) != 0u && (th & 15u) != 0u;
+                    same_xcd = same_xcd && (tl & 15u) == xcc1 && (th & 15u) == xcc1;
                     mk[k] = __uint_as_float((unsigned)lo[k]);
                     qk[k] = __uint_as_float((unsigned)hi[k]);
                 }
-                if (ok) break;
+                if (ok) {
+                    if (!same_xcd) __hip_atomic_store(p.xln_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
+                // a wait that another launch of this pass (or an earlier row) already lost is not worth 0.2 s again: the results since
+                // the last status check are void anyway, the host falls back and re-runs (rohm_amd/diffusion/ddpm.py)
+                if ((it & 127) == 127 && __hip_atomic_load(p.xln_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 if (it > (1 << 19)) {                   // ~0.2 s: never on a healthy device (the partner tiles are co-resident); do not hang it
                     __hip_atomic_store(p.xln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -805,7 +826,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 __syncthreads();
                 if (tid == 0) {
                     const unsigned long long xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
-                    __hip_atomic_store(p.sk_flag + blockIdx.x, (xcc << 32) | p.xln_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.sk_flag + blockIdx.x, (xcc << 32) | xln_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 continue;
             }
@@ -819,13 +840,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         const unsigned long long xcc = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
                         for (int it = 0;; ++it) {
                             const unsigned long long f = __hip_atomic_load(p.sk_flag + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned)f == p.xln_epoch) {
+                            if ((unsigned)f == xln_ep && (f >> 32) != 0ull) {      // (XCD id + 1 is never 0: zeroed memory is stale)
                                 // a producer on another XCD would have left its partial in another L2: never with the hardware's
                                 // round-robin placement, and not survivable silently
                                 if ((f >> 32) != xcc) __hip_atomic_store(p.xln_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 break;
                             }
                             __builtin_amdgcn_s_sleep(1);
+                            if ((it & 127) == 127 && __hip_atomic_load(p.xln_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                             if (it > (1 << 19)) {                   // ~0.2 s: do not hang the device; the host reads the word
                                 __hip_atomic_store(p.xln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 break;
@@ -1178,9 +1200,8 @@ bool gemm_ln_supported(int M, int N, int K) {
     return M > 0 && M % BM == 0 && K > 0 && K % BK == 0 && N > 0 && ln_tile_width(M / BM, N) != 0;
 }
 
-// scratch layout: [error word, 64 B] [statistics: tiles_m x 8 column tiles x 144 rows x (mean, tag, M2, tag)] [XCD id + 1 of every tile:
+// scratch layout: [exchange header, 64 B: error word, magic, pass counter] [statistics: tiles_m x 8 column tiles x 144 rows x (mean, tag, M2, tag)] [XCD id + 1 of every tile:
 // tiles_m x 8 words]
-size_t gemm_ln_zero_bytes(int M) { (void)M; return 64; }
 static size_t ln_stats_bytes(int M) { return (size_t)((M + BM - 1) / BM) * 8 * BM * 4 * sizeof(float); }
 size_t gemm_ln_scratch_bytes(int M, int N) {
     (void)N;
@@ -1189,18 +1210,15 @@ size_t gemm_ln_scratch_bytes(int M, int N) {
 void gemm_ln_bind(GemmParams& p, void* scratch) {
     char* c = static_cast<char*>(scratch);
     p.xln_err = reinterpret_cast<unsigned*>(c);
+    p.xln_pass = reinterpret_cast<unsigned*>(c) + 2;      // exchange header (exchange.hip): [0] error, [1] magic, [2] pass counter
     p.xln_stats = reinterpret_cast<float*>(c + 64);
     p.xln_xcc = reinterpret_cast<unsigned*>(c + 64 + ln_stats_bytes(p.M));
 }
 
-// The tag of a launch's exchange slots (LayerNorm statistics, stream-K flags): unique per launch in this process and never 0, so
-// whatever an earlier launch (or nobody) left in the scratch is recognised as stale -- nothing to clear, nothing to re-arm.
-static unsigned gemm_next_epoch() {
-    static std::atomic<unsigned> epoch{0};
-    unsigned e;
-    do { e = epoch.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (e == 0u);
-    return e;
-}
+// The tag of a launch's exchange slots (LayerNorm statistics, stream-K flags) = GemmParams::xln_epoch (host part: a salt of the
+// caller + the launch's index within a pass of its network) + 64 x *xln_pass, a device word the caller's first kernel of every pass
+// increments (exchange.hip).  Nothing is cleared or re-armed between launches, and because the changing part lives in device memory
+// a launch recorded into a hipGraph gets a fresh tag on every replay.
 
 // ---- stream-K for EPI_OUT_T ----------------------------------------------------------------------------------------------------
 constexpr size_t kSkSlotBytes = (size_t)NRB * 256 * 4 * sizeof(float);      // the 9 accumulator quads of 256 threads (144 x 64 tile)
@@ -1209,6 +1227,7 @@ void gemm_sk_bind(GemmParams& p, void* scratch, unsigned* err) {
     p.sk_flag = static_cast<unsigned long long*>(scratch);
     p.sk_part = reinterpret_cast<float*>(static_cast<char*>(scratch) + (size_t)kSkWorkgroups * 8);
     p.xln_err = err;
+    p.xln_pass = err + 2;      // `err` is the first word of an exchange header
 }
 // Possible when every XCD gets the same number of tiles and every workgroup the same number of units, with no tile in more than
 // three pieces (units per workgroup >= half the chunks of a tile); worth it when that is at least four chunks (~5 us) shorter than
@@ -1232,19 +1251,13 @@ bool stream_is_capturing(hipStream_t s) {
 }
 
 static int launch_ln(const GemmParams& p, hipStream_t s) {
-    if (stream_is_capturing(s)) {
-        set_error("gemm: the LayerNorm epilogue exchanges statistics under a per-launch tag and cannot be recorded into a hipGraph");
-        return ROHM_ERR_UNSUPPORTED;
-    }
     ROHM_ARG_CHECK(gemm_ln_supported(p.M, p.N, p.K), "gemm: shape (%d, %d, %d) has no in-kernel LayerNorm form", p.M, p.N, p.K);
-    ROHM_ARG_CHECK(p.bias && p.R && p.ln_gamma && p.ln_beta && p.xln_stats && p.xln_err, "gemm: LayerNorm epilogue: null operand");
+    ROHM_ARG_CHECK(p.bias && p.R && p.ln_gamma && p.ln_beta && p.xln_stats && p.xln_err && p.xln_pass, "gemm: LayerNorm epilogue: null operand");
     ROHM_ARG_CHECK(p.ln_dim == p.N && p.ldc % 4 == 0 && p.ldr % 4 == 0 && al16(p.C) && al16(p.R) && al16(p.bias) && al16(p.ln_gamma) &&
                        al16(p.ln_beta) && (((uintptr_t)p.xln_stats) & 15) == 0 && p.ksplit <= 1 && p.conv_taps == 0,
                    "gemm: LayerNorm epilogue needs ln_dim == N and 16-byte aligned operands");
-    GemmParams q = p;
-    q.xln_epoch = gemm_next_epoch();
-    if (ln_tile_width(p.M / BM, p.N) == 128) return launch_one<128, EPI_BIAS_RES_LN, 0, true>(q, s);
-    return launch_one<64, EPI_BIAS_RES_LN, 0, true>(q, s);
+    if (ln_tile_width(p.M / BM, p.N) == 128) return launch_one<128, EPI_BIAS_RES_LN, 0, true>(p, s);
+    return launch_one<64, EPI_BIAS_RES_LN, 0, true>(p, s);
 }
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
@@ -1287,9 +1300,8 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
         case EPI_OUT_T: {
             GemmParams q = p;
             q.sk_units = q.sk_tiles8 = 0;
-            if (p.sk_part && !stream_is_capturing(s) && gemm_sk_plan(p.M, p.N, p.K, &q.sk_units, &q.sk_tiles8)) {
-                ROHM_ARG_CHECK(p.sk_flag && p.xln_err && al16(p.sk_part) && p.bias, "gemm: stream-K: bad scratch / null bias");
-                q.xln_epoch = gemm_next_epoch();
+            if (p.sk_part && gemm_sk_plan(p.M, p.N, p.K, &q.sk_units, &q.sk_tiles8)) {
+                ROHM_ARG_CHECK(p.sk_flag && p.xln_err && p.xln_pass && al16(p.sk_part) && p.bias, "gemm: stream-K: bad scratch / null bias");
                 return launch_t<64, EPI_OUT_T>(q, s);
             }
             return launch_bn<EPI_OUT_T>(q, s);

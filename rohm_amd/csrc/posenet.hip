@@ -60,6 +60,14 @@ struct rohm_posenet {
     bool ln_fold;                         // LayerNorm folded into the CONSUMER GEMMs (opt-in, measured slower) or run as a kernel
     bool ln_fused;                        // LayerNorm inside the PRODUCER GEMMs (EPI_BIAS_RES_LN; default on, ROHM_POSENET_LN_FUSED=0: kernel)
     bool head_sk;                         // output head as a stream-K launch where the shape qualifies (default on, ROHM_POSENET_HEAD_SK=0: tiles)
+    // The two launch forms above exchange data between workgroups of one launch (exchange.hip).  They are used only where the device
+    // passed the layout guard at create (exch_allowed) and until an exchange failed on this handle (exch_fallback, set by
+    // rohm_posenet_set_exchange: the Python loops then re-run the chunk on the exchange-free launches).
+    bool ln_fused_env, head_sk_env;       // what the environment asked for
+    bool exch_allowed, exch_fallback;
+    const char* exch_reason;              // why the guard refused (static string), or what it saw
+    unsigned salt;                        // host part of this handle's launch tags
+    mutable int fault_left;               // test hook (rohm_posenet_inject_exchange_fault): LayerNorm launches still to sabotage
     int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2 / 16: split GEMMs on planes (bf16x6 / bf16x3 / fp16x3)
     char* wplanes;                        // one allocation holding the weight planes of every layer
     bool pp_fold;                         // plane modes: LayerNorm folded into the plane GEMMs (ROHM_PP_LNFOLD=1, two-plane modes)
@@ -73,9 +81,12 @@ namespace rohm {
 // ----------------------------------------------------------------------------- small kernels
 // [B, C, T] (T contiguous) -> columns [col0, col0+C) of the token-major pack [B*S, KP], rows tok>=1.
 // Also zeroes the tok = 0 row and (when zero_to > C) the pad columns [col0+C, col0+zero_to).
+// `pass_ctr` (the x_t pack, i.e. the first kernel of a network pass): the workspace's pass counter, advanced by one thread -- the
+// device part of the tags of this pass's exchanging launches (exchange.hip; every reader of the word is a LATER kernel of the stream).
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                   int C, int T, int S, int KP, int col0, int zero_to) {
+                                                   int C, int T, int S, int KP, int col0, int zero_to, unsigned* pass_ctr) {
     __shared__ float tile[32][33];
+    if (pass_ctr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *pass_ctr += 1u;
     const int b = blockIdx.z;
     const int c0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -265,18 +276,18 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
     return w;
 }
 
-// The first words of w.xln are the workspace's STATUS: [0] = error word of the in-kernel exchanges (LayerNorm statistics between
-// column tiles, stream-K partials of the output head: a wait that ran into its bound, a partner on the wrong XCD), [1] = a magic that
-// says [0] has been initialised.  Every entry point arms it -- clears [0] only on a workspace it sees for the first time -- so an
-// error stays until rohm_posenet_exchange_status() reads and clears it: no host synchronisation on the forward path, and no silent
-// wrong statistics either.
-constexpr unsigned kStatusMagic = 0x524f484du;
-__global__ void arm_status_kernel(unsigned* st) {
-    if (st[1] != kStatusMagic) { st[0] = 0u; st[1] = kStatusMagic; }
+// The first words of w.xln are the workspace's exchange header (exchange.hip): [0] = error word of the in-kernel exchanges (LayerNorm
+// statistics between column tiles, stream-K partials of the output head: a wait that ran into its bound, a partner on the wrong
+// XCD), [1] = a magic that says the workspace has been armed, [2] = the pass counter.  Every entry point arms it -- on a workspace
+// it sees for the first time that zeroes the error word, the counter, the statistics slots and the stream-K flags (torch.empty
+// memory may hold anything) -- so an error stays until rohm_posenet_exchange_status() reads and clears it: no host synchronisation
+// on the forward path, and no silent wrong statistics either.
+static int arm_status(const rohm_posenet* p, const Workspace& w, int B, int T, hipStream_t s) {
+    const size_t M = (size_t)B * (T + 1);
+    return exchange_arm(reinterpret_cast<unsigned*>(w.xln), reinterpret_cast<char*>(w.xln) + 64, gemm_ln_scratch_bytes((int)M, p->D) - 64,
+                        w.sk, 256 * sizeof(unsigned long long), false, s);
 }
-static void arm_status(const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(arm_status_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<unsigned*>(w.xln));
-}
+static inline unsigned* pass_counter(const Workspace& w) { return reinterpret_cast<unsigned*>(w.xln) + 2; }
 
 static int check_shape(const rohm_posenet* p, int B, int T) {
     ROHM_ARG_CHECK(p != nullptr, "posenet: null handle");
@@ -363,7 +374,10 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     const bool fold = p->ln_fold && !planes;
     // LayerNorm inside the producer GEMMs (out-projection, FF2): whole clips of 144 tokens, widths whose column tiles pair up
     // (not while the stream records a hipGraph: the exchange's per-launch tag would be replayed -- the GEMM + LayerNorm pair then)
-    const bool lnf = p->ln_fused && !fold && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F) && !stream_is_capturing(s);
+    // (a stream that is recording a hipGraph keeps them: their tags come from the workspace's pass counter, a replay draws new ones)
+    const bool lnf = p->ln_fused && !fold && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F);
+    // tag of exchanging launch number `idx` of this pass (2 l, 2 l + 1: the LayerNorm GEMMs of layer l; 2 L: the output head)
+    auto tag_launch = [&](GemmParams& g, int idx) { g.xln_epoch = p->salt + (unsigned)idx; };
     const int parts = D / 64;
     auto ln_operand = [&](GemmParams& g, const float* stats, const float* c) {
         g.ln_stats = stats; g.ln_parts = parts; g.ln_c = c; g.ln_dim = D; g.ln_eps = 1e-5f;
@@ -390,6 +404,8 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         if (lnf) {      // y = norm1(h + out_proj(ctx)) in one launch
             g.ln_gamma = lw.n1_w; g.ln_beta = lw.n1_b; g.ln_dim = D; g.ln_eps = 1e-5f;
             gemm_ln_bind(g, w.xln);
+            tag_launch(g, 2 * l);
+            if (p->fault_left > 0) { --p->fault_left; g.xln_fault = 1; }
             if ((rc = launch_gemm(g, EPI_BIAS_RES_LN, s))) return rc;
         } else {
             if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
@@ -410,6 +426,8 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         if (lnf) {      // h = norm2(y + linear2(gelu(linear1(y))))
             g.ln_gamma = lw.n2_w; g.ln_beta = lw.n2_b; g.ln_dim = D; g.ln_eps = 1e-5f;
             gemm_ln_bind(g, w.xln);
+            tag_launch(g, 2 * l + 1);
+            if (p->fault_left > 0) { --p->fault_left; g.xln_fault = 1; }
             if ((rc = launch_gemm(g, EPI_BIAS_RES_LN, s))) return rc;
         } else {
             if ((rc = launch_gemm(g, EPI_BIAS_RES, s))) return rc;
@@ -422,19 +440,19 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         g.bias = p->out_b; g.S = S; g.ch_off = p->Cin - p->Cout; g.C_total = p->Cin; g.T = T;
         if (fold) ln_operand(g, w.stats_b, p->out_c);
         // B = 64: 2 x 144 tiles on 256 CUs -- dealt out as (tile, K chunk) units instead of a second, 1/8-full round (common.h sk_*)
-        if (p->head_sk) gemm_sk_bind(g, w.sk, reinterpret_cast<unsigned*>(w.xln));
+        if (p->head_sk) { gemm_sk_bind(g, w.sk, reinterpret_cast<unsigned*>(w.xln)); tag_launch(g, 2 * p->L); }
         if ((rc = launch_gemm(g, EPI_OUT_T, s))) return rc;
     }
     return ROHM_OK;
 }
 
 static int launch_pack(const rohm_posenet* p, const float* src, float* apack, int B, int T, int which,
-                       hipStream_t s) {
+                       hipStream_t s, unsigned* pass_ctr = nullptr) {
     const int C = p->Cin, S = T + 1;
     const int zero_to = which == 0 ? C : (p->KP - C);   // second half also clears the K padding
     dim3 grid((zero_to + 31) / 32, (T + 31) / 32, B);
     prof::Scope ps("pack", 0.0, 8.0 * B * C * T, s);
-    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, s, src, apack, C, T, S, p->KP, which * C, zero_to);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, s, src, apack, C, T, S, p->KP, which * C, zero_to, pass_ctr);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
@@ -524,6 +542,21 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         p->ln_fused = !(e6 && e6[0] == '0');
         const char* e7 = getenv("ROHM_POSENET_HEAD_SK");
         p->head_sk = !(e7 && e7[0] == '0');
+        // Both launch forms assume a whole MI355X (256 CUs free for one launch, block b on XCD b % 8); the tags leave 6 bits for the
+        // launch index of a pass.  A device that does not look like that -- partitioned, CU-masked, shared -- gets the GEMM +
+        // LayerNorm kernel pair and plain output-head tiles from the start (exchange.hip: properties + environment + a probe launch).
+        p->ln_fused_env = p->ln_fused; p->head_sk_env = p->head_sk;
+        p->exch_fallback = false;
+        p->fault_left = 0;
+        p->exch_reason = "not asked for";
+        p->exch_allowed = (p->ln_fused || p->head_sk) && 2 * n_layer + 1 <= 64 && exchange_layout_ok(device, &p->exch_reason);
+        if (!p->exch_allowed) p->ln_fused = p->head_sk = false;
+        {      // per-handle salt of the launch tags: a recycled workspace that holds another handle's (or anybody's) old words is stale
+            static unsigned counter = 0;
+            unsigned v = (unsigned)(uintptr_t)p ^ (unsigned)((uintptr_t)p >> 32) ^ (++counter * 0x9e3779b9u);
+            v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+            p->salt = v & ~63u;
+        }
         // The cond half of the input embedding (InputProcess of batch['cond'], model/posenet.py:85-87) does not change over a sampling
         // loop: rohm_posenet_sample_loop computes it once per call and each step contracts the x_t half only (K 608 -> 320).
         const char* e8 = getenv("ROHM_POSENET_COND_HOIST");
@@ -703,6 +736,33 @@ void rohm_posenet_destroy(rohm_posenet_t* h) {
 
 int rohm_posenet_precision(const rohm_posenet_t* h) { return h ? h->nplane : 0; }
 
+int rohm_posenet_exchange_mode(const rohm_posenet_t* h) {
+    if (!h) return 0;
+    return (h->ln_fused ? 1 : 0) | (h->head_sk ? 2 : 0) | ((!h->exch_allowed && (h->ln_fused_env || h->head_sk_env)) ? 4 : 0) |
+           (h->exch_fallback ? 8 : 0);
+}
+
+const char* rohm_posenet_exchange_guard(const rohm_posenet_t* h) { return h ? h->exch_reason : ""; }
+
+int rohm_posenet_set_exchange(rohm_posenet_t* h, int on) {
+    ROHM_ARG_CHECK(h != nullptr, "posenet_set_exchange: null handle");
+    if (on) {      // back to what the environment asked for and the guard allowed
+        h->exch_fallback = false;
+        h->ln_fused = h->ln_fused_env && h->exch_allowed;
+        h->head_sk = h->head_sk_env && h->exch_allowed;
+    } else {
+        h->exch_fallback = h->ln_fused || h->head_sk || h->exch_fallback;
+        h->ln_fused = h->head_sk = false;
+    }
+    return ROHM_OK;
+}
+
+int rohm_posenet_inject_exchange_fault(rohm_posenet_t* h, int n_launches) {
+    ROHM_ARG_CHECK(h != nullptr && n_launches >= 0, "posenet_inject_exchange_fault: bad argument");
+    h->fault_left = n_launches;
+    return ROHM_OK;
+}
+
 size_t rohm_posenet_workspace_bytes(const rohm_posenet_t* h, int B, int T) {
     if (!h || B <= 0 || T <= 0) return 0;
     return carve(h, B, T, nullptr).floats * sizeof(float);
@@ -720,8 +780,8 @@ int rohm_posenet_forward(const rohm_posenet_t* h, const float* x_t, const float*
         set_error("posenet_forward: workspace too small (%zu < %zu)", ws_bytes, w.floats * sizeof(float));
         return ROHM_ERR_WORKSPACE;
     }
-    arm_status(w, s);
-    if ((rc = launch_pack(h, x_t, w.apack, B, T, 0, s))) return rc;
+    if ((rc = arm_status(h, w, B, T, s))) return rc;
+    if ((rc = launch_pack(h, x_t, w.apack, B, T, 0, s, pass_counter(w)))) return rc;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;
     if ((rc = run_network(h, w, t, 0, nullptr, x0_out, B, T, s))) return rc;
     const size_t n = (size_t)B * h->Cin * T;
@@ -744,7 +804,7 @@ int rohm_posenet_exchange_status(const rohm_posenet_t* h, int B, int T, void* ws
     unsigned st[2] = {0u, 0u};
     ROHM_HIP_CHECK(hipMemcpyAsync(st, w.xln, sizeof(st), hipMemcpyDeviceToHost, s));
     ROHM_HIP_CHECK(hipStreamSynchronize(s));
-    if (st[1] != kStatusMagic || st[0] == 0u) return ROHM_OK;      // never used, or clean
+    if (st[1] != kExchangeMagic || st[0] == 0u) return ROHM_OK;      // never used, or clean
     ROHM_HIP_CHECK(hipMemsetAsync(w.xln, 0, sizeof(unsigned), s));
     set_error("posenet: an in-kernel exchange failed since the last check (%s): the outputs computed on this workspace since then are "
               "not valid", st[0] == 2u ? "partner workgroups were placed on different XCDs" : "a wait for a partner workgroup ran into its bound");
@@ -768,7 +828,7 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
     const size_t n = (size_t)B * h->Cin * T;
     ROHM_ARG_CHECK(n_steps <= kLoopChunk, "posenet_sample_loop: at most %d steps per call", kLoopChunk);
     if (n_steps == 0) return ROHM_OK;
-    arm_status(w, s);
+    if ((rc = arm_status(h, w, B, T, s))) return rc;
     if ((rc = launch_pack(h, cond, w.apack, B, T, 1, s))) return rc;   // cond is constant over the loop
     // ... and so is its half of the input embedding: one [0 | cond] pass of the embed GEMM now, K = KX instead of KP in every step.
     // (The steps' A rows still carry cond in columns C .. KX: w_embed_x is zero there.)
@@ -788,7 +848,7 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
         ROHM_ARG_CHECK(sigma == 0.f || noise, "posenet_sample_loop: noise is required when sigma != 0");
         if (x_in_last && i == n_steps - 1)       // the reference keeps the input of the last step in batch['x_t']
             ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        if ((rc = launch_pack(h, x, w.apack, B, T, 0, s))) return rc;
+        if ((rc = launch_pack(h, x, w.apack, B, T, 0, s, pass_counter(w)))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
         if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s, hoist))) return rc;
         if ((rc = launch_finish(x0, cond, x, noise ? noise + (size_t)i * n : nullptr, x, c1, c2, sigma, h->traj,

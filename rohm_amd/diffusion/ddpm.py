@@ -152,6 +152,9 @@ class DDPMSampler:
         raw = getattr(model, 'model', model)
         batch['x_t'] = x
         x0 = raw(batch, self._mapped(t))
+        if self._exchange_failed(raw):                     # the forward is a pure function of (x, cond, t): run it again, exchange-free
+            x0 = raw(batch, self._mapped(t))
+            self._check_exchange(raw)
         noise = self._noise(step, x)                       # drawn BEFORE guidance (…posenet.py:458)
         grads = []
         if grad_type is not None:
@@ -219,16 +222,40 @@ class DDPMSampler:
             return self.noise_source(-1, like).to(device=device, dtype=torch.float32).contiguous()
         return torch.randn(*shape, device=device)
 
+    @staticmethod
+    def _copy_into(buf, x):
+        if buf is None:
+            return x.clone()
+        buf.copy_(x)
+        return buf
+
     def _fused_ok(self, raw):
         return hasattr(raw, 'sample_loop_native') and not self.rescale_timesteps
 
     @staticmethod
     def _check_exchange(raw):
-        """End of a sampling run: ask the network whether one of its in-kernel exchanges failed on the way
-        (rohm_posenet_exchange_status: one stream synchronisation per RUN, raises instead of returning wrong samples)."""
+        """Ask the network whether one of its in-kernel exchanges failed since the last check (rohm_posenet_exchange_status: one
+        stream synchronisation) and raise instead of returning wrong samples."""
         fn = getattr(raw, 'check_exchange', None)
         if fn is not None:
             fn()
+
+    @staticmethod
+    def _exchange_failed(raw):
+        """After a fused chunk / a step-wise forward: True if an in-kernel exchange failed since the last check -- the network has
+        then switched itself to its exchange-free launches (PoseNet.recover_exchange) and the caller re-runs what it just computed.
+        Networks without such launches (TrajNet) answer False without touching the device."""
+        fn = getattr(raw, 'recover_exchange', None)
+        return bool(fn()) if fn is not None else False
+
+    @staticmethod
+    def _new_run(raw):
+        """Start of a sampling run: per-run caches of the guidance (the all-reduced global batch size, rohm_amd/guidance.py) are
+        dropped so that every rank enters the same collectives in every run, whatever its local batch sizes were before."""
+        cache = getattr(raw, '__dict__', {}).get('_rohm_global_batch')
+        if cache:
+            for k in [k for k in cache if k != 'fixed']:
+                del cache[k]
 
     def p_sample_loop(self, model, batch, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
@@ -236,6 +263,7 @@ class DDPMSampler:
                       dump_steps=None, const_noise=False, save_intermediate_result=False):
         """Full sampling run; returns the last `sample` (or last `pred_xstart` with `early_stop`)."""
         raw = getattr(model, 'model', model)
+        self._new_run(raw)
         if dump_steps is not None or save_intermediate_result or not self._fused_ok(raw):
             final = None
             dump = []
@@ -286,6 +314,7 @@ class DDPMSampler:
         with torch.no_grad():
             pos = 0
             x_in_last = None
+            x_save = None
             while pos < n_free:
                 n = min(self.fused_chunk, n_free - pos)
                 ts = indices[pos:pos + n]
@@ -300,8 +329,16 @@ class DDPMSampler:
                 last = (pos + n == len(indices))
                 if last:      # the native loop copies the input of its last step out (one device copy, no extra loop call)
                     x_in_last = torch.empty_like(x)
+                x_save = self._copy_into(x_save, x) if hasattr(raw, 'recover_exchange') else None
                 x0 = raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz,
                                             want_x0_last=last, batch=batch, x_in_last=x_in_last if last else None)
+                if x_save is not None and self._exchange_failed(raw):
+                    # an in-kernel exchange of this chunk failed: the network now runs its exchange-free launches; the chunk is
+                    # repeated from its saved input with the same noise -- exact, not approximately right
+                    x.copy_(x_save)
+                    x0 = raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz,
+                                                want_x0_last=last, batch=batch, x_in_last=x_in_last if last else None)
+                    self._check_exchange(raw)
                 if last:
                     x0_last = x0
                 pos += n
@@ -369,6 +406,7 @@ class DDPMSampler:
         indices = self._indices(0, False)
         with torch.no_grad():
             pos = 0
+            x_save = None
             while pos < len(indices):
                 n = min(self.fused_chunk, len(indices) - pos)
                 ts = indices[pos:pos + n]
@@ -379,8 +417,14 @@ class DDPMSampler:
                     nz = torch.stack([self._noise(pos + k, x) for k in range(n)])
                 else:
                     nz = torch.randn((n,) + tuple(x.shape), device=x.device, dtype=torch.float32)
+                x_save = self._copy_into(x_save, x) if hasattr(raw, 'recover_exchange') else None
                 raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz, want_x0_last=False,
                                        batch=batch)
+                if x_save is not None and self._exchange_failed(raw):      # see _fused_loop
+                    x.copy_(x_save)
+                    raw.sample_loop_native(x, cond, [self.timestep_map[i] for i in ts], coef, nz, want_x0_last=False,
+                                           batch=batch)
+                    self._check_exchange(raw)
                 pos += n
         batch['x_t'] = x
         self._check_exchange(raw)

@@ -32,16 +32,18 @@ def _allreduce_sum(t, group):
 
 
 def global_batch(B, group, device, model=None):
-    """Total number of clips over the ranks of `group` (shards may be ragged).  Constant over a run: given by the caller of
-    `sharding.use_global_batch_guidance(..., global_batch=)` or all-reduced once and cached on the model (per local batch size) --
-    not an all-reduce + host sync on every guided step."""
+    """Total number of clips over the ranks of `group` (shards may be ragged).  Constant over a sampling run: given by the caller of
+    `sharding.use_global_batch_guidance(..., global_batch=)`, or all-reduced ONCE PER RUN -- at the first guided 2-D step, which
+    every rank reaches at the same loop index -- and kept until the next run starts (`DDPMSampler._new_run` drops it).  The decision
+    to enter the collective must not depend on anything rank-local: a cache keyed by the local batch size would let one rank of a
+    ragged split hit an old entry while its peer all-reduces alone."""
     cache = model.__dict__.setdefault('_rohm_global_batch', {}) if model is not None else {}
     if 'fixed' in cache:
         return cache['fixed']
-    if B not in cache:
+    if 'run' not in cache:
         n = torch.tensor([float(B)], device=device)
-        cache[B] = float(_allreduce_sum(n, group).item())
-    return cache[B]
+        cache['run'] = float(_allreduce_sum(n, group).item())
+    return cache['run']
 
 
 def _stats(model, device):

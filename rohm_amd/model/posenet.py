@@ -100,14 +100,43 @@ class _NativePoseNet:
             self._ws[key] = ws
         return ws
 
-    def check_exchange(self):
-        """rohm_posenet_exchange_status on the workspace(s) of the current stream: synchronises it and raises RohmHipError
-        (ROHM_ERR_EXCHANGE) if an in-kernel exchange failed in a forward / loop since the last check."""
+    def poll_exchange(self):
+        """rohm_posenet_exchange_status on the workspace(s) of the current stream: synchronises it; returns None, or the library's
+        message if an in-kernel exchange failed in a forward / loop since the last check (the word is cleared by the read)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        msg = None
         for (B, T, st), ws in list(self._ws.items()):
             if st == stream:
-                check(lib().rohm_posenet_exchange_status(self.handle, B, T, ptr(ws), ws.numel(), stream_ptr(self.device)),
-                      'rohm_posenet_exchange_status')
+                rc = lib().rohm_posenet_exchange_status(self.handle, B, T, ptr(ws), ws.numel(), stream_ptr(self.device))
+                if rc == _lib.ROHM_ERR_EXCHANGE:
+                    m = lib().rohm_last_error()
+                    msg = f'rohm_posenet_exchange_status failed (code {rc}): {m.decode() if m else "?"}'
+                else:
+                    check(rc, 'rohm_posenet_exchange_status')
+        return msg
+
+    def check_exchange(self):
+        """poll_exchange that raises RohmHipError (ROHM_ERR_EXCHANGE)."""
+        msg = self.poll_exchange()
+        if msg is not None:
+            raise _lib.RohmHipError(msg)
+
+    @property
+    def exchange_mode(self):
+        """include/rohm_hip.h rohm_posenet_exchange_mode: bit 0 LayerNorm inside the GEMMs, bit 1 stream-K head, bit 2 refused by
+        the layout guard at create, bit 3 switched off after a failed exchange."""
+        return int(lib().rohm_posenet_exchange_mode(self.handle))
+
+    @property
+    def exchange_guard(self):
+        m = lib().rohm_posenet_exchange_guard(self.handle)
+        return m.decode() if m else ''
+
+    def set_exchange(self, on):
+        check(lib().rohm_posenet_set_exchange(self.handle, 1 if on else 0), 'rohm_posenet_set_exchange')
+
+    def inject_exchange_fault(self, n_launches):
+        check(lib().rohm_posenet_inject_exchange_fault(self.handle, int(n_launches)), 'rohm_posenet_inject_exchange_fault')
 
     def __del__(self):
         try:
@@ -219,9 +248,30 @@ class PoseNet(nn.Module):
     def check_exchange(self):
         """Raise if a forward / sampling loop since the last check saw one of its in-kernel exchanges fail (the LayerNorm inside
         the out-projection / FF2 GEMMs, the stream-K output head: include/rohm_hip.h rohm_posenet_exchange_status).  Synchronises
-        the current stream; the diffusion loops call it once per run."""
+        the current stream.  MANDATORY after direct `forward` calls whose output matters (the status is not polled per forward: that
+        would be a host synchronisation on the hot path); the diffusion loops use `recover_exchange` instead."""
         if self._native is not None:
             self._native.check_exchange()
+
+    def recover_exchange(self):
+        """What the diffusion loops call after every fused chunk of steps and after every step-wise forward: False if every
+        in-kernel exchange since the last check went through.  Otherwise the handle is switched -- for good -- to the exchange-free
+        launches (GEMM + LayerNorm kernel pair, plain output-head tiles: rohm_posenet_set_exchange), a warning says so, and True
+        tells the caller to RE-RUN what it computed since the last check (noise is injected or pre-drawn, so the re-run is exact).
+        A failure while the exchange-free launches were already in use cannot come from them and raises."""
+        nat = self._native
+        if nat is None:
+            return False
+        msg = nat.poll_exchange()
+        if msg is None:
+            return False
+        if nat.exchange_mode & 3 == 0:
+            raise _lib.RohmHipError(msg + ' -- and the handle was not using the exchanging launches')
+        nat.set_exchange(False)
+        warnings.warn('PoseNet: ' + msg + '.  The device is shared, partitioned or masked in a way the layout guard did not see at '
+                      'create; this handle now runs the GEMM + LayerNorm kernel pair and plain output-head tiles (a few percent '
+                      'slower), and the affected steps are re-run.')
+        return True
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch, timesteps):

@@ -79,8 +79,8 @@ def use_global_batch_guidance(model, group=True, global_batch=None):
     clips are sharded over the ranks of `group` (default process group if True; None switches back to per-rank
     semantics).  Costs one 8-byte all-reduce per guided step (the two skating mask counts, model/posenet.py:231,243).
     The 2-D term needs the global batch size (its loss is a mean over the batch, :309): pass `global_batch` if the caller knows
-    it (no collective at all); otherwise it is all-reduced ONCE, at the first guided step, and cached per local batch size --
-    call this function again if the split changes."""
+    it (no collective at all); otherwise it is all-reduced once per sampling run, at the first guided step -- every rank enters
+    that collective in every run, whatever its local batch size (ragged splits included)."""
     raw = getattr(model, 'model', model)
     raw.guidance_group = group
     raw.__dict__['_rohm_global_batch'] = {} if global_batch is None else {'fixed': float(global_batch)}

@@ -206,6 +206,80 @@ def test_global_batch_guidance_equals_full_batch():
     assert max_abs(local.cpu(), full_s[0:3].cpu()) > 1e-3 * float(full_s.abs().max())
 
 
+def _mixed_batch(B, mean, std):
+    """B clips whose foot-contact channels differ per clip: clip 1 has no contact at all, clip 2 contact in every frame, clip 3
+    contact on the left foot only, every fifth clip a shorter contact window -- so the batch-wide mask counts (model/posenet.py:
+    231,243) are sums of very different per-clip contributions."""
+    x0 = synth.plausible_motion(70 + B, B, 143, mean, std)
+    lo = torch.from_numpy((0.0 - mean[290:]) / std[290:]).view(4, 1, 1)
+    hi = torch.from_numpy((1.0 - mean[290:]) / std[290:]).view(4, 1, 1)
+    x0[1, 290:] = lo
+    x0[2, 290:] = hi
+    x0[3, 290:292] = hi[:2]
+    x0[3, 292:] = lo[2:]
+    for b in range(5, B, 5):
+        x0[b, 290:, :, :40 + b] = lo
+    return x0
+
+
+@pytest.mark.parametrize('B', [32, 64])
+def test_guidance_gradients_vs_oracle_at_the_batch_sizes_of_the_configs(B):
+    """BASELINE configs[3] runs the guidance at B = 32, the headline batch is 64; the batch-wide reductions (the two skating mask
+    counts -- fp32 atomicAdd of small integers in csrc/smplx.hip -- and the mean over the batch of the 2-D loss,
+    model/posenet.py:231,243,309) are exactly what scales with B.  Both gradients against oracle/geometry.py, T = 143, clips with
+    empty, full and partial contact masks in one batch; same bars as the B <= 4 tests."""
+    from rohm_amd.guidance import guide_2d_projection, guide_skating
+    mean, std = synth.synthetic_stats(0)
+    net = _posenet(mean, std)
+    m, s = torch.from_numpy(mean), torch.from_numpy(std)
+    body = G.BodyModel(synth.synthetic_smplx_tensors(0))
+    x0 = _mixed_batch(B, mean, std)
+    ref_s = G.guide_skating(x0, m, s, body)
+    grad_s, counts = guide_skating(net, {}, {'pred_xstart': x0.to(DEV)}, None, 'x_0', return_counts=True)
+    # the counts are exact integers: compare with the per-clip masks the oracle's definition gives
+    per_clip = [guide_skating(net, {}, {'pred_xstart': x0[b:b + 1].to(DEV)}, None, 'x_0', return_counts=True)[1].cpu() for b in range(B)]
+    assert torch.equal(counts.cpu(), torch.stack(per_clip).sum(0)) and float(per_clip[1].abs().max()) == 0.0
+    assert max_abs(grad_s.cpu(), ref_s) < 1e-4 * float(ref_s.abs().max())
+    assert float(grad_s[1].abs().max()) == 0.0                                  # the clip without contact gets no skating gradient
+    cam = synth.synthetic_camera_batch(3, B)
+    ref_p = G.guide_2d_projection(x0, m, s, body, cam['transf_matrix'], cam['focal_length'], cam['camera_center'],
+                                  cam['keypoints_2d'], torch.tensor(synth.SYNTH_CAM_R), torch.tensor(synth.SYNTH_CAM_T))
+    grad_p = guide_2d_projection(net, {k: v.to(DEV) for k, v in cam.items()}, {'pred_xstart': x0.to(DEV)}, None, 'x_0')
+    assert max_abs(grad_p.cpu(), ref_p) < 1e-3 * float(ref_p.abs().max())
+
+
+def test_global_batch_guidance_4_ranks_of_8_equals_batch_32():
+    """configs[4]: 4 x 32; here 4 'ranks' x 8 clips against the single-process B = 32 gradients (themselves held to the oracle
+    above): mask counts summed as the all-reduce would, 2-D term scaled by B_local / B_global."""
+    from rohm_amd.guidance import guide_2d_projection, guide_skating
+    from rohm_amd.sharding import slice_bounds, use_global_batch_guidance
+    mean, std = synth.synthetic_stats(0)
+    net = _posenet(mean, std)
+    B, world = 32, 4
+    x0 = _mixed_batch(B, mean, std).to(DEV)
+    cam = {k: v.to(DEV) for k, v in synth.synthetic_camera_batch(3, B).items()}
+    full_s, full_counts = guide_skating(net, {}, {'pred_xstart': x0}, None, 'x_0', return_counts=True)
+    full_p = guide_2d_projection(net, dict(cam), {'pred_xstart': x0}, None, 'x_0')
+    shards = [slice(*slice_bounds(B, world, r)) for r in range(world)]
+    contrib = []
+    for sl in shards:
+        use_global_batch_guidance(net, group=lambda t: t)
+        contrib.append(guide_skating(net, {}, {'pred_xstart': x0[sl].contiguous()}, None, 'x_0', return_counts=True)[1].clone())
+    total = torch.stack(contrib).sum(0)
+    assert torch.equal(total, full_counts)
+
+    def fake_allreduce(t):
+        t.copy_(total if t.numel() == 2 else torch.tensor([float(B)], device=t.device))
+        return t
+    use_global_batch_guidance(net, group=fake_allreduce)
+    gs = torch.cat([guide_skating(net, {}, {'pred_xstart': x0[sl].contiguous()}, None, 'x_0') for sl in shards])
+    gp = torch.cat([guide_2d_projection(net, {k: v[sl].contiguous() for k, v in cam.items()},
+                                        {'pred_xstart': x0[sl].contiguous()}, None, 'x_0') for sl in shards])
+    use_global_batch_guidance(net, group=None)
+    assert max_abs(gs.cpu(), full_s.cpu()) <= 1e-6 * float(full_s.abs().max())
+    assert max_abs(gp.cpu(), full_p.cpu()) <= 1e-6 * float(full_p.abs().max())
+
+
 # ---------------------------------------------------------------------------------------------- PROX (BASELINE config 4)
 def _prox_net(g):
     mean, std = synth.synthetic_stats(int(g['stats_seed']))

@@ -77,9 +77,11 @@ def test_ragged_splits_world4_and_world8():
 
 
 def test_global_batch_is_reduced_once_per_run_or_given_by_the_caller():
-    """the global batch size is constant over a run -- one all-reduce at the first guided step (cached per
-    local batch size), or none when the caller states it; never one collective + host sync per guided step."""
+    """The global batch size is constant over a run: ONE all-reduce at the first guided step of every run -- entered by every rank
+    whatever its local batch size was in earlier runs (a cache keyed by the local batch size let one rank of a ragged split
+    skip a collective its peer entered) -- or none when the caller states it; never one collective + host sync per guided step."""
     from rohm_amd import guidance
+    from rohm_amd.diffusion.ddpm import DDPMSampler
 
     class M:
         pass
@@ -92,11 +94,54 @@ def test_global_batch_is_reduced_once_per_run_or_given_by_the_caller():
     for _ in range(5):
         assert guidance.global_batch(8, group, 'cpu', m) == 32.0
     assert calls == [1]
-    assert guidance.global_batch(7, group, 'cpu', m) == 28.0 and calls == [1, 1]      # another local batch size: its own entry
+    DDPMSampler._new_run(m)                                                            # the next sampling run starts: reduce again
+    assert guidance.global_batch(7, group, 'cpu', m) == 28.0 and calls == [1, 1]
+    assert guidance.global_batch(7, group, 'cpu', m) == 28.0 and calls == [1, 1]
     sharding.use_global_batch_guidance(m, group)                                       # re-arming forgets the cache
     assert guidance.global_batch(8, group, 'cpu', m) == 32.0 and calls == [1, 1, 1]
     m = sharding.use_global_batch_guidance(M(), group, global_batch=256)
+    DDPMSampler._new_run(m)                                                            # ... but never what the caller stated
     assert guidance.global_batch(32, group, 'cpu', m) == 256.0 and calls == [1, 1, 1]
+
+
+def _worker_ragged_runs(rank, world, port, q):
+    """Two sampling runs with different ragged splits -- (3, 2) then (3, 3): rank 0's local batch size repeats, rank 1's does not.
+    Every rank must enter exactly one size-1 all-reduce per run, followed by the per-step mask-count all-reduce (size 2)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from rohm_amd import guidance
+        from rohm_amd.diffusion.ddpm import DDPMSampler
+
+        class M:
+            pass
+        m = sharding.use_global_batch_guidance(M())
+        totals = []
+        for split in ((3, 2), (3, 3)):
+            DDPMSampler._new_run(m)
+            for _step in range(3):                                   # guided steps of the run
+                totals.append(guidance.global_batch(split[rank], True, 'cpu', m))
+                counts = torch.tensor([1.0 + rank, 2.0])
+                guidance._allreduce_sum(counts, True)                # a mis-paired collective (size 1 vs size 2) would raise or hang here
+                assert counts.tolist() == [3.0, 4.0]
+        q.put((rank, totals))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_batch_over_runs_with_changing_ragged_splits_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged_runs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, totals in res:
+        assert totals == [5.0] * 3 + [6.0] * 3
 
 
 def test_slice_bounds_cover_everything():
