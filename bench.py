@@ -340,11 +340,11 @@ def scheme_bench(args, world, rank, dev, dist):
         bt, bp = batches()
         run = run_prox_iterations if ego else run_amass_iterations
         pose, _, _ = run(sargs, nets, diffs, bt, bp, tds, pds, layer)
-        if dist is not None:
-            sharding.gather_clips(pose, world * B, force=True)
+        gather.submit(pose)
         return pose
 
-    elapsed, out, prof = timed_region(one_pass, args, world, dev, dist)
+    gather = ResultGather(world * B, dist)
+    elapsed, out, prof = timed_region(one_pass, args, world, dev, dist, drain=gather.drain)
     finite = bool(torch.isfinite(out).all())
     assert finite, 'non-finite samples'
     if rank == 0:
@@ -357,23 +357,14 @@ def scheme_bench(args, world, rank, dev, dist):
         kernels = {k: {'launches': v['launches'], 'avg_us': round(v['total_ms'] / v['launches'] * 1e3, 2),
                        'time_share': round(v['total_ms'] / all_ms, 4)}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
-        if ego:
-            metric = (f'denoised 145-frame clips/sec, 3-iteration PROX/EgoBody scheme (TrajNet 100 + 2 x TrajControl 100 + '
-                      f'3 x PoseNet 980 of {S} steps, 2-D + skating guidance on t<=100)')
-            wl = (f'EgoBody scheme [BASELINE.json configs[4] / SURVEY cfg 5], batch={B} clips per GPU, sample_iter=3, '
-                  f'visibility mask 80 % visible, early stop, guidance weights as the reference (3e5 / 1e5)')
-        else:
-            metric = (f'denoised 145-frame clips/sec, full 2-iteration RoHM scheme (TrajNet 100 + PoseNet {S} '
-                      f'+ TrajControl 100 + PoseNet {S} steps, skating guidance on t<=50)')
-            wl = (f'full scheme [BASELINE.json configs[2] / SURVEY cfg 3], batch={B} clips per GPU, '
-                  f'sample_iter=2, mask_scheme=lower, guidance weights as the reference (3e6)')
+        metric, wl = scheme_names(args.workload, B, S)
         rec = {'metric': metric,
                'value': clips / elapsed, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': wl, 'clips_per_gpu': B, 'ddpm_steps': S, 'finite_output': finite,
                           'output_digest': [float(out.double().sum()), float(out.double().abs().sum())],      # rank 0's clips
-                          'sharding': sharding_note(args, world, B, dist)},
+                          'sharding': sharding_note(args, world, B, dist), 'cpu_binding': args.cpu_binding},
                'roofline': {'kernel': 'gemm_f32_kernel (all fp32-MFMA GEMM / conv-GEMM launches, sampled)', 'bound': 'mfma',
                             'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': None,
@@ -381,6 +372,20 @@ def scheme_bench(args, world, rank, dev, dist):
                             'kernels': kernels}}
         print(json.dumps(rec), flush=True)
     finish(world, dist)
+
+
+def scheme_names(workload, B, S):
+    """(metric, config.workload) of the scheme / egobody workloads -- one place, so that the launcher self-test names what the
+    measuring path would name."""
+    if workload == 'egobody':
+        return ((f'denoised 145-frame clips/sec, 3-iteration PROX/EgoBody scheme (TrajNet 100 + 2 x TrajControl 100 + '
+                 f'3 x PoseNet 980 of {S} steps, 2-D + skating guidance on t<=100)'),
+                (f'EgoBody scheme [BASELINE.json configs[4] / SURVEY cfg 5], batch={B} clips per GPU, sample_iter=3, '
+                 f'visibility mask 80 % visible, early stop, guidance weights as the reference (3e5 / 1e5)'))
+    return ((f'denoised 145-frame clips/sec, full 2-iteration RoHM scheme (TrajNet 100 + PoseNet {S} '
+             f'+ TrajControl 100 + PoseNet {S} steps, skating guidance on t<=50)'),
+            (f'full scheme [BASELINE.json configs[2] / SURVEY cfg 3], batch={B} clips per GPU, '
+             f'sample_iter=2, mask_scheme=lower, guidance weights as the reference (3e6)'))
 
 
 def sharding_note(args, world, B, dist):
@@ -477,6 +482,16 @@ def extras(args, budget_s=420.0):
     return second, cfg
 
 
+def exchange_note(net):
+    """Which launch forms the PoseNet handle ended the run with (include/rohm_hip.h rohm_posenet_exchange_mode)."""
+    nat = getattr(net, '_native', None)
+    if nat is None:
+        return None
+    m = nat.exchange_mode
+    return {'layernorm_in_gemm': bool(m & 1), 'stream_k_head': bool(m & 2), 'refused_by_layout_guard': bool(m & 4),
+            'fell_back_after_failed_exchange': bool(m & 8), 'guard': nat.exchange_guard}
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -496,11 +511,94 @@ def spawn_ranks(n, argv, env=None):
     return subprocess.call(cmd, env=e)
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (sysfs cpulist format)."""
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def plan_rank_cpus(local_rank, local_world, allowed, node_of_rank=None, cpus_of_node=None):
+    """Which CPUs rank `local_rank` of `local_world` ranks on this host should run on.  `allowed`: this process's affinity mask.
+    `node_of_rank(r)`: NUMA node of rank r's GPU (None / negative = unknown); `cpus_of_node(n)`: that node's CPUs.  Ranks whose GPUs
+    hang off the same node split that node's allowed CPUs evenly (contiguous blocks, in rank order); a rank whose node is unknown,
+    or has no allowed CPU, takes its block of an even split of the whole mask.  Never returns an empty list: with more ranks than
+    CPUs ranks share.  Pure function: tests/test_bench_launcher.py drives it with made-up topologies."""
+    allowed = sorted(allowed)
+
+    def block(cpus, idx, parts):
+        if not cpus:
+            return []
+        if len(cpus) < parts:
+            return [cpus[idx % len(cpus)]]
+        base, extra = divmod(len(cpus), parts)
+        lo = idx * base + min(idx, extra)
+        return cpus[lo:lo + base + (1 if idx < extra else 0)]
+    nodes = [None] * local_world
+    if node_of_rank is not None and cpus_of_node is not None:
+        for r in range(local_world):
+            try:
+                n = node_of_rank(r)
+            except Exception:
+                n = None
+            nodes[r] = n if (n is not None and n >= 0) else None
+    mine = nodes[local_rank]
+    if mine is not None:
+        try:
+            node_cpus = sorted(set(cpus_of_node(mine)) & set(allowed))
+        except Exception:
+            node_cpus = []
+        peers = [r for r in range(local_world) if nodes[r] == mine]
+        got = block(node_cpus, peers.index(local_rank), len(peers))
+        if got:
+            return got, f'NUMA node {mine}: {len(got)} of its {len(node_cpus)} allowed CPUs ({len(peers)} rank(s) on the node)'
+    got = block(allowed, local_rank, local_world)
+    return got, f'even split of the {len(allowed)} allowed CPUs (GPU NUMA node unknown)'
+
+
+def gpu_numa_node(index):
+    """NUMA node of HIP device `index` from sysfs (PCI address of the device), or None."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        addr = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+        n = int(open(f'/sys/bus/pci/devices/{addr}/numa_node').read())
+        return n if n >= 0 else None
+    except Exception:
+        return None
+
+
+def node_cpus(node):
+    return parse_cpulist(open(f'/sys/devices/system/node/node{node}/cpulist').read())
+
+
+def bind_rank(local_rank, local_world, gpu=True):
+    """Pin this rank to its share of the host's cores (the TrajNet loops are host-enqueue-bound, eight unpinned
+    ranks would fight over whatever cores the OS hands out and wander between NUMA nodes).  Returns the note that goes into
+    `config.cpu_binding`.  ROHM_BENCH_NO_BIND=1 leaves the affinity alone."""
+    if os.environ.get('ROHM_BENCH_NO_BIND') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return 'not bound'
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus, how = plan_rank_cpus(local_rank, local_world, allowed, gpu_numa_node if gpu else None, node_cpus if gpu else None)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError as e:
+        return f'not bound ({e})'
+    torch.set_num_threads(max(1, min(len(cpus), 8)))
+    return f'rank bound to {len(cpus)} CPU(s) [{cpus[0]}..{cpus[-1]}]: {how}'
+
+
 def init_ranks(args):
     """(world, rank, device, dist): one process per GPU; `--gpus` must agree with the launched world size."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    args.cpu_binding = 'single rank: not bound'
+    if world > 1:
+        args.cpu_binding = bind_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)), gpu=args.backend != 'gloo')
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                          f'--nproc-per-node {args.gpus} (or drop WORLD_SIZE and let --gpus spawn the ranks)')
@@ -533,10 +631,14 @@ def init_ranks(args):
     return world, rank, dev, dist
 
 
-def timed_region(one_pass, args, world, dev, dist, profile=True):
+def timed_region(one_pass, args, world, dev, dist, profile=True, drain=None):
     """W untimed warm-up passes, then EXACTLY K passes bracketed by barrier + device synchronize on both sides; the
-    elapsed time is the MAX over ranks.  Returns (elapsed_s, last_output, profiler_dict)."""
+    elapsed time is the MAX over ranks.  `drain`: completes what `one_pass` left in flight (the asynchronous result all-gather of
+    the last pass) -- called inside the bracket, so the timed region contains every collective it started.
+    Returns (elapsed_s, last_output, profiler_dict)."""
     def sync():
+        if drain is not None:
+            drain()
         if dist is not None:
             dist.barrier()
         if dev.type == 'cuda':
@@ -563,6 +665,27 @@ def timed_region(one_pass, args, world, dev, dist, profile=True):
     return elapsed, out, prof
 
 
+class ResultGather:
+    """The path's only exchange -- the finished clips of a pass, one all-gather -- issued asynchronously: it runs on the backend's
+    stream while this rank's stream already works on the next pass, and is completed before the next one is issued (at most one
+    in flight) or by `drain()` at the end of the timed region."""
+
+    def __init__(self, n_total, dist):
+        self.n_total, self.dist, self.pending, self.last = n_total, dist, None, None
+
+    def submit(self, x0):
+        from rohm_amd import sharding
+        if self.dist is None:
+            return
+        self.drain()
+        self.pending = sharding.gather_clips(x0, self.n_total, force=True, async_op=True)
+
+    def drain(self):
+        if self.pending is not None:
+            self.last = self.pending.result()
+            self.pending = None
+
+
 def finish(world, dist):
     if dist is not None:
         dist.barrier()
@@ -576,18 +699,29 @@ def selftest_bench(args, world, rank, dev, dist):
     from rohm_amd import sharding
     B = args.batch
 
+    gather = ResultGather(world * B, dist if world > 1 else None)
+
     def one_pass():
         x0 = torch.full((B, 4), float(rank))
         time.sleep(0.01 * (rank + 1))
-        return sharding.gather_clips(x0, world * B) if world > 1 else x0
-    elapsed, out, _ = timed_region(one_pass, args, world, dev, dist, profile=False)
+        gather.submit(x0)
+        return x0
+    elapsed, out, _ = timed_region(one_pass, args, world, dev, dist, profile=False, drain=gather.drain)
+    if world > 1:
+        out = gather.last
     if rank == 0:
         ranks_seen = sorted(set(int(v) for v in out[:, 0].tolist()))
+        # what the measuring path would call this launch (same helper functions), so that a dry run of e.g.
+        # `--workload scheme --gpus 8 --batch 32` shows the record naming BASELINE.json configs[2] before any hardware run does
+        stands_for = (scheme_names(args.workload, B, args.ddpm_steps) if args.workload in ('scheme', 'egobody') else
+                      (None, f'{args.workload} [see main()]'))
         print(json.dumps({'metric': 'bench launcher self-test (NOT a measurement: stub sampler on CPU/gloo)', 'value': 0.0,
                           'unit': 'none', 'n_gpus': world, 'world_size': world, 'backend': 'gloo', 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'data': 'selftest-stub',
                           'gathered_clips': int(out.shape[0]), 'ranks_seen': ranks_seen,
-                          'config': {'workload': 'selftest'}}), flush=True)
+                          'config': {'workload': 'selftest', 'stands_for_metric': stands_for[0], 'stands_for_workload': stands_for[1],
+                                     'clips_per_gpu': B, 'sharding': sharding_note(args, world, B, dist),
+                                     'cpu_binding': args.cpu_binding}}), flush=True)
     finish(world, dist)
 
 
@@ -678,11 +812,11 @@ def main(argv=None):
             _, x0 = diffusion.eval_losses(model=net, batch=batch, shape=[B, 294, 1, 143], progress=False,
                                           clip_denoised=False, timestep_respacing='', cond_fn_with_grad=False,
                                           compute_loss=False)
-        if dist is not None:
-            sharding.gather_clips(x0, world * B, force=True)      # the path's only exchange: finished clips, RCCL all-gather
+        gather.submit(x0)      # the path's only exchange: finished clips, one RCCL all-gather, overlapping the next pass
         return x0
 
-    elapsed, out, prof = timed_region(one_pass, args, world, dev, dist)
+    gather = ResultGather(world * B, dist)
+    elapsed, out, prof = timed_region(one_pass, args, world, dev, dist, drain=gather.drain)
     finite = bool(torch.isfinite(out).all())
     assert finite, 'non-finite samples'
 
@@ -717,8 +851,14 @@ def main(argv=None):
                                     f'[BASELINE.json configs[1]]'),
                        'guidance': 'prox [BASELINE.json configs[3]]: synthetic camera + OpenPose-style keypoints, weights as '
                                    f'the reference (3e5 / 1e5); finite_output={finite}' if prox else 'none',
-                       'clips_per_gpu': B, 'ddpm_steps': S, 'sharding': sharding_note(args, world, B, dist), 'weights': 'random (seed 0)'},
+                       'clips_per_gpu': B, 'ddpm_steps': S, 'sharding': sharding_note(args, world, B, dist), 'cpu_binding': args.cpu_binding,
+                       'weights': 'random (seed 0)', 'exchange_mode': exchange_note(net)},
             'model_tflops': clips * S * POSENET_GFLOP_PER_CLIP_STEP * 1e-3 / elapsed,
+            # end to end against the fp32-MFMA peak: on the reference's flops, and on the flops the device EXECUTES (the cond half of
+            # the input embedding is contracted once per sampling loop instead of once per step: 2 x 144 x 512 x 288 flop per clip-step less)
+            'e2e_frac': clips * S * POSENET_GFLOP_PER_CLIP_STEP * 1e-3 / elapsed / PEAK_F32_MFMA_TFLOPS if not _PRODUCTS else None,
+            'e2e_frac_executed': (clips * S * (POSENET_GFLOP_PER_CLIP_STEP - 2e-9 * 144 * 512 * 288) * 1e-3 / elapsed / PEAK_F32_MFMA_TFLOPS
+                                  if not _PRODUCTS else None),
             'roofline': {
                 'kernel': ('gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region, ' if not _PRODUCTS else
                            f'gemm_pp_stream_kernel / gemm_pp_kernel on {_PLANE_TYPE} planes + the fp32 embed / output-head GEMMs (all GEMM launches '

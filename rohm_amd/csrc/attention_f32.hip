@@ -153,8 +153,16 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
             at_dma16(vg + (size_t)(2 * piece + half_row) * ldq + (cphys << 2), Vs + piece * 256);
         }
     };
+    // Issue order behind Q and the first key group.  AT_KFIRST (default): K1, K2 | V0, V1 | V2 -- all of K ahead of all of V: the
+    // QK^T phase is gated by K's arrival (timeline at B = 32, profiles/r5_attn_split_*: the third key group landed at 11.8k cycles
+    // with V instalments queued in between, 9.2k without), while V is not needed before the softmax is done and still lands
+    // underneath QK^T.  AT_KFIRST=0: the round-2 order K1, V0 | K2, V1 | V2.
+#ifndef AT_KFIRST
+#define AT_KFIRST 1
+#endif
     issue_k(1);
-    issue_v(0);
+    if constexpr (AT_KFIRST != 0) issue_k(2);
+    else issue_v(0);
 
     // ---- QK^T of the owned block, one 48-key group at a time as K lands ----------------------------------------
     f32x4 sacc[AT_NB];
@@ -162,8 +170,19 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     for (int kb = 0; kb < AT_NB; ++kb) sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int G = 0; G < 3; ++G) {
-        // issue order: Q, K0 | K1, V0 | K2, V1 | V2  (vmcnt retires in issue order)
-        if (G == 0) {
+        // (vmcnt retires in issue order)
+        if constexpr (AT_KFIRST != 0) {              // issue order: Q, K0 | K1, K2 | V0, V1 | V2
+            if (G == 0) {
+                AT_WAIT_VM(2 * NKP);                 // K0 landed; K1, K2 may be in flight
+            } else if (G == 1) {
+                issue_v(0);
+                issue_v(1);
+                AT_WAIT_VM(NKP + 2 * NV3);           // K1 landed; K2, V0, V1 in flight
+            } else {
+                issue_v(2);
+                AT_WAIT_VM(3 * NV3);                 // K2 landed; V0, V1, V2 in flight
+            }
+        } else if (G == 0) {                         // issue order: Q, K0 | K1, V0 | K2, V1 | V2
             AT_WAIT_VM(NKP + NV3);                   // K0 landed; K1, V0 may be in flight
         } else if (G == 1) {
             issue_k(2);

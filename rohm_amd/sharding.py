@@ -43,20 +43,39 @@ def shard_batch(batch, world=None, rank=None, batch_dim_keys=None):
     return out
 
 
-def gather_clips(local, n_total, group=None, force=False):
+class PendingGather:
+    """An all-gather in flight (`gather_clips(..., async_op=True)`): the collective runs on the backend's own stream behind the work
+    already queued on the caller's stream; `result()` makes the caller's stream wait for it and assembles the global batch.  Between
+    the two the caller may queue the next sampling run -- the gather of run k overlaps the start of run k + 1 (or, at the end of a
+    job, the tail of the slowest rank)."""
+
+    def __init__(self, work, parts, counts, keep):
+        self._work, self._parts, self._counts, self._keep = work, parts, counts, keep
+
+    def result(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return torch.cat([p[:c] for p, c in zip(self._parts, self._counts)], dim=0)
+
+
+def gather_clips(local, n_total, group=None, force=False, async_op=False):
     """All-gather the per-rank results (possibly ragged along dim 0) back into the global batch order.  A single-rank group
     returns its input untouched unless `force` asks for the collective anyway (bench.py --force-dist: the RCCL path on a
-    one-GPU box)."""
+    one-GPU box).  `async_op=True` returns a `PendingGather` instead of the tensor."""
     world = dist.get_world_size(group)
     if world == 1 and not force:
-        return local
+        return PendingGather(None, [local], [local.shape[0]], None) if async_op else local
     counts = [slice_bounds(n_total, world, r)[1] - slice_bounds(n_total, world, r)[0] for r in range(world)]
     width = max(counts)
     pad = local
     if local.shape[0] < width:
         pad = torch.cat([local, local.new_zeros((width - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    pad = pad.contiguous()
     parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad.contiguous(), group=group)
+    work = dist.all_gather(parts, pad, group=group, async_op=async_op)
+    if async_op:
+        return PendingGather(work, parts, counts, pad)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 

@@ -48,6 +48,45 @@ def test_gpus_4_and_8_spawn_that_many_ranks(world):
     assert rec['ms_per_step'] >= 10.0 * world - 1.0          # MAX over ranks: the last rank sleeps 10 ms x world per pass
 
 
+@pytest.mark.parametrize('workload,world,cfg', [('scheme', 8, 'configs[2]'), ('egobody', 4, 'configs[4]')])
+def test_dry_run_of_the_sharded_baseline_configs(workload, world, cfg):
+    """`--workload scheme --gpus 8 --batch 32` (BASELINE.json configs[2]: batch = 256 sharded 8 x) and `--workload egobody --gpus 4
+    --batch 32` (configs[4]: 128 sharded 4 x) through the launcher over gloo: the record names the configuration the measuring path
+    would name (same helper), every rank contributed its slice, every rank bound itself to its own CPUs."""
+    r = _run(['--gpus', str(world), '--backend', 'gloo', '--workload', workload, '--batch', '32', '--steps', '1', '--warmup', '0',
+              '--guidance-semantics', 'global'], {'ROHM_BENCH_SELFTEST': '1', 'OMP_NUM_THREADS': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json_line(r.stdout)
+    assert rec['n_gpus'] == world and rec['ranks_seen'] == list(range(world)) and rec['gathered_clips'] == 32 * world
+    c = rec['config']
+    assert cfg in c['stands_for_workload'] and 'batch=32 clips per GPU' in c['stands_for_workload'] and c['clips_per_gpu'] == 32
+    assert f'{world} x 32 independent clips' in c['sharding'] and f'the reference at batch {32 * world}' in c['sharding']
+    assert c['cpu_binding'].startswith('rank bound to') or c['cpu_binding'].startswith('not bound')
+
+
+def test_rank_cpu_plan_splits_numa_nodes_between_the_ranks_that_share_them():
+    """per-rank CPU / NUMA placement.  An 8-GPU host with two NUMA nodes of 64 cores (GPUs 0-3 on node 0, 4-7 on
+    node 1): every rank gets 16 cores of ITS node; unknown topology: an even split of the mask; a cgroup that leaves fewer cores
+    than ranks: ranks share, nobody gets an empty mask; a node whose cores are all outside the mask falls back to the even split."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(128))
+    node_of = lambda r: 0 if r < 4 else 1
+    cpus_of = lambda n: list(range(64 * n, 64 * n + 64))
+    plans = [bench.plan_rank_cpus(r, 8, allowed, node_of, cpus_of)[0] for r in range(8)]
+    assert all(len(p) == 16 for p in plans) and sorted(sum(plans, [])) == allowed
+    assert all(set(plans[r]) <= set(cpus_of(node_of(r))) for r in range(8))
+    even = [bench.plan_rank_cpus(r, 8, allowed)[0] for r in range(8)]
+    assert all(len(p) == 16 for p in even) and sorted(sum(even, [])) == allowed
+    tight = [bench.plan_rank_cpus(r, 8, [3, 5, 9])[0] for r in range(8)]
+    assert all(len(p) == 1 and p[0] in (3, 5, 9) for p in tight)
+    outside, how = bench.plan_rank_cpus(5, 8, list(range(16)), node_of, cpus_of)      # node 1's cores are not in the mask
+    assert outside == [10, 11] and 'even split' in how
+    lone, how = bench.plan_rank_cpus(0, 1, allowed, lambda r: 1, cpus_of)
+    assert lone == cpus_of(1) and 'NUMA node 1' in how
+
+
 def test_single_rank_selftest_and_gloo_needs_the_switch():
     r = _run(['--gpus', '1', '--backend', 'gloo', '--steps', '1', '--warmup', '0', '--batch', '2'],
              {'ROHM_BENCH_SELFTEST': '1'})
