@@ -239,8 +239,10 @@ size_t rohm_posenet_status_offset(const rohm_posenet_t* h, int B, int T);
  * bit 0 LayerNorm inside the out-projection / FF2 GEMMs, bit 1 stream-K output head; bit 2: the environment asked for them but the
  * layout guard refused at create (rohm_posenet_exchange_guard says why: < 256 CUs = a partitioned device, HSA_CU_MASK /
  * ROC_GLOBAL_CU_MASK set, or the probe launch -- 256 one-per-CU workgroups that must be resident together, block b on XCD b % 8 --
- * failed); bit 3: switched off after a failed exchange (rohm_posenet_set_exchange(h, 0)).  ROHM_EXCHANGE_GUARD=off skips the guard,
- * =probe skips its environment shortcut. */
+ * failed); bit 3: switched off after a failed exchange (rohm_posenet_set_exchange(h, 0)); bit 4: where the shape allows it (whole
+ * 144-token clips, d_model 512, d_ff 1024) the four GEMMs between two attention launches -- out-projection + norm1, linear1 + GELU,
+ * linear2 + norm2, the next layer's in-projection -- run as ONE launch whose workgroups hand tiles to each other per clip
+ * (ROHM_POSENET_CHAIN=0: one launch per GEMM).  ROHM_EXCHANGE_GUARD=off skips the guard, =probe skips its environment shortcut. */
 int rohm_posenet_exchange_mode(const rohm_posenet_t* h);
 const char* rohm_posenet_exchange_guard(const rohm_posenet_t* h);
 /* on = 0: from now on this handle runs the exchange-free launches (GEMM + LayerNorm kernel pair, plain output-head tiles) -- what the

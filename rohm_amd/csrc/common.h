@@ -164,11 +164,12 @@ void gemm_ln_bind(GemmParams& p, void* scratch);  // fills xln_* from a scratch 
 // ---- in-kernel exchanges: header words, first-use arming, layout guard (exchange.hip) -------------------------------------------
 // An exchange scratch starts with a 64-byte header: [0] error word (0 fine, 1 a bounded wait expired, 2 partners on different XCDs),
 // [1] kExchangeMagic once armed, [2] pass counter (the device part of the launch tags).  exchange_arm: on a scratch it sees for the
-// first time (magic missing: torch.empty memory, a recycled block) it zeroes the header AND the slot regions `za` / `zb` -- a tag is
+// first time (magic missing: torch.empty memory, a recycled block) it zeroes the header AND the slot regions `za` / `zb` / `zc` -- a tag is
 // never 0 in its XCD field, so zeroed slots are stale by construction, whatever the block held before -- and, with `bump`, advances
 // the pass counter (callers whose own first kernel does that pass bump = false).  Two tiny launches, no host synchronisation.
 constexpr unsigned kExchangeMagic = 0x524f484du;
-int exchange_arm(unsigned* header, void* za, size_t za_bytes, void* zb, size_t zb_bytes, bool bump, hipStream_t s);
+int exchange_arm(unsigned* header, void* za, size_t za_bytes, void* zb, size_t zb_bytes, bool bump, hipStream_t s, void* zc = nullptr,
+                 size_t zc_bytes = 0);
 // Does this device look like what the exchanging launches assume -- 256 CUs all available to one launch, 8 XCDs, block b on XCD
 // b % 8 (a whole MI355X in SPX mode, no CU mask, nobody else's kernels resident)?  Queried once per device: properties, the CU-mask
 // environment variables and a probe launch (256 one-per-CU workgroups that must all be resident at once and report their XCD).
@@ -176,6 +177,25 @@ int exchange_arm(unsigned* header, void* za, size_t za_bytes, void* zb, size_t z
 bool exchange_layout_ok(int device, const char** why);
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
+
+// ---- the GEMM chain of one encoder layer as one launch (encoder_chain.hip) ---------------------------------------------------------
+// y = norm1(h + out_proj(ctx)); ff = gelu(linear1(y)); h = norm2(y + linear2(ff)); qkv = in_proj_next(h) (absent when qkv == null).
+// Token-major activations [M, ...], M = clips x 144; D = 512, F = 1024.  The workgroups of a clip exchange LayerNorm statistics and
+// "my tile is stored" flags through L2: same scratch, tags and error word as EPI_BIAS_RES_LN (gemm_ln_bind fills xln_*), plus
+// `flags` (encoder_chain_flag_bytes(M), zeroed at first use).  epoch: tags epoch, epoch + 1 (the two LayerNorm exchanges) and epoch
+// (the flags) must be distinct from every other exchanging launch of the pass.
+struct ChainParams {
+    const float* ctx; float* h; float* y; float* ff; float* qkv;
+    int M, D, F, tiles_m;
+    const float *out_w, *out_b, *n1_w, *n1_b, *l1_w, *l1_b, *l2_w, *l2_b, *n2_w, *n2_b, *in_w, *in_b;
+    float qscale, ln_eps;
+    float* xln_stats; unsigned* xln_err; const unsigned* xln_pass; unsigned* xln_xcc; unsigned epoch;
+    unsigned long long* flags;
+    int fault;      // test hook: bit 0 / 1 sabotage the first / second LayerNorm exchange of the launch
+};
+int encoder_chain_parts(int M, int D, int F);      // column tiles per clip (4 or 8), 0 = no chain form for this shape
+size_t encoder_chain_flag_bytes(int M);
+int launch_encoder_chain(const ChainParams& p, hipStream_t s);
 // Is `s` recording a hipGraph?
 bool stream_is_capturing(hipStream_t s);
 #ifdef __HIPCC__

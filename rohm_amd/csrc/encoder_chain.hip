@@ -1,0 +1,583 @@
+// The GEMM chain of one nn.TransformerEncoderLayer as ONE launch (model/posenet.py:63-69, post-norm):
+//
+//     y   = norm1(h + out_proj(ctx))                      phase A   tile 144 x 512/G   (+ residual + LayerNorm, EPI_BIAS_RES_LN's form)
+//     ff  = gelu(linear1(y))                              phase B   tile 144 x 1024/G
+//     h   = norm2(y + linear2(ff))                        phase C   tile 144 x 512/G   (K = 1024)
+//     qkv = in_proj(h)   of the NEXT layer (q pre-scaled) phase D   tile 144 x 1536/G  (absent behind the last layer)
+//
+// Why: with one launch per GEMM every launch pays ~2 us of prologue (first operands from L2 / HBM with idle matrix cores), its
+// epilogue's store burst with all 256 CUs idle on the matrix side, and the ramp-down until the slowest of 256 tiles is done --
+// 5-7 us of 36-115 us, four times per layer ("persistent per-layer kernel").  The dependency between these GEMMs is
+// all-to-all inside a CLIP (the next GEMM contracts over the full 512 / 1024 columns of the clip's 144 rows) and nil across clips,
+// and at B = 64 (32) every one of them is cut into exactly G = 4 (8) column tiles per clip.  So a workgroup is (clip g, part tn) for
+// the whole chain: it computes its column tile of every phase, and between phases only the G workgroups of a clip meet -- a flag
+// exchange through the L2 of the XCD they share (the block -> tile map of EPI_BIAS_RES_LN: partners dispatched back to back onto one
+// XCD), while the next phase's WEIGHT chunks, which depend on nobody, are already on their way into LDS underneath the epilogue.
+//
+// Arithmetic: every tile is computed exactly as gemm_f32_kernel<BN, EPI, 0, true> computes it (same fragments, same k order, same
+// LayerNorm statistics tree) -- the chain and the launch-per-GEMM path agree bit for bit (tests/test_gpu_chain.py).
+// Exchange discipline: gemm_f32.hip's -- tags from (salt + index) + 64 x the workspace's pass counter, bounded waits that report
+// into the error word, layout guard at create, fallback + re-run by the host (exchange.hip).
+#include <type_traits>
+#include "common.h"
+#include "gemm_sched.h"
+
+namespace rohm {
+
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+
+namespace chain {
+
+constexpr int BM = 144, BK = kGemmBK, NRB = BM / 16;
+constexpr int A_UNITS = BM * 8, A_ITERS = (A_UNITS + 255) / 256;      // 16-byte units per A chunk; the fifth pass is half populated
+constexpr int kMaxBN = 384;
+// LDS: [A: 2 x 144 x 32] [W: 2 x BN x 32, BN <= 384] and, at a FIXED place behind the widest W buffers, the DMA landing zone and
+// the statistics / bias-row zone -- so that the next phase's weight chunks can land while this phase's epilogue still uses its zone
+constexpr int kZone = 2 * (BM + kMaxBN) * BK;                          // float offset
+constexpr int kLdsFloats = kZone + 512 + 4 * BM * 2;
+constexpr int kSc1 = 16;                                               // cache policy of a load that must come from L2 (device scope)
+
+struct PhaseArgs {
+    const float* A; int lda;
+    const float* W; int ldw;
+    float* C; int ldc;
+    int K;
+    const float* bias;
+    const float* R; int ldr;                       // RES_LN
+    const float* gamma; const float* beta; float eps; int ln_dim;
+    int qcols; float qscale;                       // QKV
+    int m0, n0;
+    float* row_stats; unsigned tag28; int tn, tiles_n;      // RES_LN: this row tile's slots, tag of this exchange
+    unsigned* err; unsigned xcc1; int fault;
+};
+
+// Issue the first two K chunks of a phase's weight tile (rows n0 .. n0 + BN of W) into the two W buffers: 2 x BN * 8 / 256 LDS-DMA
+// instructions per wave, no register staging.  Called while the PREVIOUS phase's epilogue is still to run.
+template <int BN>
+__device__ __forceinline__ void prefetch_w(const float* W, int ldw, int n0, float* smem, int tid, int wave_u) {
+    constexpr int B_ITERS = BN * 8 / 256;
+    float* Bs = smem + 2 * BM * BK;
+#pragma unroll
+    for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int u = tid + i * 256;
+            const int row = u >> 3;
+            const int slot = (u & 7) ^ ((row >> 1) & 7);
+            const float* src = W + (size_t)(n0 + row) * ldw + slot * 4 + buf * BK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * (BN * BK) + (i * 256 + wave_u) * 4), 16, 0, 0);
+        }
+}
+
+// The G workgroups of a clip meet: everybody's stores of the phase are in L2 before anybody reads them.  flags[k] = (XCD id + 1) << 32
+// | tag of workgroup k.  One lane per partner polls; bounded like every wait of this library, reported, never silently survived.
+__device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, int G, unsigned tag, unsigned xcc1, unsigned* err, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are acknowledged by L2
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(flags + tn, ((unsigned long long)xcc1 << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < G && tid != tn) {
+        for (int it = 0;; ++it) {
+            const unsigned long long f = __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)f == tag && (f >> 32) != 0ull) {
+                if ((unsigned)(f >> 32) != xcc1) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if ((it & 127) == 127 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (it > (1 << 19)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// One tile of one phase: C[m0.., n0..n0+BN) = epi(A[m0.., :K] . W[n0.., :K]^T).  PREF: the first two W chunks are in LDS (or on
+// their way) already; SC1: A was written by partner workgroups of this launch -- fetch it from L2, never from this CU's L1.
+// `after_loop()` runs once all waves are done with the staging buffers (the place to start the next phase's weights).
+template <int BN, int EPI, bool PREF, bool SC1, typename AfterLoop>
+__device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, AfterLoop&& after_loop) {
+    static_assert(EPI == EPI_BIAS_RES_LN || EPI == EPI_BIAS_GELU || EPI == EPI_QKV, "chain phases: LN tail, GELU, QKV");
+    constexpr int WN = BN / 4;
+    constexpr bool M32 = WN >= 64;
+    constexpr int NCB = WN / 16, NCB32 = WN / 32;
+    constexpr int B_ITERS = BN * 8 / 256;
+    constexpr int PIECES = A_ITERS + B_ITERS;
+    constexpr int AUX = SC1 ? kSc1 : 0;
+    static_assert(!(EPI == EPI_BIAS_RES_LN && M32), "the LayerNorm tail exists for the 16x16 layouts (BN <= 128)");
+
+    float* As = smem;
+    float* Bs = smem + 2 * BM * BK;
+    float* lds_dummy = smem + kZone;
+    float* const zone = lds_dummy + 512;          // statistics of the LayerNorm tail / bias row of the 384-wide tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int li32 = lane & 31, lg32 = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave) * 64;
+    const int m0 = p.m0, n0 = p.n0;
+
+    // ---- staging -----------------------------------------------------------------------------------------------------------
+    const float* a_src[A_ITERS];
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int u = tid + i * 256;
+        const int row = (u < A_UNITS) ? (u >> 3) : 0;
+        const int slot = (u & 7) ^ ((row >> 1) & 7);
+        a_src[i] = p.A + (size_t)(m0 + row) * p.lda + slot * 4;
+    }
+    const float* b_src[B_ITERS];
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+        const int u = tid + i * 256;
+        const int row = u >> 3;
+        const int slot = (u & 7) ^ ((row >> 1) & 7);
+        b_src[i] = p.W + (size_t)(n0 + row) * p.ldw + slot * 4;
+    }
+    auto dma_a = [&](int buf, int k0) {
+#pragma unroll
+        for (int piece = 0; piece < A_ITERS; ++piece) {
+            float* dst = As + buf * (BM * BK) + (piece * 256 + wave_u) * 4;
+            if (piece == A_ITERS - 1 && A_UNITS % 256 != 0)
+                dst = (wave_u < A_UNITS - (A_ITERS - 1) * 256) ? dst : lds_dummy + (wave_u & 64) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[piece] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, AUX);
+        }
+    };
+    auto dma_b = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * (BN * BK) + (i * 256 + wave_u) * 4), 16, 0, 0);
+    };
+
+    // ---- accumulators and fragments (gemm_f32.hip's layouts) ---------------------------------------------------------------------
+    constexpr int N32 = M32 ? 4 * NCB32 : 1;
+    constexpr int N16 = M32 ? NCB : NRB * NCB;
+    f32x16c acc32[N32];
+    f32x4 acc16[N16];
+#pragma unroll
+    for (int i = 0; i < N32; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc32[i][q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < N16; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int FA = M32 ? 9 : NRB;
+    constexpr int FB = M32 ? 2 * NCB32 + NCB : NCB;
+    constexpr int READS = FA + FB;
+    constexpr int MFMAS = M32 ? 32 * NCB32 + 4 * NCB : 4 * NRB * NCB;
+    struct Frag { f32x4 a[FA]; f32x4 b[FB]; };
+    Frag f0, f1;
+    auto read_frags = [&](Frag& f, int buf, int ks) {
+        const float* as = As + buf * (BM * BK);
+        const float* bs = Bs + buf * (BN * BK) + wave * WN * BK;
+        if constexpr (M32) {
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8) {
+                const int slot = ks * 4 + s8 * 2 + lg32;
+#pragma unroll
+                for (int cb = 0; cb < NCB32; ++cb)
+                    f.b[s8 * NCB32 + cb] = *reinterpret_cast<const f32x4*>(bs + lds_off(cb * 32 + li32, slot));
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+                    f.a[s8 * 4 + rb] = *reinterpret_cast<const f32x4*>(as + lds_off(rb * 32 + li32, slot));
+            }
+            const int slot16 = ks * 4 + lg;
+            f.a[8] = *reinterpret_cast<const f32x4*>(as + lds_off(128 + li, slot16));
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+                f.b[2 * NCB32 + c] = *reinterpret_cast<const f32x4*>(bs + lds_off(c * 16 + li, slot16));
+        } else {
+            const int slot = ks * 4 + lg;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) f.b[c] = *reinterpret_cast<const f32x4*>(bs + lds_off(c * 16 + li, slot));
+#pragma unroll
+            for (int r = 0; r < NRB; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(as + lds_off(r * 16 + li, slot));
+        }
+    };
+    auto mma_half = [&](const Frag& f) {      // weights on the MFMA "A" side: a lane ends with 4 consecutive output columns
+        if constexpr (M32) {
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < NCB32; ++cb)
+                            acc32[rb * NCB32 + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[s8 * NCB32 + cb][j], f.a[s8 * 4 + rb][j],
+                                                                                          acc32[rb * NCB32 + cb], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+                    acc16[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[2 * NCB32 + c][j], f.a[8][j], acc16[c], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NRB; ++r)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc16[r * NCB + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[c][j], f.a[r][j], acc16[r * NCB + c], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue -----------------------------------------------------------------------------------------------------------
+    const int nk = p.K / BK;                       // >= 16 here
+    constexpr bool COL_LDS = BN >= 384;            // no registers for 18 column groups of bias during the loop: the row goes through LDS
+    if constexpr (!PREF) { dma_b(0, 0); dma_b(1, BK); }
+    if constexpr (COL_LDS) {
+        if (wave == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int unit = h * 64 + lane;
+                const float* src = p.bias + n0 + (unit < BN / 4 ? unit : BN / 4 - 1) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(zone + h * 256), 16, 0, 0);
+            }
+        }
+    }
+    dma_a(0, 0);
+    dma_a(1, BK);
+
+    // ---- epilogue operands (requested at the top of the peeled last chunk: they land under its MFMAs) --------------------------
+    const int nw = n0 + wave * WN;
+    struct ColOps { f32x4 bias, g4, b4; };
+    constexpr bool RES = (EPI == EPI_BIAS_RES_LN);
+    constexpr bool PEEL = BN <= 256;
+    constexpr bool EARLY = PEEL;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_col = [&](int nb) __attribute__((always_inline)) {
+        ColOps o{zero4, zero4, zero4};
+        if constexpr (COL_LDS) o.bias = *reinterpret_cast<const f32x4*>(zone + (nb - n0));
+        else o.bias = *reinterpret_cast<const f32x4*>(p.bias + nb);
+        if constexpr (RES) {
+            o.g4 = *reinterpret_cast<const f32x4*>(p.gamma + nb);
+            o.b4 = *reinterpret_cast<const f32x4*>(p.beta + nb);
+        }
+        return o;
+    };
+    constexpr int NUNIT = M32 ? 16 * NCB32 + NCB : NCB * NRB;
+    constexpr int NCG = M32 ? 4 * NCB32 + NCB : NCB;
+    auto for_units = [&](auto&& fn) __attribute__((always_inline)) {
+        if constexpr (M32) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB32; ++cb)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x16c& a = acc32[rb * NCB32 + cb];
+                        fn((rb * NCB32 + cb) * 4 + qq, cb * 4 + qq, m0 + rb * 32 + li32, nw + cb * 32 + 8 * qq + 4 * lg32,
+                           f32x4{a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]});
+                    }
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) fn(16 * NCB32 + c, 4 * NCB32 + c, m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int r = 0; r < NRB; ++r) fn(c * NRB + r, c, m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c]);
+        }
+    };
+    ColOps col[NCG];
+    f32x4 res[RES ? NUNIT : 1];
+    auto request_ops = [&]() __attribute__((always_inline)) {
+        if constexpr (M32) {
+#pragma unroll
+            for (int cb = 0; cb < NCB32; ++cb)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) col[cb * 4 + qq] = load_col(nw + cb * 32 + 8 * qq + 4 * lg32);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) col[4 * NCB32 + c] = load_col(nw + c * 16 + lg * 4);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) col[c] = load_col(nw + c * 16 + lg * 4);
+        }
+        if constexpr (RES)
+            for_units([&](int i, int, int m, int nb, f32x4) __attribute__((always_inline)) {
+                res[i] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nb);
+            });
+    };
+
+    // chunk 0 has landed when at most the A pieces of chunk 1 are outstanding (everything older -- the prefetched or just issued W
+    // chunks, the bias row, A chunk 0 -- retires first: loads return in order, and no store of this wave is in flight here)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");
+    __syncthreads();
+    read_frags(f0, 0, 0);
+    constexpr int NG = READS;
+    constexpr int MF = (MFMAS + NG - 1) / NG;
+    auto chunk = [&](int kc, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int buf = kc & 1;
+        if constexpr (LAST && EARLY) request_ops();
+        read_frags(f1, buf, 1);
+        mma_half(f0);
+        SchedGroups<0, NG, MF, READS, 0, 0>::run();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAST) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = ((kc + 2 < nk) ? (kc + 2) : (nk - 1)) * BK;      // the last iterations re-fetch the last chunk: one basic block
+            dma_a(buf, kn);
+            dma_b(buf, kn);
+            read_frags(f0, buf ^ 1, 0);
+            mma_half(f1);
+            SchedGroups<0, NG, MF, READS, PIECES, 1>::run();
+        } else {
+            mma_half(f1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (PEEL) {
+        for (int kc = 0; kc + 1 < nk; ++kc) chunk(kc, std::false_type{});
+        chunk(nk - 1, std::true_type{});
+    } else {
+        for (int kc = 0; kc < nk; ++kc) chunk(kc, std::false_type{});
+    }
+    // every DMA of this phase has landed (the re-fetched last chunk included) and every wave is done reading the staging buffers:
+    // they belong to the next phase from here on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    after_loop();
+    if constexpr (!EARLY) request_ops();
+
+    // ---- epilogue -----------------------------------------------------------------------------------------------------------
+    if constexpr (EPI == EPI_BIAS_RES_LN) {
+        // gemm_f32.hip EPI_BIAS_RES_LN, statement for statement (same statistics, same merge tree: bit-identical results)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int r = 0; r < NRB; ++r) {
+                f32x4& a = acc16[r * NCB + c];
+                const f32x4 rr = res[c * NRB + r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = (a[q] + col[c].bias[q]) + rr[q];
+            }
+        typedef unsigned rohm_u2 __attribute__((ext_vector_type(2)));
+        auto merge_swap = [](float& m, float& q2, float n, bool far) __attribute__((always_inline)) {
+            rohm_u2 tm, tq;
+            if (far) { tm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                       tq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q2), __float_as_uint(q2), false, false); }
+            else     { tm = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                       tq = __builtin_amdgcn_permlane16_swap(__float_as_uint(q2), __float_as_uint(q2), false, false); }
+            const float ma = __uint_as_float(tm[0]), mb = __uint_as_float(tm[1]);
+            const float d = mb - ma;
+            m = 0.5f * (ma + mb);
+            q2 = (__uint_as_float(tq[0]) + __uint_as_float(tq[1])) + 0.5f * n * d * d;
+        };
+        float* const part = zone;                       // [4 waves][BM][2]
+        constexpr float kLane = (float)(4 * NCB);
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            float sm = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sm += acc16[r * NCB + c][k];
+            float m = sm * (1.0f / kLane), q2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float d = acc16[r * NCB + c][k] - m; q2 += d * d; }
+            merge_swap(m, q2, kLane, true);
+            merge_swap(m, q2, 2.0f * kLane, false);
+            if (lg == 0) *reinterpret_cast<f32x2*>(part + (wave * BM + r * 16 + li) * 2) = f32x2{m, q2};
+        }
+        __syncthreads();
+        const int tn = p.tn, tiles_n = p.tiles_n;
+        const unsigned xcc1 = p.xcc1, ep28 = p.tag28;
+        const unsigned tag = (ep28 << 4) | xcc1;
+        float* const row_stats = p.row_stats;
+        if (tid < BM) {
+            auto merge = [](float ma, float qa, float mb, float qb, float n, float& m, float& q2) __attribute__((always_inline)) {
+                const float d = mb - ma;
+                m = 0.5f * (ma + mb);
+                q2 = (qa + qb) + 0.5f * n * d * d;
+            };
+            f32x2 w4[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) w4[w] = *reinterpret_cast<const f32x2*>(part + (w * BM + tid) * 2);
+            float m01, q01, m23, q23, a, b;
+            merge(w4[0][0], w4[0][1], w4[1][0], w4[1][1], (float)WN, m01, q01);
+            merge(w4[2][0], w4[2][1], w4[3][0], w4[3][1], (float)WN, m23, q23);
+            merge(m01, q01, m23, q23, 2.0f * (float)WN, a, b);
+            const unsigned pub = (p.fault && tn == 0) ? (tag ^ 0x80000000u) : tag;
+            *reinterpret_cast<f32x4*>(row_stats + ((size_t)tn * BM + tid) * 4) = f32x4{a, __uint_as_float(pub), b, __uint_as_float(pub)};
+            float mk[8], qk[8];
+            for (int it = 0;; ++it) {
+                unsigned long long lo[8], hi[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    lo[k] = hi[k] = 0ull;
+                    if (k < tiles_n && k != tn) {
+                        const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(row_stats + ((size_t)k * BM + tid) * 4);
+                        lo[k] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[k] = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                bool ok = true, same_xcd = true;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    mk[k] = 0.f; qk[k] = 0.f;
+                    if (k >= tiles_n) continue;
+                    if (k == tn) { mk[k] = a; qk[k] = b; continue; }
+                    const unsigned tl = (unsigned)(lo[k] >> 32), th = (unsigned)(hi[k] >> 32);
+                    ok = ok && (tl >> 4) == ep28 && (th >> 4) == ep28 && (tl & 15u) != 0u && (th & 15u) != 0u;
+                    same_xcd = same_xcd && (tl & 15u) == xcc1 && (th & 15u) == xcc1;
+                    mk[k] = __uint_as_float((unsigned)lo[k]);
+                    qk[k] = __uint_as_float((unsigned)hi[k]);
+                }
+                if (ok) {
+                    if (!same_xcd) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if ((it & 127) == 127 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (it > (1 << 19)) {
+                    __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            constexpr float kT = (float)BN;
+            if (tiles_n > 1) {
+                merge(mk[0], qk[0], mk[1], qk[1], kT, mk[0], qk[0]);
+                if (tiles_n > 2) merge(mk[2], qk[2], mk[3], qk[3], kT, mk[2], qk[2]);
+                if (tiles_n > 4) { merge(mk[4], qk[4], mk[5], qk[5], kT, mk[4], qk[4]); merge(mk[6], qk[6], mk[7], qk[7], kT, mk[6], qk[6]); }
+            }
+            if (tiles_n > 2) {
+                merge(mk[0], qk[0], mk[2], qk[2], 2.0f * kT, mk[0], qk[0]);
+                if (tiles_n > 4) merge(mk[4], qk[4], mk[6], qk[6], 2.0f * kT, mk[4], qk[4]);
+            }
+            if (tiles_n > 4) merge(mk[0], qk[0], mk[4], qk[4], 4.0f * kT, mk[0], qk[0]);
+            const float mu = mk[0];
+            const float var = qk[0] / (float)p.ln_dim;
+            *reinterpret_cast<f32x2*>(part + tid * 2) = f32x2{mu, 1.0f / sqrtf(var + p.eps)};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const f32x2 mrv = *reinterpret_cast<const f32x2*>(part + (r * 16 + li) * 2);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const f32x4 a = acc16[r * NCB + c];
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (a[q] - mrv[0]) * mrv[1] * col[c].g4[q] + col[c].b4[q];
+                *reinterpret_cast<f32x4*>(p.C + (size_t)(m0 + r * 16 + li) * p.ldc + nw + c * 16 + lg * 4) = v;
+            }
+        }
+    } else {
+        for_units([&](int, int cg, int m, int nb, f32x4 a) __attribute__((always_inline)) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = a[q] + col[cg].bias[q];
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+            }
+            if constexpr (EPI == EPI_QKV) {
+                if (nb < p.qcols) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= p.qscale;
+                }
+            }
+            *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + nb) = v;
+        });
+    }
+}
+
+}  // namespace chain
+
+// G = column tiles per clip of every phase = partner workgroups of a clip: 4 (B = 64: tiles 144 x 128 / 256 / 128 / 384) or 8 (B = 32:
+// 144 x 64 / 128 / 64 / 192)
+template <int G>
+__global__ __launch_bounds__(256) void encoder_chain_kernel(ChainParams p) {
+    using namespace chain;
+    constexpr int BNL = 512 / G, BNF = 1024 / G, BNQ = 1536 / G;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+    // block -> (clip, part): the G parts of a clip are consecutive workgroups of ONE XCD (hardware deals block b to XCD b % 8 in
+    // block order) -- co-resident, one L2 (gemm_f32.hip EPI_BIAS_RES_LN's map)
+    const int x = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+    const int g = (j / G) * kNumXCD + x, tn = j % G;
+    if (g >= p.tiles_m) return;
+    const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+    const unsigned ep = p.epoch + 64u * *p.xln_pass;      // the pass counter was advanced by an EARLIER kernel of the stream
+    if (tid == 0) p.xln_xcc[g * 8 + tn] = xcc1;
+    unsigned long long* const flags = p.flags + (size_t)g * 3 * 8;
+
+    PhaseArgs a{};
+    a.m0 = g * BM; a.err = p.xln_err; a.xcc1 = xcc1; a.tn = tn; a.tiles_n = G;
+    a.row_stats = p.xln_stats + ((size_t)g * G * BM) * 4;
+    a.eps = p.ln_eps; a.ln_dim = p.D;
+
+    // ---- A: y = norm1(h + ctx . Wo^T + bo) ---------------------------------------------------------------------------------------
+    a.A = p.ctx; a.lda = p.D; a.W = p.out_w; a.ldw = p.D; a.C = p.y; a.ldc = p.D; a.K = p.D; a.bias = p.out_b;
+    a.R = p.h; a.ldr = p.D; a.gamma = p.n1_w; a.beta = p.n1_b; a.n0 = tn * BNL; a.tag28 = ep & 0x0fffffffu; a.fault = p.fault & 1;
+    gemm_phase<BNL, EPI_BIAS_RES_LN, false, false>(a, smem, [&]() { prefetch_w<BNF>(p.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
+    group_sync(flags, tn, G, ep, xcc1, p.xln_err, tid);
+
+    // ---- B: ff = gelu(y . W1^T + b1) ---------------------------------------------------------------------------------------------
+    a.A = p.y; a.lda = p.D; a.W = p.l1_w; a.ldw = p.D; a.C = p.ff; a.ldc = p.F; a.K = p.D; a.bias = p.l1_b; a.n0 = tn * BNF;
+    gemm_phase<BNF, EPI_BIAS_GELU, true, true>(a, smem, [&]() { prefetch_w<BNL>(p.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
+    group_sync(flags + 8, tn, G, ep, xcc1, p.xln_err, tid);
+
+    // ---- C: h = norm2(y + ff . W2^T + b2) ----------------------------------------------------------------------------------------
+    a.A = p.ff; a.lda = p.F; a.W = p.l2_w; a.ldw = p.F; a.C = p.h; a.ldc = p.D; a.K = p.F; a.bias = p.l2_b;
+    a.R = p.y; a.ldr = p.D; a.gamma = p.n2_w; a.beta = p.n2_b; a.n0 = tn * BNL; a.tag28 = (ep + 1u) & 0x0fffffffu; a.fault = (p.fault >> 1) & 1;
+    gemm_phase<BNL, EPI_BIAS_RES_LN, true, true>(a, smem, [&]() { if (p.qkv) prefetch_w<BNQ>(p.in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+    if (p.qkv == nullptr) return;      // last layer: the output head follows as its own launch (uniform over the launch)
+    group_sync(flags + 16, tn, G, ep, xcc1, p.xln_err, tid);
+
+    // ---- D: qkv = h . Win^T + bin of the next layer, q pre-scaled ------------------------------------------------------------------
+    a.A = p.h; a.lda = p.D; a.W = p.in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.in_b; a.n0 = tn * BNQ;
+    a.qcols = p.D; a.qscale = p.qscale;
+    gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, []() {});
+}
+
+int encoder_chain_parts(int M, int D, int F) {      // 0: this shape has no chain form
+    if (D != 512 || F != 1024 || M <= 0 || M % chain::BM != 0) return 0;
+    const int tm = M / chain::BM;
+    return tm * 4 >= 256 ? 4 : 8;      // the tile widths launch_gemm picks for these GEMMs (ln_tile_width: 144 x 128 while every CU gets a tile)
+}
+
+size_t encoder_chain_flag_bytes(int M) { return (size_t)((M + chain::BM - 1) / chain::BM) * 3 * 8 * sizeof(unsigned long long); }
+
+int launch_encoder_chain(const ChainParams& p, hipStream_t s) {
+    const int G = encoder_chain_parts(p.M, p.D, p.F);
+    ROHM_ARG_CHECK(G != 0, "encoder_chain: shape (M %d, D %d, F %d) has no chain form", p.M, p.D, p.F);
+    ROHM_ARG_CHECK(p.ctx && p.h && p.y && p.ff && p.out_w && p.out_b && p.n1_w && p.n1_b && p.l1_w && p.l1_b && p.l2_w && p.l2_b &&
+                       p.n2_w && p.n2_b && p.xln_stats && p.xln_err && p.xln_pass && p.xln_xcc && p.flags && (!p.qkv || (p.in_w && p.in_b)),
+                   "encoder_chain: null operand");
+    ChainParams q = p;
+    q.tiles_m = p.M / chain::BM;
+    const int groups8 = (q.tiles_m + kNumXCD - 1) / kNumXCD * kNumXCD;
+    const size_t lds = (size_t)chain::kLdsFloats * sizeof(float);
+    static bool attr_set[64][2] = {};
+    int dev = 0;
+    ROHM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev][G == 8]) {
+        if (G == 4) ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_chain_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_chain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev][G == 8] = true;
+    }
+    const double MM = (double)p.M, D = p.D, F = p.F;
+    const double flops = 2.0 * MM * (D * D + 2.0 * D * F + (p.qkv ? 3.0 * D * D : 0.0));
+    const double bytes = 4.0 * (MM * (4.0 * D + 2.0 * F + D + (p.qkv ? 3.0 * D : 0.0)) + D * D + 2.0 * D * F + (p.qkv ? 3.0 * D * D : 0.0));
+    prof::Scope ps(p.qkv ? "gemm_chain" : "gemm_chain_last", flops, bytes, s);
+    if (G == 4) hipLaunchKernelGGL(encoder_chain_kernel<4>, dim3(groups8 * 4), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL(encoder_chain_kernel<8>, dim3(groups8 * 8), dim3(256), lds, s, q);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+}  // namespace rohm

@@ -15,12 +15,13 @@ namespace rohm {
 
 // zero the slot regions of a scratch whose header does not carry the magic yet (16-byte units; grid-stride)
 __global__ __launch_bounds__(256) void exchange_zero_kernel(const unsigned* __restrict__ header, f32x4* __restrict__ za, size_t na,
-                                                            f32x4* __restrict__ zb, size_t nb) {
+                                                            f32x4* __restrict__ zb, size_t nb, f32x4* __restrict__ zc, size_t nc) {
     if (header[1] == kExchangeMagic) return;
     const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
     for (size_t i = i0; i < na; i += stride) za[i] = z;
     for (size_t i = i0; i < nb; i += stride) zb[i] = z;
+    for (size_t i = i0; i < nc; i += stride) zc[i] = z;
 }
 
 __global__ void exchange_arm_kernel(unsigned* header, int bump) {
@@ -28,14 +29,15 @@ __global__ void exchange_arm_kernel(unsigned* header, int bump) {
     if (bump) header[2] += 1u;
 }
 
-int exchange_arm(unsigned* header, void* za, size_t za_bytes, void* zb, size_t zb_bytes, bool bump, hipStream_t s) {
-    ROHM_ARG_CHECK(header && (((uintptr_t)za | (uintptr_t)zb | za_bytes | zb_bytes) & 15) == 0, "exchange_arm: misaligned scratch");
-    const size_t units = (za_bytes + zb_bytes) / 16;
+int exchange_arm(unsigned* header, void* za, size_t za_bytes, void* zb, size_t zb_bytes, bool bump, hipStream_t s, void* zc, size_t zc_bytes) {
+    ROHM_ARG_CHECK(header && (((uintptr_t)za | (uintptr_t)zb | (uintptr_t)zc | za_bytes | zb_bytes | zc_bytes) & 15) == 0,
+                   "exchange_arm: misaligned scratch");
+    const size_t units = (za_bytes + zb_bytes + zc_bytes) / 16;
     unsigned blocks = (unsigned)((units + 255) / 256);
     if (blocks > 256) blocks = 256;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(exchange_zero_kernel, dim3(blocks), dim3(256), 0, s, header, static_cast<f32x4*>(za), za_bytes / 16,
-                       static_cast<f32x4*>(zb), zb_bytes / 16);
+                       static_cast<f32x4*>(zb), zb_bytes / 16, static_cast<f32x4*>(zc), zc_bytes / 16);
     ROHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(exchange_arm_kernel, dim3(1), dim3(1), 0, s, header, bump ? 1 : 0);
     ROHM_LAUNCH_CHECK();

@@ -39,6 +39,7 @@
 #include <type_traits>
 #include <string.h>
 #include "common.h"
+#include "gemm_sched.h"
 
 namespace rohm {
 
@@ -50,29 +51,6 @@ constexpr int NRB = BM / 16;        // 9 row blocks of 16 (BN = 64 path)
 constexpr int kSkWorkgroups = 256;  // stream-K launches: one workgroup per CU (32 per XCD)
 constexpr int A_UNITS = BM * 8;     // 16-byte units per A chunk (1152)
 constexpr int A_ITERS = (A_UNITS + 255) / 256;  // 5 (the last pass is half populated)
-
-__device__ __forceinline__ int lds_off(int row, int slot) {   // float index inside a [rows][32] tile
-    return row * BK + ((slot ^ ((row >> 1) & 7)) << 2);
-}
-
-// compile-time repetition of sched_group_barrier triples (the builtin needs literal arguments)
-// VAL > 0 (conv gather): the per-chunk address arithmetic of the gathered operand (VALU) is dealt out between the MFMA
-// groups as well -- left alone the scheduler hoists all of it in front of the half's first MFMA.
-template <int I, int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID, int VAL = 0>
-struct SchedGroups {
-    static __device__ __forceinline__ void run() {
-        constexpr int kValu = 0x002, kMfma = 0x008, kVmem = 0x010, kDsRead = 0x100;
-        __builtin_amdgcn_sched_group_barrier(kMfma, MF, ID);
-        __builtin_amdgcn_sched_group_barrier(kDsRead, DS_TOTAL / N + (I < DS_TOTAL % N ? 1 : 0), ID);
-        if constexpr (VAL > 0) __builtin_amdgcn_sched_group_barrier(kValu, VAL, ID);
-        __builtin_amdgcn_sched_group_barrier(kVmem, VM_TOTAL / N + (I < VM_TOTAL % N ? 1 : 0), ID);
-        SchedGroups<I + 1, N, MF, DS_TOTAL, VM_TOTAL, ID, VAL>::run();
-    }
-};
-template <int N, int MF, int DS_TOTAL, int VM_TOTAL, int ID, int VAL>
-struct SchedGroups<N, N, MF, DS_TOTAL, VM_TOTAL, ID, VAL> {
-    static __device__ __forceinline__ void run() {}
-};
 
 // (mu, rstd) of one row from its partial (sum, sum of squares) pairs -- biased variance, eps inside the root, like
 // nn.LayerNorm.  The pairs of a row are contiguous (parts x 2 floats, parts a multiple of 2): independent 16-byte

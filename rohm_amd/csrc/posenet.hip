@@ -63,6 +63,9 @@ struct rohm_posenet {
     // The two launch forms above exchange data between workgroups of one launch (exchange.hip).  They are used only where the device
     // passed the layout guard at create (exch_allowed) and until an exchange failed on this handle (exch_fallback, set by
     // rohm_posenet_set_exchange: the Python loops then re-run the chunk on the exchange-free launches).
+    bool chain_any;                       // chain at every batch size (tests)
+    bool chain;                           // the four GEMMs between two attention launches as ONE launch (encoder_chain.hip; needs ln_fused;
+                                          // default on, ROHM_POSENET_CHAIN=0: one launch per GEMM)
     bool ln_fused_env, head_sk_env;       // what the environment asked for
     bool exch_allowed, exch_fallback;
     const char* exch_reason;              // why the guard refused (static string), or what it saw
@@ -234,6 +237,7 @@ struct Workspace {
     float* xln;                   // scratch of the LayerNorm-producing GEMMs (common.h gemm_ln_*): status words, statistics
     float* sk;                    // scratch of the stream-K output head (common.h gemm_sk_*): flags, partial tiles
     float* econd;                 // [M, D] cond half of the input embedding + positional table + biases (sampling loop)
+    float* chain_flags;           // "my tile is stored" flags of the encoder chain (common.h ChainParams::flags)
     int64_t* t_all;
     size_t floats;
 };
@@ -272,6 +276,7 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
     w.xln = take(gemm_ln_scratch_bytes((int)M, p->D) / sizeof(float));
     w.sk = take(gemm_sk_scratch_bytes() / sizeof(float));
     w.econd = take(M * p->D);
+    w.chain_flags = take(encoder_chain_flag_bytes((int)M) / sizeof(float));
     w.floats = off;
     return w;
 }
@@ -285,7 +290,7 @@ static Workspace carve(const rohm_posenet* p, int B, int T, float* base) {
 static int arm_status(const rohm_posenet* p, const Workspace& w, int B, int T, hipStream_t s) {
     const size_t M = (size_t)B * (T + 1);
     return exchange_arm(reinterpret_cast<unsigned*>(w.xln), reinterpret_cast<char*>(w.xln) + 64, gemm_ln_scratch_bytes((int)M, p->D) - 64,
-                        w.sk, 256 * sizeof(unsigned long long), false, s);
+                        w.sk, 256 * sizeof(unsigned long long), false, s, w.chain_flags, encoder_chain_flag_bytes((int)M));
 }
 static inline unsigned* pass_counter(const Workspace& w) { return reinterpret_cast<unsigned*>(w.xln) + 2; }
 
@@ -376,7 +381,7 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     // (not while the stream records a hipGraph: the exchange's per-launch tag would be replayed -- the GEMM + LayerNorm pair then)
     // (a stream that is recording a hipGraph keeps them: their tags come from the workspace's pass counter, a replay draws new ones)
     const bool lnf = p->ln_fused && !fold && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F);
-    // tag of exchanging launch number `idx` of this pass (2 l, 2 l + 1: the LayerNorm GEMMs of layer l; 2 L: the output head)
+    // tag of exchanging launch number `idx` of this pass (2 l, 2 l + 1: the LayerNorm GEMMs of layer l; 60: the output head)
     auto tag_launch = [&](GemmParams& g, int idx) { g.xln_epoch = p->salt + (unsigned)idx; };
     const int parts = D / 64;
     auto ln_operand = [&](GemmParams& g, const float* stats, const float* c) {
@@ -385,7 +390,41 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     auto ln_residual = [&](GemmParams& g, const float* stats, const float* gamma, const float* beta) {
         g.r_stats = stats; g.r_parts = parts; g.r_gamma = gamma; g.r_beta = beta; g.ln_dim = D; g.ln_eps = 1e-5f;
     };
-    for (int l = 0; l < (planes ? 0 : p->L); ++l) {
+    // The four GEMMs between two attention launches as ONE launch (encoder_chain.hip): needs the in-kernel LayerNorm exchange (lnf) and
+    // the released widths.  Layer l: [QKV of layer 0: its own launch] attention(l), chain(l) = out-proj + norm1, FF1, FF2 + norm2 and
+    // the QKV projection of layer l + 1.  Tags: 4 l, 4 l + 1 (the chain's two LayerNorm exchanges and its flags); the head: 60.
+    // From 32 clips on (every phase then has >= 256 tiles): below that the launch-per-GEMM path picks narrower tiles per GEMM and keeps
+    // more CUs busy (ROHM_POSENET_CHAIN=2 chains every shape that has the form: tests).
+    const bool chained = lnf && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && (B >= 32 || p->chain_any);
+    const float qscale = 1.0f / sqrtf((float)(D / p->H));
+    for (int l = 0; l < ((planes || !chained) ? 0 : p->L); ++l) {
+        const LayerW& lw = p->layers[l];
+        if (l == 0) {
+            GemmParams g{};
+            g.A = h; g.lda = D; g.W = lw.in_w; g.ldw = D; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+            g.bias = lw.in_b; g.qcols = D; g.qscale = qscale;
+            if ((rc = launch_gemm(g, EPI_QKV, s))) return rc;
+        }
+        if ((rc = launch_attention(w.qkv, w.ctx, B, p->H, S, D / p->H, s))) return rc;
+        ChainParams c{};
+        c.ctx = w.ctx; c.h = h; c.y = y; c.ff = w.ff; c.qkv = (l + 1 < p->L) ? w.qkv : nullptr;
+        c.M = M; c.D = D; c.F = p->F;
+        c.out_w = lw.out_w; c.out_b = lw.out_b; c.n1_w = lw.n1_w; c.n1_b = lw.n1_b; c.l1_w = lw.l1_w; c.l1_b = lw.l1_b;
+        c.l2_w = lw.l2_w; c.l2_b = lw.l2_b; c.n2_w = lw.n2_w; c.n2_b = lw.n2_b;
+        if (l + 1 < p->L) { c.in_w = p->layers[l + 1].in_w; c.in_b = p->layers[l + 1].in_b; }
+        c.qscale = qscale; c.ln_eps = 1e-5f;
+        {
+            GemmParams b{};
+            b.M = M;
+            gemm_ln_bind(b, w.xln);
+            c.xln_stats = b.xln_stats; c.xln_err = b.xln_err; c.xln_pass = b.xln_pass; c.xln_xcc = b.xln_xcc;
+        }
+        c.epoch = p->salt + (unsigned)(4 * l);
+        c.flags = reinterpret_cast<unsigned long long*>(w.chain_flags);
+        if (p->fault_left > 0) { --p->fault_left; c.fault = 1; }
+        if ((rc = launch_encoder_chain(c, s))) return rc;
+    }
+    for (int l = 0; l < ((planes || chained) ? 0 : p->L); ++l) {
         const LayerW& lw = p->layers[l];
         // With folding, h holds the RAW (pre-norm2) output of the previous layer for l >= 1 and stats_b its row sums.
         GemmParams g{};
@@ -440,7 +479,7 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         g.bias = p->out_b; g.S = S; g.ch_off = p->Cin - p->Cout; g.C_total = p->Cin; g.T = T;
         if (fold) ln_operand(g, w.stats_b, p->out_c);
         // B = 64: 2 x 144 tiles on 256 CUs -- dealt out as (tile, K chunk) units instead of a second, 1/8-full round (common.h sk_*)
-        if (p->head_sk) { gemm_sk_bind(g, w.sk, reinterpret_cast<unsigned*>(w.xln)); tag_launch(g, 2 * p->L); }
+        if (p->head_sk) { gemm_sk_bind(g, w.sk, reinterpret_cast<unsigned*>(w.xln)); tag_launch(g, 60); }
         if ((rc = launch_gemm(g, EPI_OUT_T, s))) return rc;
     }
     return ROHM_OK;
@@ -545,11 +584,14 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         // Both launch forms assume a whole MI355X (256 CUs free for one launch, block b on XCD b % 8); the tags leave 6 bits for the
         // launch index of a pass.  A device that does not look like that -- partitioned, CU-masked, shared -- gets the GEMM +
         // LayerNorm kernel pair and plain output-head tiles from the start (exchange.hip: properties + environment + a probe launch).
+        const char* e9 = getenv("ROHM_POSENET_CHAIN");
+        p->chain = !(e9 && e9[0] == '0');
+        p->chain_any = e9 && e9[0] == '2';
         p->ln_fused_env = p->ln_fused; p->head_sk_env = p->head_sk;
         p->exch_fallback = false;
         p->fault_left = 0;
         p->exch_reason = "not asked for";
-        p->exch_allowed = (p->ln_fused || p->head_sk) && 2 * n_layer + 1 <= 64 && exchange_layout_ok(device, &p->exch_reason);
+        p->exch_allowed = (p->ln_fused || p->head_sk) && 2 * n_layer + 1 <= 60 && exchange_layout_ok(device, &p->exch_reason);
         if (!p->exch_allowed) p->ln_fused = p->head_sk = false;
         {      // per-handle salt of the launch tags: a recycled workspace that holds another handle's (or anybody's) old words is stale
             static unsigned counter = 0;
@@ -739,7 +781,7 @@ int rohm_posenet_precision(const rohm_posenet_t* h) { return h ? h->nplane : 0; 
 int rohm_posenet_exchange_mode(const rohm_posenet_t* h) {
     if (!h) return 0;
     return (h->ln_fused ? 1 : 0) | (h->head_sk ? 2 : 0) | ((!h->exch_allowed && (h->ln_fused_env || h->head_sk_env)) ? 4 : 0) |
-           (h->exch_fallback ? 8 : 0);
+           (h->exch_fallback ? 8 : 0) | ((h->chain && h->ln_fused) ? 16 : 0);
 }
 
 const char* rohm_posenet_exchange_guard(const rohm_posenet_t* h) { return h ? h->exch_reason : ""; }

@@ -1,0 +1,138 @@
+"""The GEMM chain of an encoder layer as one launch (csrc/encoder_chain.hip: out-projection + norm1, linear1 + GELU, linear2 + norm2
+and the next layer's in-projection -- nn.TransformerEncoderLayer, model/posenet.py:63-69) against the launch-per-GEMM path it
+replaces, and against the reference's goldens.  At the batch sizes it is used by default (B >= 32: 4 or 8 column tiles per clip in
+every phase, the very tiles the launch-per-GEMM path picks) the two paths must agree BIT FOR BIT: same fragments, same k order, same
+LayerNorm statistics tree."""
+import pytest
+import torch
+
+from helpers import cpu_noise_sequence, golden, max_abs, seeded
+from test_gpu_posenet import DEV, make_diffusion, make_posenet
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(monkeypatch, seed=5, chain='1'):
+    with monkeypatch.context() as m:
+        m.setenv('ROHM_POSENET_CHAIN', '0')
+        plain, _ = make_posenet(seed)
+        plain.native(torch.device(DEV))
+    with monkeypatch.context() as m:
+        m.setenv('ROHM_POSENET_CHAIN', chain)
+        net, _ = make_posenet(seed)
+        nat = net.native(torch.device(DEV))
+    if nat.exchange_mode & 16 == 0:
+        pytest.skip(f'the layout guard refused the exchanging launches on this device: {nat.exchange_guard}')
+    assert plain.native(torch.device(DEV)).exchange_mode & 16 == 0
+    return plain, net
+
+
+def _inputs(B, T=143):
+    x, c = seeded(1, B, 294, 1, T).to(DEV), seeded(2, B, 294, 1, T).to(DEV)
+    t = torch.tensor([(37 * i + 1) % 1000 for i in range(B)], device=DEV)
+    return x, c, t
+
+
+@pytest.mark.parametrize('B', [64, 32, 128])
+def test_chain_forward_is_bit_identical_to_one_launch_per_gemm(B, monkeypatch):
+    plain, net = _pair(monkeypatch)
+    x, c, t = _inputs(B)
+    want = plain({'x_t': x, 'cond': c}, t)
+    got = net({'x_t': x, 'cond': c}, t)
+    net.check_exchange()
+    assert torch.equal(got, want)
+    for _ in range(20):      # race screen: the clip's workgroups meet five times per layer; every run the same bits
+        assert torch.equal(net({'x_t': x, 'cond': c}, t), want)
+    net.check_exchange()
+
+
+@pytest.mark.parametrize('B', [40, 33, 3, 1])
+def test_chain_at_other_batch_sizes(B, monkeypatch):
+    """Row tiles that are not a multiple of 8 (surplus workgroups leave), more than one round of workgroups (B = 40: 320), tiny
+    batches (forced: by default they keep the launch-per-GEMM path, whose narrower tiles fill more CUs).  The launch-per-GEMM path
+    picks other tile widths here, so agreement is to summation order."""
+    plain, net = _pair(monkeypatch, chain='2')
+    x, c, t = _inputs(B)
+    want = plain({'x_t': x, 'cond': c}, t)
+    got = net({'x_t': x, 'cond': c}, t)
+    net.check_exchange()
+    assert max_abs(got, want) < 2e-5
+    assert torch.equal(net({'x_t': x, 'cond': c}, t), got)
+
+
+def test_chain_vs_reference_goldens(monkeypatch):
+    """Forward < 1e-4 and the 8-step loop < 1e-4 against the reference's own outputs, with the chain forced at B = 2."""
+    monkeypatch.setenv('ROHM_POSENET_CHAIN', '2')
+    g = golden('posenet_forward.npz')
+    net, _ = make_posenet(int(g['weight_seed']))
+    x, c = seeded(int(g['x_seed']), 2, 294, 1, 143), seeded(int(g['cond_seed']), 2, 294, 1, 143)
+    y = net({'x_t': x.to(DEV), 'cond': c.to(DEV)}, torch.from_numpy(g['t']).to(DEV)).cpu()
+    if net.native(torch.device(DEV)).exchange_mode & 16 == 0:
+        pytest.skip('layout guard refused the exchanging launches')
+    assert max_abs(y, torch.from_numpy(g['y'])) < 1e-4
+    g = golden('posenet_loop8.npz')
+    net, _ = make_posenet(int(g['weight_seed']))
+    steps = int(g['steps'])
+    cond = seeded(int(g['cond_seed']), 2, 294, 1, 143)
+    x_T, noises = cpu_noise_sequence(int(g['torch_seed']), (2, 294, 1, 143), steps)
+    diff = make_diffusion(steps)
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    y = diff.p_sample_loop(net, {'cond': cond.to(DEV)}, [2, 294, 1, 143])
+    assert max_abs(y.cpu(), torch.from_numpy(g['y'])) < 1e-4
+
+
+def test_chain_loop_at_the_headline_batch_is_bit_identical(monkeypatch):
+    """8 denoising steps of 64 clips through the fused loop: chain vs launch-per-GEMM, bit for bit; recorded into a hipGraph the chain
+    replays correctly (its tags come from the workspace's pass counter)."""
+    plain, net = _pair(monkeypatch)
+    B = 64
+    cond = seeded(4, B, 294, 1, 143).to(DEV)
+    x_T, noises = cpu_noise_sequence(9, (B, 294, 1, 143), 8)
+    outs = []
+    for n in (plain, net):
+        diff = make_diffusion(8)
+        diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+        outs.append(diff.p_sample_loop(n, {'cond': cond}, [B, 294, 1, 143]))
+    assert torch.equal(outs[0], outs[1])
+    x, c, t = _inputs(B)
+    ref = net({'x_t': x, 'cond': c}, t)
+    side = torch.cuda.Stream()
+    xs = x.clone()
+    with torch.cuda.stream(side):
+        net({'x_t': xs, 'cond': c}, t)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        y = net({'x_t': xs, 'cond': c}, t)
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+    with torch.cuda.stream(side):
+        net.check_exchange()
+
+
+def test_a_failed_exchange_inside_the_chain_is_survived(monkeypatch):
+    """The chain's first LayerNorm exchange sabotaged (rohm_posenet_inject_exchange_fault): waits expire, the loop falls back to one
+    launch per GEMM without the in-kernel LayerNorm and repeats the chunk -- the result of a handle that never used them."""
+    with monkeypatch.context() as m:
+        m.setenv('ROHM_POSENET_LN_FUSED', '0')
+        m.setenv('ROHM_POSENET_HEAD_SK', '0')
+        plain, _ = make_posenet(5)
+    _, net = _pair(monkeypatch)
+    B = 32
+    cond = seeded(4, B, 294, 1, 143).to(DEV)
+    x_T, noises = cpu_noise_sequence(9, (B, 294, 1, 143), 6)
+
+    def run(n):
+        diff = make_diffusion(6)
+        diff.fused_chunk = 3
+        diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+        return diff.p_sample_loop(n, {'cond': cond}, [B, 294, 1, 143])
+    want = run(plain)
+    nat = net.native(torch.device(DEV))
+    nat.inject_exchange_fault(1)
+    with pytest.warns(UserWarning, match='ran into its bound'):
+        got = run(net)
+    assert nat.exchange_mode & 19 == 0 and nat.exchange_mode & 8
+    assert torch.equal(got, want)
