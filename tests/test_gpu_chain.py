@@ -119,6 +119,7 @@ def test_a_failed_exchange_inside_the_chain_is_survived(monkeypatch):
         m.setenv('ROHM_POSENET_LN_FUSED', '0')
         m.setenv('ROHM_POSENET_HEAD_SK', '0')
         plain, _ = make_posenet(5)
+        assert plain.native(torch.device(DEV)).exchange_mode == 0      # the handle reads the environment when it is created
     _, net = _pair(monkeypatch)
     B = 32
     cond = seeded(4, B, 294, 1, 143).to(DEV)
