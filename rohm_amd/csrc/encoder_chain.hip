@@ -15,7 +15,8 @@
 // XCD), while the next phase's WEIGHT chunks, which depend on nobody, are already on their way into LDS underneath the epilogue.
 //
 // Arithmetic: every tile is computed exactly as gemm_f32_kernel<BN, EPI, 0, true> computes it (same fragments, same k order, same
-// LayerNorm statistics tree) -- the chain and the launch-per-GEMM path agree bit for bit (tests/test_gpu_chain.py).
+// LayerNorm statistics tree) -- the chain and the launch-per-GEMM path agree to the last bit or two (fma contraction of the epilogue
+// expressions is the compiler's choice per instantiation; tests/test_gpu_chain.py).
 // Exchange discipline: gemm_f32.hip's -- tags from (salt + index) + 64 x the workspace's pass counter, bounded waits that report
 // into the error word, layout guard at create, fallback + re-run by the host (exchange.hip).
 #include <type_traits>

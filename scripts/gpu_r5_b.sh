@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-( time timeout 900 python -m pytest tests/test_gpu_chain.py -m gpu -q -p no:cacheprovider -x --durations=8 2>&1 | grep -v "^$" | tail -40 ) 2>&1 | tee $OUT/pytest_chain.txt
+( time timeout 900 python -m pytest tests/test_gpu_chain.py -m gpu -q -p no:cacheprovider -s --durations=8 2>&1 | grep -v "^$" | tail -40 ) 2>&1 | tee $OUT/pytest_chain.txt
 for leg in "1 64" "0 64" "1 32" "0 32"; do
   set -- $leg
   ROHM_POSENET_CHAIN=$1 timeout 400 python bench.py --no-extras --no-cpu-baseline --batch $2 > $OUT/bench_chain$1_b$2.json 2> $OUT/bench_chain$1_b$2.err
