@@ -193,6 +193,20 @@ struct ChainParams {
     unsigned long long* flags;
     int fault;      // test hook: bit 0 / 1 sabotage the first / second LayerNorm exchange of the launch
 };
+// ---- ... and the whole encoder stack as one launch: per layer  attention (one head, or half of one, per workgroup of the clip) ->
+// the chain above, the layers looped inside the kernel.  qkv holds layer 0's projection on entry (its own launch); h the embedded
+// tokens; on return h = the encoder's output.  n_head must be 4.  flags: encoder_chain_flag_bytes(M).
+struct StackLayerW { const float *out_w, *out_b, *n1_w, *n1_b, *l1_w, *l1_b, *l2_w, *l2_b, *n2_w, *n2_b, *in_w, *in_b; };
+struct StackParams {
+    float *h, *y, *ff, *qkv, *ctx;
+    int M, D, F, tiles_m, L, n_head;
+    float qscale, ln_eps;
+    float* xln_stats; unsigned* xln_err; const unsigned* xln_pass; unsigned* xln_xcc; unsigned epoch;
+    unsigned long long* flags;
+    int fault;
+    StackLayerW layer[8];      // in_w / in_b of layer l feed the phase that closes layer l - 1
+};
+int launch_encoder_stack(const StackParams& p, hipStream_t s);
 int encoder_chain_parts(int M, int D, int F);      // column tiles per clip (4 or 8), 0 = no chain form for this shape
 size_t encoder_chain_flag_bytes(int M);
 int launch_encoder_chain(const ChainParams& p, hipStream_t s);

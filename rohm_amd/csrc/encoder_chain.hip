@@ -22,6 +22,7 @@
 #include <type_traits>
 #include "common.h"
 #include "gemm_sched.h"
+#include "attention_tile.h"
 
 namespace rohm {
 
@@ -94,13 +95,15 @@ __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, in
         }
     }
     __syncthreads();
+    // acquire: nothing this CU cached before the meeting may be served to the loads behind it (buffer_inv sc1)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // One tile of one phase: C[m0.., n0..n0+BN) = epi(A[m0.., :K] . W[n0.., :K]^T).  PREF: the first two W chunks are in LDS (or on
 // their way) already; SC1: A was written by partner workgroups of this launch -- fetch it from L2, never from this CU's L1.
 // `after_loop()` runs once all waves are done with the staging buffers (the place to start the next phase's weights).
 template <int BN, int EPI, bool PREF, bool SC1, typename AfterLoop>
-__device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, AfterLoop&& after_loop) {
+__device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, const int tid, AfterLoop&& after_loop) {
     static_assert(EPI == EPI_BIAS_RES_LN || EPI == EPI_BIAS_GELU || EPI == EPI_QKV, "chain phases: LN tail, GELU, QKV");
     constexpr int WN = BN / 4;
     constexpr bool M32 = WN >= 64;
@@ -115,7 +118,6 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, Afte
     float* lds_dummy = smem + kZone;
     float* const zone = lds_dummy + 512;          // statistics of the LayerNorm tail / bias row of the 384-wide tile
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(256) void encoder_chain_kernel(ChainParams p) {
     const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
     const unsigned ep = p.epoch + 64u * *p.xln_pass;      // the pass counter was advanced by an EARLIER kernel of the stream
     if (tid == 0) p.xln_xcc[g * 8 + tn] = xcc1;
-    unsigned long long* const flags = p.flags + (size_t)g * 3 * 8;
+    unsigned long long* const flags = p.flags + (size_t)g * 8 * 5 * 8;
 
     PhaseArgs a{};
     a.m0 = g * BM; a.err = p.xln_err; a.xcc1 = xcc1; a.tn = tn; a.tiles_n = G;
@@ -524,25 +526,116 @@ __global__ __launch_bounds__(256) void encoder_chain_kernel(ChainParams p) {
     // ---- A: y = norm1(h + ctx . Wo^T + bo) ---------------------------------------------------------------------------------------
     a.A = p.ctx; a.lda = p.D; a.W = p.out_w; a.ldw = p.D; a.C = p.y; a.ldc = p.D; a.K = p.D; a.bias = p.out_b;
     a.R = p.h; a.ldr = p.D; a.gamma = p.n1_w; a.beta = p.n1_b; a.n0 = tn * BNL; a.tag28 = ep & 0x0fffffffu; a.fault = p.fault & 1;
-    gemm_phase<BNL, EPI_BIAS_RES_LN, false, false>(a, smem, [&]() { prefetch_w<BNF>(p.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
+    gemm_phase<BNL, EPI_BIAS_RES_LN, false, false>(a, smem, tid, [&]() { prefetch_w<BNF>(p.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
     group_sync(flags, tn, G, ep, xcc1, p.xln_err, tid);
 
     // ---- B: ff = gelu(y . W1^T + b1) ---------------------------------------------------------------------------------------------
     a.A = p.y; a.lda = p.D; a.W = p.l1_w; a.ldw = p.D; a.C = p.ff; a.ldc = p.F; a.K = p.D; a.bias = p.l1_b; a.n0 = tn * BNF;
-    gemm_phase<BNF, EPI_BIAS_GELU, true, true>(a, smem, [&]() { prefetch_w<BNL>(p.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
+    gemm_phase<BNF, EPI_BIAS_GELU, true, true>(a, smem, tid, [&]() { prefetch_w<BNL>(p.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
     group_sync(flags + 8, tn, G, ep, xcc1, p.xln_err, tid);
 
     // ---- C: h = norm2(y + ff . W2^T + b2) ----------------------------------------------------------------------------------------
     a.A = p.ff; a.lda = p.F; a.W = p.l2_w; a.ldw = p.F; a.C = p.h; a.ldc = p.D; a.K = p.F; a.bias = p.l2_b;
     a.R = p.y; a.ldr = p.D; a.gamma = p.n2_w; a.beta = p.n2_b; a.n0 = tn * BNL; a.tag28 = (ep + 1u) & 0x0fffffffu; a.fault = (p.fault >> 1) & 1;
-    gemm_phase<BNL, EPI_BIAS_RES_LN, true, true>(a, smem, [&]() { if (p.qkv) prefetch_w<BNQ>(p.in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+    gemm_phase<BNL, EPI_BIAS_RES_LN, true, true>(a, smem, tid, [&]() { if (p.qkv) prefetch_w<BNQ>(p.in_w, p.D, tn * BNQ, smem, tid, wave_u); });
     if (p.qkv == nullptr) return;      // last layer: the output head follows as its own launch (uniform over the launch)
     group_sync(flags + 16, tn, G, ep, xcc1, p.xln_err, tid);
 
     // ---- D: qkv = h . Win^T + bin of the next layer, q pre-scaled ------------------------------------------------------------------
     a.A = p.h; a.lda = p.D; a.W = p.in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.in_b; a.n0 = tn * BNQ;
     a.qcols = p.D; a.qscale = p.qscale;
-    gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, []() {});
+    gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, tid, []() {});
+}
+
+// The whole encoder: for every layer  [qkv of the clip complete] attention  [ctx complete]  A  B  C  [D = the next layer's QKV].
+// Workgroup (clip g, part tn) computes, per layer, head tn (G = 4: a whole (clip, head) item on four waves, two owned query blocks
+// per wave) or half tn & 1 of head tn >> 1 (G = 8: the SPLIT shape of attention_f32.hip), then its column tile of every GEMM phase.
+// Every operand another workgroup wrote earlier in THIS launch is fetched past the L1 (sc1 DMA; the L1 is invalidated at each meeting
+// point as well): the same addresses were read one layer earlier.
+template <int G>
+__global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
+    using namespace chain;
+    constexpr int BNL = 512 / G, BNF = 1024 / G, BNQ = 1536 / G;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid0 = threadIdx.x;
+    const int x = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+    const int g = (j / G) * kNumXCD + x, tn = j % G;
+    if (g >= p.tiles_m) return;
+    const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+    const unsigned ep = p.epoch + 64u * *p.xln_pass;
+    if (tid0 == 0) p.xln_xcc[g * 8 + tn] = xcc1;
+
+    PhaseArgs a{};
+    a.m0 = g * BM; a.err = p.xln_err; a.xcc1 = xcc1; a.tn = tn; a.tiles_n = G;
+    a.row_stats = p.xln_stats + ((size_t)g * G * BM) * 4;
+    a.eps = p.ln_eps; a.ln_dim = p.D;
+    a.qcols = p.D; a.qscale = p.qscale;
+#pragma unroll 1
+    for (int l = 0; l < p.L; ++l) {
+        // Everything a phase derives from the thread index -- operand addresses of four GEMM shapes and the attention item -- is
+        // layer-invariant; hoisted out of this loop it is several hundred live registers (measured: 363 spilled).  The index is made
+        // opaque per layer so that each phase computes its addresses where it uses them.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+        const StackLayerW& w = p.layer[l];
+        unsigned long long* const fl = p.flags + ((size_t)g * 8 + l) * 5 * 8;
+        if (l > 0) group_sync(fl, tn, G, ep, xcc1, p.xln_err, tid);                  // the clip's qkv of this layer is complete
+        if constexpr (G == 4) attention_item<4, 0, kSc1, 2>(p.qkv, p.ctx, p.n_head, g * p.n_head + tn, 0, AT_NB, smem, tid);
+        else attention_item<4, 0, kSc1, 1>(p.qkv, p.ctx, p.n_head, g * p.n_head + (tn >> 1), (tn & 1) ? 5 : 0, (tn & 1) ? 4 : 5, smem, tid);
+        group_sync(fl + 8, tn, G, ep, xcc1, p.xln_err, tid);                         // ... its ctx
+
+        a.A = p.ctx; a.lda = p.D; a.W = w.out_w; a.ldw = p.D; a.C = p.y; a.ldc = p.D; a.K = p.D; a.bias = w.out_b;
+        a.R = p.h; a.ldr = p.D; a.gamma = w.n1_w; a.beta = w.n1_b; a.n0 = tn * BNL; a.tag28 = (ep + 4u * l) & 0x0fffffffu;
+        a.fault = (l == 0) ? (p.fault & 1) : 0;
+        gemm_phase<BNL, EPI_BIAS_RES_LN, false, true>(a, smem, tid, [&]() { prefetch_w<BNF>(w.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
+        group_sync(fl + 16, tn, G, ep, xcc1, p.xln_err, tid);
+
+        a.A = p.y; a.lda = p.D; a.W = w.l1_w; a.ldw = p.D; a.C = p.ff; a.ldc = p.F; a.K = p.D; a.bias = w.l1_b; a.n0 = tn * BNF;
+        gemm_phase<BNF, EPI_BIAS_GELU, true, true>(a, smem, tid, [&]() { prefetch_w<BNL>(w.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
+        group_sync(fl + 24, tn, G, ep, xcc1, p.xln_err, tid);
+
+        const bool more = l + 1 < p.L;
+        a.A = p.ff; a.lda = p.F; a.W = w.l2_w; a.ldw = p.F; a.C = p.h; a.ldc = p.D; a.K = p.F; a.bias = w.l2_b;
+        a.R = p.y; a.ldr = p.D; a.gamma = w.n2_w; a.beta = w.n2_b; a.n0 = tn * BNL; a.tag28 = (ep + 4u * l + 1u) & 0x0fffffffu;
+        a.fault = (l == 0) ? ((p.fault >> 1) & 1) : 0;
+        gemm_phase<BNL, EPI_BIAS_RES_LN, true, true>(a, smem, tid, [&]() { if (more) prefetch_w<BNQ>(p.layer[l + 1].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+        if (!more) break;
+        group_sync(fl + 32, tn, G, ep, xcc1, p.xln_err, tid);
+
+        a.A = p.h; a.lda = p.D; a.W = p.layer[l + 1].in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.layer[l + 1].in_b;
+        a.n0 = tn * BNQ;
+        gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, tid, []() {});
+    }
+}
+
+int launch_encoder_stack(const StackParams& p, hipStream_t s) {
+    const int G = encoder_chain_parts(p.M, p.D, p.F);
+    ROHM_ARG_CHECK(G != 0 && p.n_head == 4 && p.L >= 1 && p.L <= 8, "encoder_stack: shape (M %d, D %d, F %d, %d heads, %d layers) has no stack form",
+                   p.M, p.D, p.F, p.n_head, p.L);
+    ROHM_ARG_CHECK(p.h && p.y && p.ff && p.qkv && p.ctx && p.xln_stats && p.xln_err && p.xln_pass && p.xln_xcc && p.flags, "encoder_stack: null operand");
+    StackParams q = p;
+    q.tiles_m = p.M / chain::BM;
+    const int groups8 = (q.tiles_m + kNumXCD - 1) / kNumXCD * kNumXCD;
+    constexpr int kFloats = AT_LDS_FLOATS > chain::kLdsFloats ? AT_LDS_FLOATS : chain::kLdsFloats;
+    const size_t lds = (size_t)kFloats * sizeof(float);
+    static bool attr_set[64][2] = {};
+    int dev = 0;
+    ROHM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev][G == 8]) {
+        if (G == 4) ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_stack_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_stack_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev][G == 8] = true;
+    }
+    const double MM = (double)p.M, D = p.D, F = p.F, L = p.L;
+    // algorithmic work of the launch: L x (attention 4 S^2 d_h per (clip, head) + out-proj + FF1 + FF2) + (L - 1) QKV projections
+    const double flops = L * (4.0 * 144.0 * 128.0 * MM * p.n_head + 2.0 * MM * (D * D + 2.0 * D * F)) + (L - 1.0) * 2.0 * MM * 3.0 * D * D;
+    const double bytes = 4.0 * (L * (MM * (3.0 * D + D + 4.0 * D + 2.0 * F + D) + D * D + 2.0 * D * F) + (L - 1.0) * (MM * 3.0 * D + 3.0 * D * D));
+    prof::Scope ps("gemm_stack", flops, bytes, s);
+    if (G == 4) hipLaunchKernelGGL(encoder_stack_kernel<4>, dim3(groups8 * 4), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL(encoder_stack_kernel<8>, dim3(groups8 * 8), dim3(256), lds, s, q);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
 }
 
 int encoder_chain_parts(int M, int D, int F) {      // 0: this shape has no chain form
@@ -551,7 +644,8 @@ int encoder_chain_parts(int M, int D, int F) {      // 0: this shape has no chai
     return tm * 4 >= 256 ? 4 : 8;      // the tile widths launch_gemm picks for these GEMMs (ln_tile_width: 144 x 128 while every CU gets a tile)
 }
 
-size_t encoder_chain_flag_bytes(int M) { return (size_t)((M + chain::BM - 1) / chain::BM) * 3 * 8 * sizeof(unsigned long long); }
+// [row tile][layer <= 8][meeting point <= 5][part <= 8] (the per-layer chain uses the first 3 x 8 words of a row tile's block)
+size_t encoder_chain_flag_bytes(int M) { return (size_t)((M + chain::BM - 1) / chain::BM) * 8 * 5 * 8 * sizeof(unsigned long long); }
 
 int launch_encoder_chain(const ChainParams& p, hipStream_t s) {
     const int G = encoder_chain_parts(p.M, p.D, p.F);

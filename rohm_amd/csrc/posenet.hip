@@ -63,9 +63,10 @@ struct rohm_posenet {
     // The two launch forms above exchange data between workgroups of one launch (exchange.hip).  They are used only where the device
     // passed the layout guard at create (exch_allowed) and until an exchange failed on this handle (exch_fallback, set by
     // rohm_posenet_set_exchange: the Python loops then re-run the chunk on the exchange-free launches).
-    bool chain_any;                       // chain at every batch size (tests)
-    bool chain;                           // the four GEMMs between two attention launches as ONE launch (encoder_chain.hip; needs ln_fused;
-                                          // default on, ROHM_POSENET_CHAIN=0: one launch per GEMM)
+    bool chain_any;                       // chain at every batch size (tests: ROHM_POSENET_CHAIN_ANY=1)
+    int chain;                            // 0: one launch per GEMM; 1: the four GEMMs between two attention launches as ONE launch; 2 (default):
+                                          // the whole encoder stack, attention included, as one launch (encoder_chain.hip; both need ln_fused;
+                                          // ROHM_POSENET_CHAIN=0 | layer | stack)
     bool ln_fused_env, head_sk_env;       // what the environment asked for
     bool exch_allowed, exch_fallback;
     const char* exch_reason;              // why the guard refused (static string), or what it saw
@@ -301,6 +302,8 @@ static int check_shape(const rohm_posenet* p, int B, int T) {
     return ROHM_OK;
 }
 
+static inline float qscale_of(const rohm_posenet* p) { return 1.0f / sqrtf((float)(p->D / p->H)); }
+
 // Network body: from packed input (w.apack complete) to x0 channels [traj, Cin) in `x0_out`.
 static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t* t_dev, int64_t t_host,
                        const float* tok_pre, float* x0_out, int B, int T, hipStream_t s, bool cond_done = false) {
@@ -394,10 +397,36 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     // the released widths.  Layer l: [QKV of layer 0: its own launch] attention(l), chain(l) = out-proj + norm1, FF1, FF2 + norm2 and
     // the QKV projection of layer l + 1.  Tags: 4 l, 4 l + 1 (the chain's two LayerNorm exchanges and its flags); the head: 60.
     // From 32 clips on (every phase then has >= 256 tiles): below that the launch-per-GEMM path picks narrower tiles per GEMM and keeps
-    // more CUs busy (ROHM_POSENET_CHAIN=2 chains every shape that has the form: tests).
+    // more CUs busy (ROHM_POSENET_CHAIN_ANY=1 chains every shape that has the form: tests).
     const bool chained = lnf && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && (B >= 32 || p->chain_any);
-    const float qscale = 1.0f / sqrtf((float)(D / p->H));
-    for (int l = 0; l < ((planes || !chained) ? 0 : p->L); ++l) {
+    const bool stacked = chained && p->chain == 2 && p->H == 4 && p->L <= 8 && S == 144 && D / p->H == 128;
+    if (stacked) {
+        // ... and with attention inside, the layers looped in the kernel: QKV of layer 0, then ONE launch for the whole encoder
+        const LayerW& l0 = p->layers[0];
+        GemmParams g{};
+        g.A = h; g.lda = D; g.W = l0.in_w; g.ldw = D; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        g.bias = l0.in_b; g.qcols = D; g.qscale = qscale_of(p);
+        if ((rc = launch_gemm(g, EPI_QKV, s))) return rc;
+        StackParams c{};
+        c.h = h; c.y = y; c.ff = w.ff; c.qkv = w.qkv; c.ctx = w.ctx;
+        c.M = M; c.D = D; c.F = p->F; c.L = p->L; c.n_head = p->H; c.qscale = qscale_of(p); c.ln_eps = 1e-5f;
+        for (int l = 0; l < p->L; ++l) {
+            const LayerW& lw = p->layers[l];
+            c.layer[l] = StackLayerW{lw.out_w, lw.out_b, lw.n1_w, lw.n1_b, lw.l1_w, lw.l1_b, lw.l2_w, lw.l2_b, lw.n2_w, lw.n2_b, lw.in_w, lw.in_b};
+        }
+        {
+            GemmParams b{};
+            b.M = M;
+            gemm_ln_bind(b, w.xln);
+            c.xln_stats = b.xln_stats; c.xln_err = b.xln_err; c.xln_pass = b.xln_pass; c.xln_xcc = b.xln_xcc;
+        }
+        c.epoch = p->salt;
+        c.flags = reinterpret_cast<unsigned long long*>(w.chain_flags);
+        if (p->fault_left > 0) { --p->fault_left; c.fault = 1; }
+        if ((rc = launch_encoder_stack(c, s))) return rc;
+    }
+    const float qscale = qscale_of(p);
+    for (int l = 0; l < ((planes || !chained || stacked) ? 0 : p->L); ++l) {
         const LayerW& lw = p->layers[l];
         if (l == 0) {
             GemmParams g{};
@@ -585,8 +614,17 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         // launch index of a pass.  A device that does not look like that -- partitioned, CU-masked, shared -- gets the GEMM +
         // LayerNorm kernel pair and plain output-head tiles from the start (exchange.hip: properties + environment + a probe launch).
         const char* e9 = getenv("ROHM_POSENET_CHAIN");
-        p->chain = !(e9 && e9[0] == '0');
-        p->chain_any = e9 && e9[0] == '2';
+        p->chain = 2;
+        if (e9 && (e9[0] == '0')) p->chain = 0;
+        else if (e9 && (!strcmp(e9, "layer") || !strcmp(e9, "1"))) p->chain = 1;
+        else if (e9 && *e9 && strcmp(e9, "stack") && strcmp(e9, "2")) {
+            set_error("posenet_create: ROHM_POSENET_CHAIN must be 0, layer or stack (got '%s')", e9);
+            (void)hipFree(p->arena);
+            delete p;
+            return ROHM_ERR_ARG;
+        }
+        const char* e10 = getenv("ROHM_POSENET_CHAIN_ANY");
+        p->chain_any = e10 && e10[0] == '1';
         p->ln_fused_env = p->ln_fused; p->head_sk_env = p->head_sk;
         p->exch_fallback = false;
         p->fault_left = 0;
@@ -781,7 +819,7 @@ int rohm_posenet_precision(const rohm_posenet_t* h) { return h ? h->nplane : 0; 
 int rohm_posenet_exchange_mode(const rohm_posenet_t* h) {
     if (!h) return 0;
     return (h->ln_fused ? 1 : 0) | (h->head_sk ? 2 : 0) | ((!h->exch_allowed && (h->ln_fused_env || h->head_sk_env)) ? 4 : 0) |
-           (h->exch_fallback ? 8 : 0) | ((h->chain && h->ln_fused) ? 16 : 0);
+           (h->exch_fallback ? 8 : 0) | ((h->chain && h->ln_fused) ? 16 : 0) | ((h->chain == 2 && h->ln_fused) ? 32 : 0);
 }
 
 const char* rohm_posenet_exchange_guard(const rohm_posenet_t* h) { return h ? h->exch_reason : ""; }

@@ -12,18 +12,23 @@ from test_gpu_posenet import DEV, make_diffusion, make_posenet
 pytestmark = pytest.mark.gpu
 
 
-def _pair(monkeypatch, seed=5, chain='1'):
+def _pair(monkeypatch, seed=5, chain='stack', any_batch=False):
+    """(handle with one launch per GEMM, handle with the chain form `chain`: 'layer' = the four GEMMs between two attention launches
+    as one launch, 'stack' = the whole encoder, attention included, as one launch)."""
     with monkeypatch.context() as m:
         m.setenv('ROHM_POSENET_CHAIN', '0')
         plain, _ = make_posenet(seed)
         plain.native(torch.device(DEV))
     with monkeypatch.context() as m:
         m.setenv('ROHM_POSENET_CHAIN', chain)
+        if any_batch:
+            m.setenv('ROHM_POSENET_CHAIN_ANY', '1')
         net, _ = make_posenet(seed)
         nat = net.native(torch.device(DEV))
     if nat.exchange_mode & 16 == 0:
         pytest.skip(f'the layout guard refused the exchanging launches on this device: {nat.exchange_guard}')
-    assert plain.native(torch.device(DEV)).exchange_mode & 16 == 0
+    assert bool(nat.exchange_mode & 32) == (chain == 'stack')
+    assert plain.native(torch.device(DEV)).exchange_mode & 48 == 0
     return plain, net
 
 
@@ -33,30 +38,34 @@ def _inputs(B, T=143):
     return x, c, t
 
 
+@pytest.mark.parametrize('chain', ['layer', 'stack'])
 @pytest.mark.parametrize('B', [64, 32, 128])
-def test_chain_forward_matches_one_launch_per_gemm(B, monkeypatch):
+def test_chain_forward_matches_one_launch_per_gemm(B, chain, monkeypatch):
     """Same tiles, same fragments, same k order, same LayerNorm statistics tree as the launch-per-GEMM path: the two agree to the last
     bit or two (hipcc contracts `a * b + c` of the epilogues into an fma per instantiation, so an occasional last-place difference
-    is allowed: 4e-6 on |y| <= 4; B = 64 has been seen bit-identical), and the chain itself is bit-reproducible run after run."""
-    plain, net = _pair(monkeypatch)
+    is allowed: 4e-6 on |y| <= 4; B = 64 has been seen bit-identical), and the chain itself is bit-reproducible run after run.
+    'stack' at B >= 64 also runs attention as a whole (clip, head) item on four waves instead of eight (other cooperative split of the
+    ninth query block: summation order)."""
+    plain, net = _pair(monkeypatch, chain=chain)
     x, c, t = _inputs(B)
     want = plain({'x_t': x, 'cond': c}, t)
     got = net({'x_t': x, 'cond': c}, t)
     net.check_exchange()
     diff = (got - want).abs()
-    print(f'B={B}: max|chain - launches| = {float(diff.max()):.3e}, {int((diff > 0).sum())} of {diff.numel()} elements differ')
-    assert float(diff.max()) < 4e-6
+    print(f'B={B} {chain}: max|chain - launches| = {float(diff.max()):.3e}, {int((diff > 0).sum())} of {diff.numel()} elements differ')
+    assert float(diff.max()) < (4e-6 if chain == 'layer' else 2e-5)
     for _ in range(20):      # race screen: the clip's workgroups meet five times per layer; every run the same bits
         assert torch.equal(net({'x_t': x, 'cond': c}, t), got)
     net.check_exchange()
 
 
+@pytest.mark.parametrize('chain', ['layer', 'stack'])
 @pytest.mark.parametrize('B', [40, 33, 3, 1])
-def test_chain_at_other_batch_sizes(B, monkeypatch):
+def test_chain_at_other_batch_sizes(B, chain, monkeypatch):
     """Row tiles that are not a multiple of 8 (surplus workgroups leave), more than one round of workgroups (B = 40: 320), tiny
     batches (forced: by default they keep the launch-per-GEMM path, whose narrower tiles fill more CUs).  The launch-per-GEMM path
     picks other tile widths here, so agreement is to summation order."""
-    plain, net = _pair(monkeypatch, chain='2')
+    plain, net = _pair(monkeypatch, chain=chain, any_batch=True)
     x, c, t = _inputs(B)
     want = plain({'x_t': x, 'cond': c}, t)
     got = net({'x_t': x, 'cond': c}, t)
@@ -65,9 +74,11 @@ def test_chain_at_other_batch_sizes(B, monkeypatch):
     assert torch.equal(net({'x_t': x, 'cond': c}, t), got)
 
 
-def test_chain_vs_reference_goldens(monkeypatch):
+@pytest.mark.parametrize('chain', ['layer', 'stack'])
+def test_chain_vs_reference_goldens(chain, monkeypatch):
     """Forward < 1e-4 and the 8-step loop < 1e-4 against the reference's own outputs, with the chain forced at B = 2."""
-    monkeypatch.setenv('ROHM_POSENET_CHAIN', '2')
+    monkeypatch.setenv('ROHM_POSENET_CHAIN', chain)
+    monkeypatch.setenv('ROHM_POSENET_CHAIN_ANY', '1')
     g = golden('posenet_forward.npz')
     net, _ = make_posenet(int(g['weight_seed']))
     x, c = seeded(int(g['x_seed']), 2, 294, 1, 143), seeded(int(g['cond_seed']), 2, 294, 1, 143)
@@ -86,10 +97,11 @@ def test_chain_vs_reference_goldens(monkeypatch):
     assert max_abs(y.cpu(), torch.from_numpy(g['y'])) < 1e-4
 
 
-def test_chain_loop_at_the_headline_batch(monkeypatch):
+@pytest.mark.parametrize('chain', ['layer', 'stack'])
+def test_chain_loop_at_the_headline_batch(chain, monkeypatch):
     """8 denoising steps of 64 clips through the fused loop: chain vs launch-per-GEMM; recorded into a hipGraph the chain replays
     correctly (its tags come from the workspace's pass counter)."""
-    plain, net = _pair(monkeypatch)
+    plain, net = _pair(monkeypatch, chain=chain)
     B = 64
     cond = seeded(4, B, 294, 1, 143).to(DEV)
     x_T, noises = cpu_noise_sequence(9, (B, 294, 1, 143), 8)
@@ -99,7 +111,7 @@ def test_chain_loop_at_the_headline_batch(monkeypatch):
         diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
         outs.append(diff.p_sample_loop(n, {'cond': cond}, [B, 294, 1, 143]))
     d = float((outs[0] - outs[1]).abs().max())
-    print(f'8-step loop, B = 64: max|chain - launches| = {d:.3e}')
+    print(f'8-step loop, B = 64, {chain}: max|chain - launches| = {d:.3e}')
     assert d < 2e-5
     x, c, t = _inputs(B)
     ref = net({'x_t': x, 'cond': c}, t)
@@ -119,7 +131,8 @@ def test_chain_loop_at_the_headline_batch(monkeypatch):
         net.check_exchange()
 
 
-def test_a_failed_exchange_inside_the_chain_is_survived(monkeypatch):
+@pytest.mark.parametrize('chain', ['layer', 'stack'])
+def test_a_failed_exchange_inside_the_chain_is_survived(chain, monkeypatch):
     """The chain's first LayerNorm exchange sabotaged (rohm_posenet_inject_exchange_fault): waits expire, the loop falls back to one
     launch per GEMM without the in-kernel LayerNorm and repeats the chunk -- the result of a handle that never used them."""
     with monkeypatch.context() as m:
@@ -127,7 +140,7 @@ def test_a_failed_exchange_inside_the_chain_is_survived(monkeypatch):
         m.setenv('ROHM_POSENET_HEAD_SK', '0')
         plain, _ = make_posenet(5)
         assert plain.native(torch.device(DEV)).exchange_mode == 0      # the handle reads the environment when it is created
-    _, net = _pair(monkeypatch)
+    _, net = _pair(monkeypatch, chain=chain)
     B = 32
     cond = seeded(4, B, 294, 1, 143).to(DEV)
     x_T, noises = cpu_noise_sequence(9, (B, 294, 1, 143), 6)
@@ -142,5 +155,5 @@ def test_a_failed_exchange_inside_the_chain_is_survived(monkeypatch):
     nat.inject_exchange_fault(1)
     with pytest.warns(UserWarning, match='ran into its bound'):
         got = run(net)
-    assert nat.exchange_mode & 19 == 0 and nat.exchange_mode & 8
+    assert nat.exchange_mode & 51 == 0 and nat.exchange_mode & 8
     assert torch.equal(got, want)
