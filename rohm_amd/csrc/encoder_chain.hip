@@ -95,8 +95,11 @@ __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, in
         }
     }
     __syncthreads();
-    // acquire: nothing this CU cached before the meeting may be served to the loads behind it (buffer_inv sc1)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // No acquire fence here: at agent scope it is `buffer_inv sc1`, which on this multi-XCD part also drops the L2's lines of ordinary
+    // memory -- weights and activations come back from HBM, measured +5 us per meeting (gemm_chain 322 -> 344 us per layer,
+    // profiles/r5_d_*).  Staleness is excluded where it could arise instead: every operand another workgroup wrote during this launch is
+    // fetched by LDS-DMA with sc1 (device scope: never served by this CU's L1), and the plain loads behind a meeting read constants
+    // (bias, gamma, beta) or the tile this very CU stored (residuals: a CU's own stores are coherent with its L1).
 }
 
 // One tile of one phase: C[m0.., n0..n0+BN) = epi(A[m0.., :K] . W[n0.., :K]^T).  PREF: the first two W chunks are in LDS (or on
