@@ -111,7 +111,7 @@ def pmc_mfma(batch):
         return None
     try:
         k = json.load(open(files[-1]))['kernels']
-        gem = {n: v for n, v in k.items() if 'gemm_f32_kernel' in n}
+        gem = {n: v for n, v in k.items() if 'gemm_f32_kernel' in n or 'encoder_stack_kernel' in n or 'encoder_chain_kernel' in n}
         t = sum(v['avg_us_under_pmc'] * v['launches'] for v in gem.values())
         busy = sum(v['mfma_busy_frac_at_2p4GHz'] * v['avg_us_under_pmc'] * v['launches'] for v in gem.values()) / t
         att = [v for n, v in k.items() if 'attention_f32_kernel' in n]
@@ -884,7 +884,8 @@ def main(argv=None):
             'e2e_frac_executed': (clips * S * (POSENET_GFLOP_PER_CLIP_STEP - 2e-9 * 144 * 512 * 288) * 1e-3 / elapsed / PEAK_F32_MFMA_TFLOPS
                                   if not _PRODUCTS else None),
             'roofline': {
-                'kernel': ('gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region, ' if not _PRODUCTS else
+                'kernel': ('encoder_stack_kernel / gemm_f32_kernel<BN,EPI> (all fp32-MFMA GEMM launches of the timed region -- from round 5 the '
+                           'whole encoder is ONE launch per step, attention inside --, ' if not _PRODUCTS else
                            f'gemm_pp_stream_kernel / gemm_pp_kernel on {_PLANE_TYPE} planes + the fp32 embed / output-head GEMMs (all GEMM launches '
                            'of the timed region, ') + f'sampled every {args.profile_stride}th denoising step)',
                 'bound': 'mfma', 'achieved': achieved,

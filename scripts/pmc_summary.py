@@ -42,7 +42,8 @@ def main():
         wr = vw / nw * 1024 if nw else 0.0
         rows[k] = {'launches': max(nf, nw), 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
                    'hbm_bytes_per_launch': rd + wr}
-    gem = {k: v for k, v in rows.items() if 'gemm_f32_kernel' in k}
+    # the fp32-MFMA family: the GEMM launches and, from round 5, the encoder chain / stack launches that contain most of them
+    gem = {k: v for k, v in rows.items() if 'gemm_f32_kernel' in k or 'encoder_stack_kernel' in k or 'encoder_chain_kernel' in k}
     n = sum(v['launches'] for v in gem.values())
     fam = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in gem.values()) / max(n, 1)
     out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --ddpm-steps 12, B=64',
