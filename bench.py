@@ -912,6 +912,15 @@ def main(argv=None):
                                'avg_launch_us': prof['attention']['total_ms'] / prof['attention']['launches'] * 1e3,
                                'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS}
                               if prof.get('attention', {}).get('total_ms') else standalone_attention(B, dev)),
+                # the dominant kernel on its own (VERDICT convention: algorithmic flops per launch / average launch duration)
+                'dominant': ({'kernel': 'encoder_stack_kernel (label gemm_stack: the whole encoder of one denoising step)',
+                              'launches_timed': prof['gemm_stack']['launches'],
+                              'alg_gflop_per_launch': prof['gemm_stack']['flops'] / prof['gemm_stack']['launches'] / 1e9,
+                              'avg_launch_us': prof['gemm_stack']['total_ms'] / prof['gemm_stack']['launches'] * 1e3,
+                              'achieved': prof['gemm_stack']['flops'] / (prof['gemm_stack']['total_ms'] * 1e-3) / 1e12,
+                              'frac': prof['gemm_stack']['flops'] / (prof['gemm_stack']['total_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                              'time_share_of_kernels': prof['gemm_stack']['total_ms'] / all_ms}
+                             if prof.get('gemm_stack', {}).get('total_ms') else None),
                 'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
                 'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,
                 # round 4: the out-projection / FF2 launches (`gemm_bias_res_ln`) carry the LayerNorm that used to be 16 separate

@@ -21,6 +21,7 @@
 #include <string.h>
 #include <vector>
 #include "common.h"
+#include "gemm_sched.h"
 #include "smplx_fk.h"
 
 namespace rohm {
@@ -229,23 +230,36 @@ __global__ __launch_bounds__(256) void lbs_skin_mfma_kernel(const float* __restr
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* as = As + buf * 2 * SKIN_BM * 32;
+        // K = 64 = four k16 steps (2 chunks x 2): 12 fragment reads + 108 MFMAs each.  The reads of step s + 1 are issued underneath
+        // the MFMAs of step s -- one ds_read_b128 per group of nine MFMAs, pinned with sched_group_barrier like the GEMM's main loop
+        // (round 4 left the interleave to the compiler: it clustered the twelve reads in front of each step and the matrix pipe waited
+        // for LDS four times per tile, 0.57 of fp32 MFMA).
+        struct SkinFrag { f32x4 a[9], b[3]; };
+        SkinFrag sf[2];
+        auto skin_read = [&](SkinFrag& fr, int step) __attribute__((always_inline)) {
+            const int ch = step >> 1, slot = (step & 1) * 4 + lg;
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch)
+            for (int c = 0; c < 3; ++c) fr.b[c] = *reinterpret_cast<const f32x4*>(Bs + ch * SKIN_BN * 32 + skin_lds_off(wave * 48 + c * 16 + li, slot));
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int slot = ks * 4 + lg;
-                f32x4 fa[9], fb[3];
+            for (int r = 0; r < 9; ++r) fr.a[r] = *reinterpret_cast<const f32x4*>(as + ch * SKIN_BM * 32 + skin_lds_off(r * 16 + li, slot));
+        };
+        auto skin_mma = [&](const SkinFrag& fr) __attribute__((always_inline)) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) fb[c] = *reinterpret_cast<const f32x4*>(Bs + ch * SKIN_BN * 32 + skin_lds_off(wave * 48 + c * 16 + li, slot));
+            for (int r = 0; r < 9; ++r)
 #pragma unroll
-                for (int r = 0; r < 9; ++r) fa[r] = *reinterpret_cast<const f32x4*>(as + ch * SKIN_BM * 32 + skin_lds_off(r * 16 + li, slot));
+                for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int r = 0; r < 9; ++r)
+                    for (int j = 0; j < 4; ++j) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.b[c][j], fr.a[r][j], acc[r][c], 0, 0, 0);
+        };
+        skin_read(sf[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[c][j], fa[r][j], acc[r][c], 0, 0, 0);
-            }
+        for (int step = 0; step < 4; ++step) {
+            if (step + 1 < 4) skin_read(sf[(step + 1) & 1], step + 1);
+            skin_mma(sf[step & 1]);
+            if (step + 1 < 4) SchedGroups<0, 12, 9, 12, 0, 0>::run();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // v = G p + t + transl  (G = T[0..8] row-major, t = T[9..11]); the same expression order as the VALU kernels
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
