@@ -205,6 +205,12 @@ struct StackParams {
     unsigned long long* flags;
     int fault;
     StackLayerW layer[8];      // in_w / in_b of layer l feed the phase that closes layer l - 1
+    // front != 0: the launch starts from the packed input instead of from (h, qkv of layer 0): two leading phases per clip,
+    //   h = InputProcess embedding (EPI_EMBED's arithmetic: A = apack [M, lda_pack] over k_embed columns, W = w_embed [D, ldw_embed],
+    //   + positional / timestep table rows) and qkv = in_proj_0(h) -- model/posenet.py:85-92 up to the first encoder layer.
+    int front;
+    const float* apack; int lda_pack; const float* w_embed; int ldw_embed; int k_embed;
+    int S; const float* tab; const float* tab0; int ldtab, ldtab0, tab_by_row;
 };
 int launch_encoder_stack(const StackParams& p, hipStream_t s);
 int encoder_chain_parts(int M, int D, int F);      // column tiles per clip (4 or 8), 0 = no chain form for this shape

@@ -48,6 +48,7 @@ struct PhaseArgs {
     const float* R; int ldr;                       // RES_LN
     const float* gamma; const float* beta; float eps; int ln_dim;
     int qcols; float qscale;                       // QKV
+    int S; const float* tab; const float* tab0; int ldtab, ldtab0, tab_by_row;      // EMBED (common.h GemmParams)
     int m0, n0;
     float* row_stats; unsigned tag28; int tn, tiles_n;      // RES_LN: this row tile's slots, tag of this exchange
     unsigned* err; unsigned xcc1; int fault;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, in
 // `after_loop()` runs once all waves are done with the staging buffers (the place to start the next phase's weights).
 template <int BN, int EPI, bool PREF, bool SC1, typename AfterLoop>
 __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, const int tid, AfterLoop&& after_loop) {
-    static_assert(EPI == EPI_BIAS_RES_LN || EPI == EPI_BIAS_GELU || EPI == EPI_QKV, "chain phases: LN tail, GELU, QKV");
+    static_assert(EPI == EPI_BIAS_RES_LN || EPI == EPI_BIAS_GELU || EPI == EPI_QKV || EPI == EPI_EMBED, "chain phases: LN tail, GELU, QKV, embed");
     constexpr int WN = BN / 4;
     constexpr bool M32 = WN >= 64;
     constexpr int NCB = WN / 16, NCB32 = WN / 32;
@@ -256,12 +257,14 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
     const int nw = n0 + wave * WN;
     struct ColOps { f32x4 bias, g4, b4; };
     constexpr bool RES = (EPI == EPI_BIAS_RES_LN);
+    constexpr bool HAS_RES = RES || EPI == EPI_EMBED;      // a per-unit operand from memory: the residual, or the table row of the embedding
     constexpr bool PEEL = BN <= 256;
     constexpr bool EARLY = PEEL;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto load_col = [&](int nb) __attribute__((always_inline)) {
         ColOps o{zero4, zero4, zero4};
-        if constexpr (COL_LDS) o.bias = *reinterpret_cast<const f32x4*>(zone + (nb - n0));
+        if constexpr (EPI == EPI_EMBED) { /* the biases are part of the table rows */ }
+        else if constexpr (COL_LDS) o.bias = *reinterpret_cast<const f32x4*>(zone + (nb - n0));
         else o.bias = *reinterpret_cast<const f32x4*>(p.bias + nb);
         if constexpr (RES) {
             o.g4 = *reinterpret_cast<const f32x4*>(p.gamma + nb);
@@ -293,7 +296,7 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
         }
     };
     ColOps col[NCG];
-    f32x4 res[RES ? NUNIT : 1];
+    f32x4 res[HAS_RES ? NUNIT : 1];
     auto request_ops = [&]() __attribute__((always_inline)) {
         if constexpr (M32) {
 #pragma unroll
@@ -309,6 +312,12 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
         if constexpr (RES)
             for_units([&](int i, int, int m, int nb, f32x4) __attribute__((always_inline)) {
                 res[i] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nb);
+            });
+        if constexpr (EPI == EPI_EMBED)      // gemm_f32.hip load_res: the timestep token's row for token 0, else the positional (or per-row) table
+            for_units([&](int i, int, int m, int nb, f32x4) __attribute__((always_inline)) {
+                const int bidx = m / p.S, tok = m % p.S;
+                const float* tp = (tok == 0) ? p.tab0 + (size_t)bidx * p.ldtab0 + nb : p.tab + (size_t)(p.tab_by_row ? m : tok) * p.ldtab + nb;
+                res[i] = *reinterpret_cast<const f32x4*>(tp);
             });
     };
 
@@ -480,6 +489,14 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
                 *reinterpret_cast<f32x4*>(p.C + (size_t)(m0 + r * 16 + li) * p.ldc + nw + c * 16 + lg * 4) = v;
             }
         }
+    } else if constexpr (EPI == EPI_EMBED) {
+        for_units([&](int i, int, int m, int nb, f32x4 a) __attribute__((always_inline)) {
+            const int tok = m % p.S;
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (tok == 0 ? 0.f : a[q]) + res[i][q];
+            *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + nb) = v;
+        });
     } else {
         for_units([&](int, int cg, int m, int nb, f32x4 a) __attribute__((always_inline)) {
             f32x4 v;
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(256) void encoder_chain_kernel(ChainParams p) {
     const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
     const unsigned ep = p.epoch + 64u * *p.xln_pass;      // the pass counter was advanced by an EARLIER kernel of the stream
     if (tid == 0) p.xln_xcc[g * 8 + tn] = xcc1;
-    unsigned long long* const flags = p.flags + (size_t)g * 8 * 5 * 8;
+    unsigned long long* const flags = p.flags + (size_t)g * 9 * 5 * 8;
 
     PhaseArgs a{};
     a.m0 = g * BM; a.err = p.xln_err; a.xcc1 = xcc1; a.tn = tn; a.tiles_n = G;
@@ -573,6 +590,21 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
     a.row_stats = p.xln_stats + ((size_t)g * G * BM) * 4;
     a.eps = p.ln_eps; a.ln_dim = p.D;
     a.qcols = p.D; a.qscale = p.qscale;
+    if (p.front) {
+        // ---- E: h = [x_t | cond] . We^T + table rows;  D0: qkv = in_proj_0(h) -- flags of "layer" 8 ------------------------------------
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+        unsigned long long* const fl = p.flags + ((size_t)g * 9 + 8) * 5 * 8;
+        a.A = p.apack; a.lda = p.lda_pack; a.W = p.w_embed; a.ldw = p.ldw_embed; a.C = p.h; a.ldc = p.D; a.K = p.k_embed; a.n0 = tn * BNL;
+        a.S = p.S; a.tab = p.tab; a.tab0 = p.tab0; a.ldtab = p.ldtab; a.ldtab0 = p.ldtab0; a.tab_by_row = p.tab_by_row;
+        gemm_phase<BNL, EPI_EMBED, false, false>(a, smem, tid, [&]() { prefetch_w<BNQ>(p.layer[0].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+        group_sync(fl, tn, G, ep, xcc1, p.xln_err, tid);
+        a.A = p.h; a.lda = p.D; a.W = p.layer[0].in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.layer[0].in_b;
+        a.n0 = tn * BNQ;
+        gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, tid, []() {});
+        group_sync(fl + 8, tn, G, ep, xcc1, p.xln_err, tid);
+    }
 #pragma unroll 1
     for (int l = 0; l < p.L; ++l) {
         // Everything a phase derives from the thread index -- operand addresses of four GEMM shapes and the attention item -- is
@@ -582,7 +614,7 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
         asm volatile("" : "+v"(tid));
         const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
         const StackLayerW& w = p.layer[l];
-        unsigned long long* const fl = p.flags + ((size_t)g * 8 + l) * 5 * 8;
+        unsigned long long* const fl = p.flags + ((size_t)g * 9 + l) * 5 * 8;
         if (l > 0) group_sync(fl, tn, G, ep, xcc1, p.xln_err, tid);                  // the clip's qkv of this layer is complete
         if constexpr (G == 4) attention_item<4, 0, kSc1, 2>(p.qkv, p.ctx, p.n_head, g * p.n_head + tn, 0, AT_NB, smem, tid);
         else attention_item<4, 0, kSc1, 1>(p.qkv, p.ctx, p.n_head, g * p.n_head + (tn >> 1), (tn & 1) ? 5 : 0, (tn & 1) ? 4 : 5, smem, tid);
@@ -617,6 +649,9 @@ int launch_encoder_stack(const StackParams& p, hipStream_t s) {
     ROHM_ARG_CHECK(G != 0 && p.n_head == 4 && p.L >= 1 && p.L <= 8, "encoder_stack: shape (M %d, D %d, F %d, %d heads, %d layers) has no stack form",
                    p.M, p.D, p.F, p.n_head, p.L);
     ROHM_ARG_CHECK(p.h && p.y && p.ff && p.qkv && p.ctx && p.xln_stats && p.xln_err && p.xln_pass && p.xln_xcc && p.flags, "encoder_stack: null operand");
+    ROHM_ARG_CHECK(!p.front || (p.apack && p.w_embed && p.tab && p.tab0 && p.S == chain::BM && p.k_embed >= 2 * chain::BK && p.k_embed % chain::BK == 0 &&
+                                p.lda_pack % 4 == 0 && p.ldw_embed % 4 == 0 && p.ldtab % 4 == 0 && p.ldtab0 % 4 == 0),
+                   "encoder_stack: bad operands of the leading embed phase");
     StackParams q = p;
     q.tiles_m = p.M / chain::BM;
     const int groups8 = (q.tiles_m + kNumXCD - 1) / kNumXCD * kNumXCD;
@@ -632,7 +667,8 @@ int launch_encoder_stack(const StackParams& p, hipStream_t s) {
     }
     const double MM = (double)p.M, D = p.D, F = p.F, L = p.L;
     // algorithmic work of the launch: L x (attention 4 S^2 d_h per (clip, head) + out-proj + FF1 + FF2) + (L - 1) QKV projections
-    const double flops = L * (4.0 * 144.0 * 128.0 * MM * p.n_head + 2.0 * MM * (D * D + 2.0 * D * F)) + (L - 1.0) * 2.0 * MM * 3.0 * D * D;
+    const double flops = L * (4.0 * 144.0 * 128.0 * MM * p.n_head + 2.0 * MM * (D * D + 2.0 * D * F)) + (L - 1.0 + (p.front ? 1.0 : 0.0)) * 2.0 * MM * 3.0 * D * D +
+                         (p.front ? 2.0 * MM * D * p.k_embed : 0.0);
     const double bytes = 4.0 * (L * (MM * (3.0 * D + D + 4.0 * D + 2.0 * F + D) + D * D + 2.0 * D * F) + (L - 1.0) * (MM * 3.0 * D + 3.0 * D * D));
     prof::Scope ps("gemm_stack", flops, bytes, s);
     if (G == 4) hipLaunchKernelGGL(encoder_stack_kernel<4>, dim3(groups8 * 4), dim3(256), lds, s, q);
@@ -647,8 +683,9 @@ int encoder_chain_parts(int M, int D, int F) {      // 0: this shape has no chai
     return tm * 4 >= 256 ? 4 : 8;      // the tile widths launch_gemm picks for these GEMMs (ln_tile_width: 144 x 128 while every CU gets a tile)
 }
 
-// [row tile][layer <= 8][meeting point <= 5][part <= 8] (the per-layer chain uses the first 3 x 8 words of a row tile's block)
-size_t encoder_chain_flag_bytes(int M) { return (size_t)((M + chain::BM - 1) / chain::BM) * 8 * 5 * 8 * sizeof(unsigned long long); }
+// [row tile][layer <= 8, + 1 for the leading embed / QKV phases][meeting point <= 5][part <= 8] (the per-layer chain uses the first 3 x 8
+// words of a row tile's block)
+size_t encoder_chain_flag_bytes(int M) { return (size_t)((M + chain::BM - 1) / chain::BM) * 9 * 5 * 8 * sizeof(unsigned long long); }
 
 int launch_encoder_chain(const ChainParams& p, hipStream_t s) {
     const int G = encoder_chain_parts(p.M, p.D, p.F);

@@ -177,6 +177,43 @@ __global__ __launch_bounds__(256) void finish_kernel(float* __restrict__ x0, con
     }
 }
 
+// finish_kernel with the DDPM update AND pack_kernel of the next step in one pass (sampling loop, every step but the call's last):
+// v = x0 (cond for the trajectory channels), x_prev = c1 v + c2 x_t + sigma noise is written back into x in place and, transposed
+// through LDS, into the x_t half of the next step's token-major pack -- one read of x_t less and one launch less per step.  Also the
+// first kernel of the NEXT pass: it advances the workspace's pass counter (see pack_kernel).
+__global__ __launch_bounds__(256) void finish_pack_kernel(float* __restrict__ x0, const float* __restrict__ cond, float* x,
+                                                          const float* __restrict__ noise, float* __restrict__ apack, float c1, float c2,
+                                                          float sigma, int traj, int C, int T, int S, int KP, unsigned* pass_ctr) {
+    __shared__ float tile[32][33];
+    if (pass_ctr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *pass_ctr += 1u;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const size_t base = (size_t)b * C * T;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, t = t0 + tx;
+        float o = 0.f;
+        if (c < C && t < T) {
+            const size_t idx = base + (size_t)c * T + t;
+            float v;
+            if (c < traj) { v = cond[idx]; x0[idx] = v; }
+            else v = x0[idx];
+            o = c1 * v + c2 * x[idx];
+            if (noise) o += sigma * noise[idx];
+            x[idx] = o;
+        }
+        tile[ty + i * 8][tx] = o;
+    }
+    __syncthreads();
+    float* d = apack + (size_t)b * S * KP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + i * 8, c = c0 + tx;
+        if (t < T && c < C) d[(size_t)(t + 1) * KP + c] = tile[tx][ty + i * 8];
+    }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
     // dst[c][r] = src[r][c]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,19 +357,21 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         }
     }
     int rc;
-    {   // fused input embed (+cond embed, + biases, + positional table)
-        GemmParams g{};
-        g.A = w.apack; g.lda = p->KP; g.W = p->w_embed; g.ldw = p->KP; g.C = w.h; g.ldc = D;
-        g.M = M; g.N = D; g.K = p->KP; g.S = S; g.tab = p->tab; g.tab0 = tok_pre ? tok_pre : w.tab0; g.ldtab = D;
-        g.ldtab0 = (t_dev && !tok_pre) ? D : 0;
-        if (cond_done) {      // w.econd = cond . Wc^T + bx + bc + pe[tok] already (embed_cond): contract x_t only and add it row by row
-            g.W = p->w_embed_x; g.ldw = p->KX; g.K = p->KX; g.tab = w.econd; g.tab_by_row = 1;
-        }
-        if ((rc = launch_gemm(g, EPI_EMBED, s))) return rc;
+    const bool planes = p->nplane && S == 144 && D / p->H == 128;
+    // the launch plan of the encoder (below): decided here because the stack also takes the input embedding and layer 0's in-projection
+    const bool lnf_plan = p->ln_fused && !(p->ln_fold && !planes) && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F);
+    const bool chained_plan = lnf_plan && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && (B >= 32 || p->chain_any);
+    const bool stacked_plan = chained_plan && p->chain == 2 && p->H == 4 && p->L <= 8 && S == 144 && D / p->H == 128;
+    GemmParams ge{};      // fused input embed (+cond embed, + biases, + positional table)
+    ge.A = w.apack; ge.lda = p->KP; ge.W = p->w_embed; ge.ldw = p->KP; ge.C = w.h; ge.ldc = D;
+    ge.M = M; ge.N = D; ge.K = p->KP; ge.S = S; ge.tab = p->tab; ge.tab0 = tok_pre ? tok_pre : w.tab0; ge.ldtab = D;
+    ge.ldtab0 = (t_dev && !tok_pre) ? D : 0;
+    if (cond_done) {      // w.econd = cond . Wc^T + bx + bc + pe[tok] already (embed_cond): contract x_t only and add it row by row
+        ge.W = p->w_embed_x; ge.ldw = p->KX; ge.K = p->KX; ge.tab = w.econd; ge.tab_by_row = 1;
     }
+    if (!stacked_plan && (rc = launch_gemm(ge, EPI_EMBED, s))) return rc;      // (stacked: the embedding is the stack's first phase)
     float* h = w.h;
     float* y = w.y;
-    const bool planes = p->nplane && S == 144 && D / p->H == 128;
     if (planes) {
         // Split-bf16 mode: every producer hands its consumer bf16 planes (planes.h) -- LayerNorm writes fp32 (the residual)
         // AND planes, attention and the GELU GEMM write planes only; the embed output is cut by a small kernel (once per step).
@@ -399,15 +438,18 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     // From 32 clips on (every phase then has >= 256 tiles): below that the launch-per-GEMM path picks narrower tiles per GEMM and keeps
     // more CUs busy (ROHM_POSENET_CHAIN_ANY=1 chains every shape that has the form: tests).
     const bool chained = lnf && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && (B >= 32 || p->chain_any);
-    const bool stacked = chained && p->chain == 2 && p->H == 4 && p->L <= 8 && S == 144 && D / p->H == 128;
+    const bool stacked = stacked_plan;
+    if (stacked != (chained && p->chain == 2 && p->H == 4 && p->L <= 8 && S == 144 && D / p->H == 128)) {
+        set_error("posenet: inconsistent launch plan");      // the two derivations of the plan must agree
+        return ROHM_ERR_ARG;
+    }
     if (stacked) {
-        // ... and with attention inside, the layers looped in the kernel: QKV of layer 0, then ONE launch for the whole encoder
-        const LayerW& l0 = p->layers[0];
-        GemmParams g{};
-        g.A = h; g.lda = D; g.W = l0.in_w; g.ldw = D; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
-        g.bias = l0.in_b; g.qcols = D; g.qscale = qscale_of(p);
-        if ((rc = launch_gemm(g, EPI_QKV, s))) return rc;
+        // ... and with attention inside, the layers looped in the kernel, the input embedding and layer 0's in-projection as leading
+        // phases: ONE launch from the packed input to the encoder's output
         StackParams c{};
+        c.front = 1;
+        c.apack = ge.A; c.lda_pack = ge.lda; c.w_embed = ge.W; c.ldw_embed = ge.ldw; c.k_embed = ge.K;
+        c.S = S; c.tab = ge.tab; c.tab0 = ge.tab0; c.ldtab = ge.ldtab; c.ldtab0 = ge.ldtab0; c.tab_by_row = ge.tab_by_row;
         c.h = h; c.y = y; c.ff = w.ff; c.qkv = w.qkv; c.ctx = w.ctx;
         c.M = M; c.D = D; c.F = p->F; c.L = p->L; c.n_head = p->H; c.qscale = qscale_of(p); c.ln_eps = 1e-5f;
         for (int l = 0; l < p->L; ++l) {
@@ -533,6 +575,17 @@ static int launch_finish(float* x0, const float* cond, const float* x_t, const f
     prof::Scope ps("finish_ddpm", 0.0, 4.0 * n * (x_prev ? 4 : 1), s);
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x0, cond, x_t, noise, x_prev, c1, c2,
                        sigma, traj, C, T, n);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+static int launch_finish_pack(const rohm_posenet* p, float* x0, const float* cond, float* x, const float* noise, float* apack, float c1,
+                              float c2, float sigma, int B, int T, unsigned* pass_ctr, hipStream_t s) {
+    const int C = p->Cin;
+    if (sigma == 0.f) noise = nullptr;
+    dim3 grid((C + 31) / 32, (T + 31) / 32, B);
+    prof::Scope ps("finish_pack", 0.0, 4.0 * (double)B * C * T * (noise ? 6 : 5), s);
+    hipLaunchKernelGGL(finish_pack_kernel, grid, dim3(256), 0, s, x0, cond, x, noise, apack, c1, c2, sigma, p->traj, C, T, T + 1, p->KP, pass_ctr);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
@@ -928,12 +981,17 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
         ROHM_ARG_CHECK(sigma == 0.f || noise, "posenet_sample_loop: noise is required when sigma != 0");
         if (x_in_last && i == n_steps - 1)       // the reference keeps the input of the last step in batch['x_t']
             ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        if ((rc = launch_pack(h, x, w.apack, B, T, 0, s, pass_counter(w)))) return rc;
+        // x_t into the token-major pack: by its own kernel for the first step of the call, afterwards by the previous step's
+        // finish_pack (which also advanced the pass counter)
+        if (i == 0 && (rc = launch_pack(h, x, w.apack, B, T, 0, s, pass_counter(w)))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
         if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s, hoist))) return rc;
-        if ((rc = launch_finish(x0, cond, x, noise ? noise + (size_t)i * n : nullptr, x, c1, c2, sigma, h->traj,
-                                h->Cin, T, n, s)))
+        const float* nz = noise ? noise + (size_t)i * n : nullptr;
+        if (i + 1 < n_steps) {
+            if ((rc = launch_finish_pack(h, x0, cond, x, nz, w.apack, c1, c2, sigma, B, T, pass_counter(w), s))) return rc;
+        } else if ((rc = launch_finish(x0, cond, x, nz, x, c1, c2, sigma, h->traj, h->Cin, T, n, s))) {
             return rc;
+        }
     }
     return ROHM_OK;
 }
