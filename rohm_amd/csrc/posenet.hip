@@ -64,6 +64,8 @@ struct rohm_posenet {
     // passed the layout guard at create (exch_allowed) and until an exchange failed on this handle (exch_fallback, set by
     // rohm_posenet_set_exchange: the Python loops then re-run the chunk on the exchange-free launches).
     bool chain_any;                       // chain at every batch size (tests: ROHM_POSENET_CHAIN_ANY=1)
+    bool stack_front;                     // stack: input embedding + layer 0's in-projection as leading phases (ROHM_POSENET_STACK_FRONT=0: own launches)
+    bool finish_pack;                     // sampling loop: DDPM update + the next step's pack as one kernel (ROHM_POSENET_FINISH_PACK=0: two)
     int chain;                            // 0: one launch per GEMM; 1: the four GEMMs between two attention launches as ONE launch; 2 (default):
                                           // the whole encoder stack, attention included, as one launch (encoder_chain.hip; both need ln_fused;
                                           // ROHM_POSENET_CHAIN=0 | layer | stack)
@@ -369,7 +371,8 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     if (cond_done) {      // w.econd = cond . Wc^T + bx + bc + pe[tok] already (embed_cond): contract x_t only and add it row by row
         ge.W = p->w_embed_x; ge.ldw = p->KX; ge.K = p->KX; ge.tab = w.econd; ge.tab_by_row = 1;
     }
-    if (!stacked_plan && (rc = launch_gemm(ge, EPI_EMBED, s))) return rc;      // (stacked: the embedding is the stack's first phase)
+    const bool front = stacked_plan && p->stack_front;      // the embedding and layer 0's in-projection as the stack's leading phases
+    if (!front && (rc = launch_gemm(ge, EPI_EMBED, s))) return rc;
     float* h = w.h;
     float* y = w.y;
     if (planes) {
@@ -447,9 +450,17 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         // ... and with attention inside, the layers looped in the kernel, the input embedding and layer 0's in-projection as leading
         // phases: ONE launch from the packed input to the encoder's output
         StackParams c{};
-        c.front = 1;
-        c.apack = ge.A; c.lda_pack = ge.lda; c.w_embed = ge.W; c.ldw_embed = ge.ldw; c.k_embed = ge.K;
-        c.S = S; c.tab = ge.tab; c.tab0 = ge.tab0; c.ldtab = ge.ldtab; c.ldtab0 = ge.ldtab0; c.tab_by_row = ge.tab_by_row;
+        if (front) {
+            c.front = 1;
+            c.apack = ge.A; c.lda_pack = ge.lda; c.w_embed = ge.W; c.ldw_embed = ge.ldw; c.k_embed = ge.K;
+            c.S = S; c.tab = ge.tab; c.tab0 = ge.tab0; c.ldtab = ge.ldtab; c.ldtab0 = ge.ldtab0; c.tab_by_row = ge.tab_by_row;
+        } else {      // ROHM_POSENET_STACK_FRONT=0: the round-5 first form, embed and QKV of layer 0 as their own launches
+            const LayerW& l0 = p->layers[0];
+            GemmParams g{};
+            g.A = h; g.lda = D; g.W = l0.in_w; g.ldw = D; g.C = w.qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+            g.bias = l0.in_b; g.qcols = D; g.qscale = qscale_of(p);
+            if ((rc = launch_gemm(g, EPI_QKV, s))) return rc;
+        }
         c.h = h; c.y = y; c.ff = w.ff; c.qkv = w.qkv; c.ctx = w.ctx;
         c.M = M; c.D = D; c.F = p->F; c.L = p->L; c.n_head = p->H; c.qscale = qscale_of(p); c.ln_eps = 1e-5f;
         for (int l = 0; l < p->L; ++l) {
@@ -678,6 +689,10 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         }
         const char* e10 = getenv("ROHM_POSENET_CHAIN_ANY");
         p->chain_any = e10 && e10[0] == '1';
+        const char* e11 = getenv("ROHM_POSENET_STACK_FRONT");
+        p->stack_front = !(e11 && e11[0] == '0');
+        const char* e12 = getenv("ROHM_POSENET_FINISH_PACK");
+        p->finish_pack = !(e12 && e12[0] == '0');
         p->ln_fused_env = p->ln_fused; p->head_sk_env = p->head_sk;
         p->exch_fallback = false;
         p->fault_left = 0;
@@ -983,11 +998,11 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
             ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         // x_t into the token-major pack: by its own kernel for the first step of the call, afterwards by the previous step's
         // finish_pack (which also advanced the pass counter)
-        if (i == 0 && (rc = launch_pack(h, x, w.apack, B, T, 0, s, pass_counter(w)))) return rc;
+        if ((i == 0 || !h->finish_pack) && (rc = launch_pack(h, x, w.apack, B, T, 0, s, pass_counter(w)))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
         if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s, hoist))) return rc;
         const float* nz = noise ? noise + (size_t)i * n : nullptr;
-        if (i + 1 < n_steps) {
+        if (i + 1 < n_steps && h->finish_pack) {
             if ((rc = launch_finish_pack(h, x0, cond, x, nz, w.apack, c1, c2, sigma, B, T, pass_counter(w), s))) return rc;
         } else if ((rc = launch_finish(x0, cond, x, nz, x, c1, c2, sigma, h->traj, h->Cin, T, n, s))) {
             return rc;
