@@ -176,3 +176,63 @@ def test_stream_k_schedule_covers_every_unit_once_and_waits_only_downwards():
             assert [p[1] for p in pieces] == edges[:-1] and edges[-1] == lo and hi == nk, (B, block, pieces, lo)
     assert taken >= 6                                            # B = 32, 64, 96, 128, 192, 256, ...
     assert _stream_k_walk(64)[0] == 18 and _stream_k_walk(32)[0] == 9
+
+
+class _StubNet(torch.nn.Module):
+    """A network with the fused-loop interface of rohm_amd.model.posenet.PoseNet on CPU tensors: `sample_loop_native` applies a known
+    affine update per step (so the expected result is computable), `recover_exchange` reports a failed exchange on demand."""
+
+    def __init__(self, fail_on_calls=()):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.fail_on_calls, self.calls, self.fallback, self.inputs = set(fail_on_calls), 0, False, []
+
+    def sample_loop_native(self, x, cond, t_model, coef, noise, want_x0_last=False, batch=None, x_in_last=None):
+        self.calls += 1
+        self.inputs.append(x.clone())
+        poisoned = self.calls in self.fail_on_calls and not self.fallback
+        for k in range(len(t_model)):
+            if x_in_last is not None and k == len(t_model) - 1:
+                x_in_last.copy_(x)
+            x0 = 0.5 * x + cond
+            x.copy_(float(coef[k][0]) * x0 + float(coef[k][1]) * x + float(coef[k][2]) * noise[k])
+            if poisoned:
+                x.add_(1000.0)                     # what a failed in-kernel exchange leaves behind: garbage
+        self._pending = poisoned
+        return (0.5 * self.inputs[-1] + cond) if want_x0_last else None
+
+    def recover_exchange(self):
+        failed, self._pending = getattr(self, '_pending', False), False
+        if failed:
+            self.fallback = True
+        return failed
+
+
+def test_fused_loop_reruns_a_chunk_whose_exchange_failed():
+    """rohm_amd/diffusion/ddpm.py::_fused_loop: after every fused chunk the network is asked whether an in-kernel exchange failed
+    (PoseNet.recover_exchange: the handle has then switched to its exchange-free launches); the chunk is repeated from its saved input
+    with the SAME noise, so the run equals one in which nothing failed -- also when the failing chunk is the last one (x0 / x_in_last
+    outputs) and when two different chunks fail."""
+    steps, shape = 10, [2, 3, 1, 5]
+    cond = torch.arange(30, dtype=torch.float32).view(shape) * 0.01
+
+    def run(fail_on_calls, chunk):
+        diff = create_gaussian_diffusion(Args, gdp, SpacedDiffusionPoseNet, steps, '', device='cpu')
+        g = torch.Generator().manual_seed(3)
+        x_T = torch.randn(*shape, generator=g)
+        noises = [torch.randn(*shape, generator=g) for _ in range(steps)]
+        diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+        diff.fused_chunk = chunk
+        net = _StubNet(fail_on_calls)
+        batch = {'cond': cond}
+        out = diff.p_sample_loop(net, batch, shape, device='cpu')
+        return out, batch['x_t'], net
+    clean, xin_clean, net0 = run((), 4)
+    assert net0.calls == 3                                    # chunks of 4, 4, 2 steps
+    for fails in ((1,), (3,), (2, 4)):                        # call numbers count re-runs: (2, 4) = second chunk, then the last chunk
+        out, xin, net = run(fails, 4)
+        assert net.fallback and net.calls == 3 + 1            # a handle falls back once, then nothing fails any more
+        assert torch.equal(out, clean) and torch.equal(xin, xin_clean), fails
+        # the repeated call started from the very input of the failed one
+        k = min(fails)
+        assert torch.equal(net.inputs[k - 1], net.inputs[k])
