@@ -97,6 +97,20 @@ def pmc_traffic():
         return None, None
 
 
+def pmc_traffic_of(kernel_substr):
+    """ARCHIVED, like pmc_traffic(): HBM-side bytes per launch of ONE kernel from the most recent committed PMC passes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))['kernels']
+        hit = [v for n, v in k.items() if kernel_substr in n]
+        return float(hit[0]['hbm_bytes_per_launch']) if hit else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def pmc_mfma(batch):
     """ARCHIVED counter figures, not part of this run: MFMA-pipe utilisation of the GEMM family as rocprofv3 counted it in the
     most recent committed PMC pass of THIS batch size (profiles/*pmc_sq[_b<B>].json from scripts/gpu_r2_profile.sh +
@@ -919,7 +933,10 @@ def main(argv=None):
                               'avg_launch_us': prof['gemm_stack']['total_ms'] / prof['gemm_stack']['launches'] * 1e3,
                               'achieved': prof['gemm_stack']['flops'] / (prof['gemm_stack']['total_ms'] * 1e-3) / 1e12,
                               'frac': prof['gemm_stack']['flops'] / (prof['gemm_stack']['total_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                              'time_share_of_kernels': prof['gemm_stack']['total_ms'] / all_ms}
+                              'time_share_of_kernels': prof['gemm_stack']['total_ms'] / all_ms,
+                              'traffic': pmc_traffic_of('encoder_stack_kernel') if B == 64 else None,
+                              'traffic_note': 'ARCHIVED HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 PMC passes of the '
+                                              'B = 64 workload); algorithmic: activations once + weights once per XCD = 3.3 GB'}
                              if prof.get('gemm_stack', {}).get('total_ms') else None),
                 'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
                 'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,

@@ -570,8 +570,8 @@ __global__ __launch_bounds__(256) void encoder_chain_kernel(ChainParams p) {
 // The whole encoder: for every layer  [qkv of the clip complete] attention  [ctx complete]  A  B  C  [D = the next layer's QKV].
 // Workgroup (clip g, part tn) computes, per layer, head tn (G = 4: a whole (clip, head) item on four waves, two owned query blocks
 // per wave) or half tn & 1 of head tn >> 1 (G = 8: the SPLIT shape of attention_f32.hip), then its column tile of every GEMM phase.
-// Every operand another workgroup wrote earlier in THIS launch is fetched past the L1 (sc1 DMA; the L1 is invalidated at each meeting
-// point as well): the same addresses were read one layer earlier.
+// Every operand another workgroup wrote earlier in THIS launch is fetched past the L1 (sc1 LDS-DMA): the same addresses were read one
+// layer earlier.  With front != 0 two leading phases turn the packed input into h and layer 0's qkv first (InputProcess + in_proj_0).
 template <int G>
 __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
     using namespace chain;
