@@ -351,6 +351,7 @@ def scheme_bench(args, world, rank, dev, dist):
         return bt, bp
 
     def one_pass():
+        gather.drain()
         bt, bp = batches()
         run = run_prox_iterations if ego else run_amass_iterations
         pose, _, _ = run(sargs, nets, diffs, bt, bp, tds, pds, layer)
@@ -704,9 +705,11 @@ def timed_region(one_pass, args, world, dev, dist, profile=True, drain=None):
 
 
 class ResultGather:
-    """The path's only exchange -- the finished clips of a pass, one all-gather -- issued asynchronously: it runs on the backend's
-    stream while this rank's stream already works on the next pass, and is completed before the next one is issued (at most one
-    in flight) or by `drain()` at the end of the timed region."""
+    """The path's only exchange -- the finished clips of a pass, one all-gather -- issued asynchronously on the backend's stream:
+    the host goes on preparing the next pass while the collective waits for the slowest rank.  It is completed (`drain`) BEFORE the
+    next pass enqueues compute -- an RCCL kernel that spins on its CUs while it waits for a late peer would otherwise take CUs away
+    from the encoder-stack launch, whose 256 one-per-CU workgroups would then need two rounds -- and by `drain()` inside the timed
+    bracket at the end."""
 
     def __init__(self, n_total, dist):
         self.n_total, self.dist, self.pending, self.last = n_total, dist, None, None
@@ -740,6 +743,7 @@ def selftest_bench(args, world, rank, dev, dist):
     gather = ResultGather(world * B, dist if world > 1 else None)
 
     def one_pass():
+        gather.drain()
         x0 = torch.full((B, 4), float(rank))
         time.sleep(0.01 * (rank + 1))
         gather.submit(x0)
@@ -841,6 +845,7 @@ def main(argv=None):
     torch.manual_seed(rank)
 
     def one_pass():
+        gather.drain()
         batch = {'cond': cond, **extra}
         if prox:
             _, x0 = diffusion.eval_losses(model=net, batch=batch, shape=[B, 294, 1, 143], progress=False,
