@@ -636,7 +636,7 @@ def init_ranks(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     args.cpu_binding = 'single rank: not bound'
-    if world > 1:
+    if world > 1 or args.force_dist:      # (--force-dist: the multi-GPU plumbing at world size 1, the binding included)
         args.cpu_binding = bind_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)), gpu=args.backend != 'gloo')
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with '

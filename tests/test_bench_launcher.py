@@ -149,6 +149,8 @@ def test_force_dist_runs_the_rccl_plumbing_on_one_gpu():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['process_group'] == {'backend': 'nccl', 'world_size': 1, 'forced': True}
     assert d['value'] > 0 and d['roofline']['frac'] > 0
+    # the per-rank CPU / NUMA binding ran on real sysfs (PCI address of the GPU -> numa_node -> that node's cores, or the even split)
+    assert d['config']['cpu_binding'].startswith('rank bound to'), d['config']['cpu_binding']
     # and started bare (no launcher): the script provides its own rendezvous
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--steps', '1', '--warmup', '0', '--batch', '4',
                         '--ddpm-steps', '10', '--no-cpu-baseline', '--no-extras'], env=env, capture_output=True, text=True,
