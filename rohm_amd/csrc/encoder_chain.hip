@@ -110,7 +110,15 @@ template <int BN, int EPI, bool PREF, bool SC1, typename AfterLoop>
 __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, const int tid, AfterLoop&& after_loop) {
     static_assert(EPI == EPI_BIAS_RES_LN || EPI == EPI_BIAS_GELU || EPI == EPI_QKV || EPI == EPI_EMBED, "chain phases: LN tail, GELU, QKV, embed");
     constexpr int WN = BN / 4;
+    // Every phase on v_mfma_f32_16x16x4_f32.  gemm_f32.hip's own launches run rows 0..127 of their 256- / 384-wide tiles on
+    // v_mfma_f32_32x32x2_f32 (half the operand-register traffic per flop; measured faster there in round 2); INSIDE the stack the
+    // all-16x16 form is the faster one: same box, two legs each, 22.36 -> 22.70 clips/s, stack launch 2812 -> 2773 us
+    // (profiles/r5_j_*).  -DROHM_CHAIN_M32 builds the mixed form for A/B runs.
+#ifdef ROHM_CHAIN_M32
     constexpr bool M32 = WN >= 64;
+#else
+    constexpr bool M32 = false;
+#endif
     constexpr int NCB = WN / 16, NCB32 = WN / 32;
     constexpr int B_ITERS = BN * 8 / 256;
     constexpr int PIECES = A_ITERS + B_ITERS;
@@ -237,7 +245,11 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
 
     // ---- prologue -----------------------------------------------------------------------------------------------------------
     const int nk = p.K / BK;                       // >= 16 here
-    constexpr bool COL_LDS = BN >= 384;            // no registers for 18 column groups of bias during the loop: the row goes through LDS
+#ifdef ROHM_CHAIN_NO_COL_LDS      // experiment builds: with the all-16x16 form a 384-wide tile has 6 column groups per lane, not 18
+    constexpr bool COL_LDS = false;
+#else
+    constexpr bool COL_LDS = BN >= 384;            // the 384-wide tile takes its bias row through LDS (gemm_f32.hip's choice for that width)
+#endif
     if constexpr (!PREF) { dma_b(0, 0); dma_b(1, BK); }
     if constexpr (COL_LDS) {
         if (wave == 0) {
@@ -255,11 +267,21 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
 
     // ---- epilogue operands (requested at the top of the peeled last chunk: they land under its MFMAs) --------------------------
     const int nw = n0 + wave * WN;
+#ifdef ROHM_CHAIN_NO_COL_LDS
+    constexpr bool COL_LDS_TILE = false;
+#else
+    constexpr bool COL_LDS_TILE = BN >= 384;       // (= COL_LDS of the prologue: its bias row comes from LDS, nothing to request early)
+#endif
     struct ColOps { f32x4 bias, g4, b4; };
     constexpr bool RES = (EPI == EPI_BIAS_RES_LN);
     constexpr bool HAS_RES = RES || EPI == EPI_EMBED;      // a per-unit operand from memory: the residual, or the table row of the embedding
-    constexpr bool PEEL = BN <= 256;
-    constexpr bool EARLY = PEEL;
+    // the last chunk's iteration is peeled (no wait / barrier / prefetch in it, the epilogue's operands requested at its top) for tiles up to
+    // ROHM_CHAIN_PEEL_MAX columns: 256 like gemm_f32.hip (measured: peeling the 384-wide tile too loses 0.6 %, profiles/r5_k_*)
+#ifndef ROHM_CHAIN_PEEL_MAX
+#define ROHM_CHAIN_PEEL_MAX 256
+#endif
+    constexpr bool PEEL = BN <= ROHM_CHAIN_PEEL_MAX;
+    constexpr bool EARLY = PEEL && !COL_LDS_TILE;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto load_col = [&](int nb) __attribute__((always_inline)) {
         ColOps o{zero4, zero4, zero4};
