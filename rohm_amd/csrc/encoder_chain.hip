@@ -106,7 +106,7 @@ __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, in
 // One tile of one phase: C[m0.., n0..n0+BN) = epi(A[m0.., :K] . W[n0.., :K]^T).  PREF: the first two W chunks are in LDS (or on
 // their way) already; SC1: A was written by partner workgroups of this launch -- fetch it from L2, never from this CU's L1.
 // `after_loop()` runs once all waves are done with the staging buffers (the place to start the next phase's weights).
-template <int BN, int EPI, bool PREF, bool SC1, typename AfterLoop>
+template <int BN, int EPI, bool PREF, bool SC1, bool REFETCH, typename AfterLoop>
 __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, const int tid, AfterLoop&& after_loop) {
     static_assert(EPI == EPI_BIAS_RES_LN || EPI == EPI_BIAS_GELU || EPI == EPI_QKV || EPI == EPI_EMBED, "chain phases: LN tail, GELU, QKV, embed");
     constexpr int WN = BN / 4;
@@ -350,8 +350,15 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
     read_frags(f0, 0, 0);
     constexpr int NG = READS;
     constexpr int MF = (MFMAS + NG - 1) / NG;
-    auto chunk = [&](int kc, auto last_tag) __attribute__((always_inline)) {
+    // chunk kc: [reads of half 1 | MFMAs of half 0] wait + barrier [DMA of chunk kc + 2, reads of chunk kc + 1's half 0 | MFMAs of half 1].
+    // LAST: the final chunk, peeled -- nothing to wait for or prefetch, the epilogue's operands requested at its top.  DMA = false: an
+    // iteration behind which there is no chunk kc + 2: gemm_f32.hip re-fetches the last chunk there to keep ONE loop body (REFETCH); or the
+    // body is instantiated once more without the DMA.  Measured inside the stack, same box, two rounds (profiles/r5_m_*): without the
+    // redundant DMA +0.5 % at B = 64 (4 parts per clip), -1.0 % at B = 32 (8 parts: its 64- / 128- / 192-wide tiles) -- so the kernel
+    // picks per G.
+    auto chunk = [&](int kc, auto last_tag, auto dma_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr bool DMA = decltype(dma_tag)::value;
         const int buf = kc & 1;
         if constexpr (LAST && EARLY) request_ops();
         read_frags(f1, buf, 1);
@@ -362,22 +369,28 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            const int kn = ((kc + 2 < nk) ? (kc + 2) : (nk - 1)) * BK;      // the last iterations re-fetch the last chunk: one basic block
-            dma_a(buf, kn);
-            dma_b(buf, kn);
+            if constexpr (DMA) {
+                const int kn = ((kc + 2 < nk) ? (kc + 2) : (nk - 1)) * BK;
+                dma_a(buf, kn);
+                dma_b(buf, kn);
+            }
             read_frags(f0, buf ^ 1, 0);
             mma_half(f1);
-            SchedGroups<0, NG, MF, READS, PIECES, 1>::run();
+            SchedGroups<0, NG, MF, READS, DMA ? PIECES : 0, 1>::run();
         } else {
             mma_half(f1);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    using DmaTail = std::integral_constant<bool, REFETCH>;      // do the iterations without a chunk kc + 2 issue a (redundant) DMA?
     if constexpr (PEEL) {
-        for (int kc = 0; kc + 1 < nk; ++kc) chunk(kc, std::false_type{});
-        chunk(nk - 1, std::true_type{});
+        for (int kc = 0; kc + 2 < nk; ++kc) chunk(kc, std::false_type{}, std::true_type{});
+        chunk(nk - 2, std::false_type{}, DmaTail{});
+        chunk(nk - 1, std::true_type{}, std::false_type{});
     } else {
-        for (int kc = 0; kc < nk; ++kc) chunk(kc, std::false_type{});
+        for (int kc = 0; kc + 2 < nk; ++kc) chunk(kc, std::false_type{}, std::true_type{});
+        chunk(nk - 2, std::false_type{}, DmaTail{});
+        chunk(nk - 1, std::false_type{}, DmaTail{});
     }
     // every DMA of this phase has landed (the re-fetched last chunk included) and every wave is done reading the staging buffers:
     // they belong to the next phase from here on
@@ -568,25 +581,25 @@ __global__ __launch_bounds__(256) void encoder_chain_kernel(ChainParams p) {
     // ---- A: y = norm1(h + ctx . Wo^T + bo) ---------------------------------------------------------------------------------------
     a.A = p.ctx; a.lda = p.D; a.W = p.out_w; a.ldw = p.D; a.C = p.y; a.ldc = p.D; a.K = p.D; a.bias = p.out_b;
     a.R = p.h; a.ldr = p.D; a.gamma = p.n1_w; a.beta = p.n1_b; a.n0 = tn * BNL; a.tag28 = ep & 0x0fffffffu; a.fault = p.fault & 1;
-    gemm_phase<BNL, EPI_BIAS_RES_LN, false, false>(a, smem, tid, [&]() { prefetch_w<BNF>(p.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
+    gemm_phase<BNL, EPI_BIAS_RES_LN, false, false, G == 8>(a, smem, tid, [&]() { prefetch_w<BNF>(p.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
     group_sync(flags, tn, G, ep, xcc1, p.xln_err, tid);
 
     // ---- B: ff = gelu(y . W1^T + b1) ---------------------------------------------------------------------------------------------
     a.A = p.y; a.lda = p.D; a.W = p.l1_w; a.ldw = p.D; a.C = p.ff; a.ldc = p.F; a.K = p.D; a.bias = p.l1_b; a.n0 = tn * BNF;
-    gemm_phase<BNF, EPI_BIAS_GELU, true, true>(a, smem, tid, [&]() { prefetch_w<BNL>(p.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
+    gemm_phase<BNF, EPI_BIAS_GELU, true, true, G == 8>(a, smem, tid, [&]() { prefetch_w<BNL>(p.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
     group_sync(flags + 8, tn, G, ep, xcc1, p.xln_err, tid);
 
     // ---- C: h = norm2(y + ff . W2^T + b2) ----------------------------------------------------------------------------------------
     a.A = p.ff; a.lda = p.F; a.W = p.l2_w; a.ldw = p.F; a.C = p.h; a.ldc = p.D; a.K = p.F; a.bias = p.l2_b;
     a.R = p.y; a.ldr = p.D; a.gamma = p.n2_w; a.beta = p.n2_b; a.n0 = tn * BNL; a.tag28 = (ep + 1u) & 0x0fffffffu; a.fault = (p.fault >> 1) & 1;
-    gemm_phase<BNL, EPI_BIAS_RES_LN, true, true>(a, smem, tid, [&]() { if (p.qkv) prefetch_w<BNQ>(p.in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+    gemm_phase<BNL, EPI_BIAS_RES_LN, true, true, G == 8>(a, smem, tid, [&]() { if (p.qkv) prefetch_w<BNQ>(p.in_w, p.D, tn * BNQ, smem, tid, wave_u); });
     if (p.qkv == nullptr) return;      // last layer: the output head follows as its own launch (uniform over the launch)
     group_sync(flags + 16, tn, G, ep, xcc1, p.xln_err, tid);
 
     // ---- D: qkv = h . Win^T + bin of the next layer, q pre-scaled ------------------------------------------------------------------
     a.A = p.h; a.lda = p.D; a.W = p.in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.in_b; a.n0 = tn * BNQ;
     a.qcols = p.D; a.qscale = p.qscale;
-    gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, tid, []() {});
+    gemm_phase<BNQ, EPI_QKV, true, true, G == 8>(a, smem, tid, []() {});
 }
 
 // The whole encoder: for every layer  [qkv of the clip complete] attention  [ctx complete]  A  B  C  [D = the next layer's QKV].
@@ -620,11 +633,11 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
         unsigned long long* const fl = p.flags + ((size_t)g * 9 + 8) * 5 * 8;
         a.A = p.apack; a.lda = p.lda_pack; a.W = p.w_embed; a.ldw = p.ldw_embed; a.C = p.h; a.ldc = p.D; a.K = p.k_embed; a.n0 = tn * BNL;
         a.S = p.S; a.tab = p.tab; a.tab0 = p.tab0; a.ldtab = p.ldtab; a.ldtab0 = p.ldtab0; a.tab_by_row = p.tab_by_row;
-        gemm_phase<BNL, EPI_EMBED, false, false>(a, smem, tid, [&]() { prefetch_w<BNQ>(p.layer[0].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+        gemm_phase<BNL, EPI_EMBED, false, false, G == 8>(a, smem, tid, [&]() { prefetch_w<BNQ>(p.layer[0].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
         group_sync(fl, tn, G, ep, xcc1, p.xln_err, tid);
         a.A = p.h; a.lda = p.D; a.W = p.layer[0].in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.layer[0].in_b;
         a.n0 = tn * BNQ;
-        gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, tid, []() {});
+        gemm_phase<BNQ, EPI_QKV, true, true, G == 8>(a, smem, tid, []() {});
         group_sync(fl + 8, tn, G, ep, xcc1, p.xln_err, tid);
     }
 #pragma unroll 1
@@ -645,24 +658,24 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
         a.A = p.ctx; a.lda = p.D; a.W = w.out_w; a.ldw = p.D; a.C = p.y; a.ldc = p.D; a.K = p.D; a.bias = w.out_b;
         a.R = p.h; a.ldr = p.D; a.gamma = w.n1_w; a.beta = w.n1_b; a.n0 = tn * BNL; a.tag28 = (ep + 4u * l) & 0x0fffffffu;
         a.fault = (l == 0) ? (p.fault & 1) : 0;
-        gemm_phase<BNL, EPI_BIAS_RES_LN, false, true>(a, smem, tid, [&]() { prefetch_w<BNF>(w.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
+        gemm_phase<BNL, EPI_BIAS_RES_LN, false, true, G == 8>(a, smem, tid, [&]() { prefetch_w<BNF>(w.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
         group_sync(fl + 16, tn, G, ep, xcc1, p.xln_err, tid);
 
         a.A = p.y; a.lda = p.D; a.W = w.l1_w; a.ldw = p.D; a.C = p.ff; a.ldc = p.F; a.K = p.D; a.bias = w.l1_b; a.n0 = tn * BNF;
-        gemm_phase<BNF, EPI_BIAS_GELU, true, true>(a, smem, tid, [&]() { prefetch_w<BNL>(w.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
+        gemm_phase<BNF, EPI_BIAS_GELU, true, true, G == 8>(a, smem, tid, [&]() { prefetch_w<BNL>(w.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
         group_sync(fl + 24, tn, G, ep, xcc1, p.xln_err, tid);
 
         const bool more = l + 1 < p.L;
         a.A = p.ff; a.lda = p.F; a.W = w.l2_w; a.ldw = p.F; a.C = p.h; a.ldc = p.D; a.K = p.F; a.bias = w.l2_b;
         a.R = p.y; a.ldr = p.D; a.gamma = w.n2_w; a.beta = w.n2_b; a.n0 = tn * BNL; a.tag28 = (ep + 4u * l + 1u) & 0x0fffffffu;
         a.fault = (l == 0) ? ((p.fault >> 1) & 1) : 0;
-        gemm_phase<BNL, EPI_BIAS_RES_LN, true, true>(a, smem, tid, [&]() { if (more) prefetch_w<BNQ>(p.layer[l + 1].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+        gemm_phase<BNL, EPI_BIAS_RES_LN, true, true, G == 8>(a, smem, tid, [&]() { if (more) prefetch_w<BNQ>(p.layer[l + 1].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
         if (!more) break;
         group_sync(fl + 32, tn, G, ep, xcc1, p.xln_err, tid);
 
         a.A = p.h; a.lda = p.D; a.W = p.layer[l + 1].in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.layer[l + 1].in_b;
         a.n0 = tn * BNQ;
-        gemm_phase<BNQ, EPI_QKV, true, true>(a, smem, tid, []() {});
+        gemm_phase<BNQ, EPI_QKV, true, true, G == 8>(a, smem, tid, []() {});
     }
 }
 
