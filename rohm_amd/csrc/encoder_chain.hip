@@ -311,10 +311,20 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
 #pragma unroll
             for (int c = 0; c < NCB; ++c) fn(16 * NCB32 + c, 4 * NCB32 + c, m0 + 128 + li, nw + c * 16 + lg * 4, acc16[c]);
         } else {
+            // row-major over the lane's units: the NCB 64-byte pieces of a row's WN columns are stored by consecutive instructions, so
+            // the halves of a 128-byte line reach L2 together (column-major order -- gemm_f32.hip's -- left 9 stores between them and
+            // the wide tiles' HBM-side write traffic 20 % above the algorithmic, profiles/r5_n_pmc_traffic.txt)
+#ifndef ROHM_CHAIN_STORE_COLMAJOR
+#pragma unroll
+            for (int r = 0; r < NRB; ++r)
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) fn(c * NRB + r, c, m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c]);
+#else
 #pragma unroll
             for (int c = 0; c < NCB; ++c)
 #pragma unroll
                 for (int r = 0; r < NRB; ++r) fn(c * NRB + r, c, m0 + r * 16 + li, nw + c * 16 + lg * 4, acc16[r * NCB + c]);
+#endif
         }
     };
     ColOps col[NCG];
