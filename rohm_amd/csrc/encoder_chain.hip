@@ -37,7 +37,11 @@ constexpr int kMaxBN = 384;
 // the statistics / bias-row zone -- so that the next phase's weight chunks can land while this phase's epilogue still uses its zone
 constexpr int kZone = 2 * (BM + kMaxBN) * BK;                          // float offset
 constexpr int kLdsFloats = kZone + 512 + 4 * BM * 2;
+#ifdef ROHM_CHAIN_NO_SC1      // TIMING experiments only (results may be stale): what does the device-scope policy of the operand loads cost?
+constexpr int kSc1 = 0;
+#else
 constexpr int kSc1 = 16;                                               // cache policy of a load that must come from L2 (device scope)
+#endif
 
 struct PhaseArgs {
     const float* A; int lda;
@@ -87,7 +91,9 @@ __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, in
                 if ((unsigned)(f >> 32) != xcc1) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
+#ifndef ROHM_CHAIN_NO_SLEEP
             __builtin_amdgcn_s_sleep(1);
+#endif
             if ((it & 127) == 127 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             if (it > (1 << 19)) {
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
