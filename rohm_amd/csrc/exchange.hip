@@ -9,6 +9,7 @@
 // model/heads.py:171-176.
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "common.h"
 
 namespace rohm {
@@ -115,6 +116,8 @@ bool exchange_layout_ok(int device, const char** why) {
     const char* guard = getenv("ROHM_EXCHANGE_GUARD");
     if (guard && !strcmp(guard, "off")) { if (why) *why = "guard off"; return true; }
     if (device < 0 || device >= 64) { if (why) *why = kOutOfRange; return false; }
+    static std::mutex probe_mutex;      // handles may be created from several host threads: one probe launch per device, ever
+    std::lock_guard<std::mutex> lock(probe_mutex);
     if (state[device] == 0) {
         reason[device] = probe_device(device);
         state[device] = reason[device] ? 2 : 1;

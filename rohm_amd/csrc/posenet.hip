@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <atomic>
 #include "common.h"
 #include "planes.h"
 
@@ -700,8 +701,8 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         p->exch_allowed = (p->ln_fused || p->head_sk) && 2 * n_layer + 1 <= 60 && exchange_layout_ok(device, &p->exch_reason);
         if (!p->exch_allowed) p->ln_fused = p->head_sk = false;
         {      // per-handle salt of the launch tags: a recycled workspace that holds another handle's (or anybody's) old words is stale
-            static unsigned counter = 0;
-            unsigned v = (unsigned)(uintptr_t)p ^ (unsigned)((uintptr_t)p >> 32) ^ (++counter * 0x9e3779b9u);
+            static std::atomic<unsigned> counter{0};
+            unsigned v = (unsigned)(uintptr_t)p ^ (unsigned)((uintptr_t)p >> 32) ^ ((counter.fetch_add(1u) + 1u) * 0x9e3779b9u);
             v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
             p->salt = v & ~63u;
         }
