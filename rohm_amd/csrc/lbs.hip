@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <type_traits>
 #include "common.h"
 #include "gemm_sched.h"
 #include "smplx_fk.h"
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256) void lbs_skin_mfma_kernel(const float* __restr
     if (f_ok) { tr[0] = transl[(size_t)f * 3]; tr[1] = transl[(size_t)f * 3 + 1]; tr[2] = transl[(size_t)f * 3 + 2]; }
     const float* vp_f = vposed + (size_t)(f_ok ? f : 0) * ldv;
     float* out_f = verts + (size_t)(f_ok ? f : 0) * V * 3;
-    // posed vertices: a tile's 9 x 3 values per lane are requested ONE TILE AHEAD (left to the compiler the loads sink to their
-    // use behind the MFMAs and every tile pays their round trip before its stores)
+    // posed vertices: a tile's 9 x 3 values per lane are requested at the top of the tile's iteration and used one iteration later (left to
+    // the compiler the loads sink to their use and every tile pays their round trip in front of its stores)
     auto load_pv = [&](int t, float (&o)[9][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
@@ -199,42 +200,51 @@ __global__ __launch_bounds__(256) void lbs_skin_mfma_kernel(const float* __restr
             o[r][0] = q[0]; o[r][1] = q[1]; o[r][2] = q[2];
         }
     };
-    float pv[9][3], pv_next[9][3];
-    load_pv(t0, pv);
-    // ... and a tile's results are stored at the START of the next iteration (behind its barrier): the s_waitcnt vmcnt(0) in front
-    // of every barrier then waits for stores that are a whole tile old instead of the ones just issued
-    float ov[9][3];
-    auto store_ov = [&](int t) __attribute__((always_inline)) {
+    float pv[9][3];
+    // Two accumulator sets: while tile t's 432 MFMAs run, tile t - 1's epilogue arithmetic (v = G p + t + transl: 135 VALU operations per
+    // lane) is dealt out between them -- with one wave per SIMD the matrix pipe otherwise idles through every tile's epilogue (round 5:
+    // pinning the fragment reads alone bought nothing, the kernel sat at 0.75 of its MFMA issue floor).  K = 64 = four k16 steps (2 chunks x
+    // 2) of 12 fragment reads + 108 MFMAs; step s + 1's reads and a quarter of the previous tile's rows go underneath step s's MFMAs,
+    // pinned with sched_group_barrier (one ds_read_b128 and <= 4 VALU per nine MFMAs); the quarter's (masked) stores follow the step.
+    float fin[9][12];         // the previous tile's finished accumulators (copied out of the accumulator set: 108 moves per tile), as scalars
+    float pv_prev[9][3];      // posed vertices of the previous tile (its epilogue runs now); `pv` = this tile's, landing under its MFMAs
+    struct SkinFrag { f32x4 a[9], b[3]; };
+    // rows [r_lo, r_hi) of a finished tile -> o3: the same expression order as the VALU kernels
+    auto epi_rows = [&](const float (&a)[9][12], const float (&p)[9][3], int r_lo, int r_hi, float (&o3)[3][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            if (r < r_lo || r >= r_hi) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)      // T = a[r][0..11]: G row-major in [0, 9), t in [9, 12)
+                o3[r - r_lo][c] = a[r][c * 3] * p[r][0] + a[r][c * 3 + 1] * p[r][1] + a[r][c * 3 + 2] * p[r][2] + a[r][9 + c] + tr[c];
+        }
+    };
+    auto store_rows = [&](int t, int r_lo, int r_hi, const float (&o3)[3][3]) __attribute__((always_inline)) {
         if (!f_ok) return;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
+            if (r < r_lo || r >= r_hi) continue;
             const int v = t * SKIN_BM + r * 16 + li;
             if (v < V) {
                 float* o = out_f + (size_t)v * 3;
-                o[0] = ov[r][0]; o[1] = ov[r][1]; o[2] = ov[r][2];
+                o[0] = o3[r - r_lo][0]; o[1] = o3[r - r_lo][1]; o[2] = o3[r - r_lo][2];
             }
         }
     };
-    for (int t = t0; t < t1; ++t) {
+    auto tile = [&](auto prev_tag, int t) __attribute__((always_inline)) {
+        constexpr bool HAS_PREV = decltype(prev_tag)::value;   // is there a previous tile whose epilogue rides along?
         const int buf = (t - t0) & 1;
-        const int m0 = t * SKIN_BM;
         // this tile's weights (DMA issued one iteration ago, or in the prologue) have landed; everyone is done with the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < t1) dma_rows(Wp + (size_t)(t + 1) * SKIN_BM * SKIN_K, SKIN_BM, As + (buf ^ 1) * 2 * SKIN_BM * 32, SKIN_BM * 32);
-        load_pv(t + 1 < t1 ? t + 1 : t, pv_next);
-        if (t > t0) store_ov(t - 1);
+        load_pv(t, pv);                                        // needed one tile from now
         f32x4 acc[9][3];
 #pragma unroll
         for (int r = 0; r < 9; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* as = As + buf * 2 * SKIN_BM * 32;
-        // K = 64 = four k16 steps (2 chunks x 2): 12 fragment reads + 108 MFMAs each.  The reads of step s + 1 are issued underneath
-        // the MFMAs of step s -- one ds_read_b128 per group of nine MFMAs, pinned with sched_group_barrier like the GEMM's main loop
-        // (round 4 left the interleave to the compiler: it clustered the twelve reads in front of each step and the matrix pipe waited
-        // for LDS four times per tile, 0.57 of fp32 MFMA).
-        struct SkinFrag { f32x4 a[9], b[3]; };
         SkinFrag sf[2];
         auto skin_read = [&](SkinFrag& fr, int step) __attribute__((always_inline)) {
             const int ch = step >> 1, slot = (step & 1) * 4 + lg;
@@ -253,29 +263,38 @@ __global__ __launch_bounds__(256) void lbs_skin_mfma_kernel(const float* __restr
         };
         skin_read(sf[0], 0);
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int kRowLo[5] = {0, 3, 5, 7, 9};             // the previous tile's rows whose epilogue rides under step 0 .. 3
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
+            float o3[3][3];
             if (step + 1 < 4) skin_read(sf[(step + 1) & 1], step + 1);
+            if constexpr (HAS_PREV) epi_rows(fin, pv_prev, kRowLo[step], kRowLo[step + 1], o3);
             skin_mma(sf[step & 1]);
-            if (step + 1 < 4) SchedGroups<0, 12, 9, 12, 0, 0>::run();
+            if (step + 1 < 4) SchedGroups<0, 12, 9, 12, 0, 0, HAS_PREV ? 4 : 0>::run();
+            else SchedGroups<0, 12, 9, 0, 0, 1, HAS_PREV ? 4 : 0>::run();
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // v = G p + t + transl  (G = T[0..8] row-major, t = T[9..11]); the same expression order as the VALU kernels
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const float T[12] = {acc[r][0][0], acc[r][0][1], acc[r][0][2], acc[r][0][3], acc[r][1][0], acc[r][1][1],
-                                 acc[r][1][2], acc[r][1][3], acc[r][2][0], acc[r][2][1], acc[r][2][2], acc[r][2][3]};
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                ov[r][c] = T[c * 3] * pv[r][0] + T[c * 3 + 1] * pv[r][1] + T[c * 3 + 2] * pv[r][2] + T[9 + c] + tr[c];
+            if constexpr (HAS_PREV) store_rows(t - 1, kRowLo[step], kRowLo[step + 1], o3);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 9; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pv[r][c] = pv_next[r][c];
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fin[r][c * 4 + q] = acc[r][c][q];
+                pv_prev[r][c] = pv[r][c];
+            }
         // the next tile's DMA (issued above) landed under the MFMAs; the wait at the top of the next iteration covers it
+    };
+    tile(std::false_type{}, t0);
+    for (int t = t0 + 1; t < t1; ++t) tile(std::true_type{}, t);
+    // the last tile's epilogue has nobody to ride under
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float o3[3][3];
+        epi_rows(fin, pv_prev, 3 * q, 3 * q + 3, o3);
+        store_rows(t1 - 1, 3 * q, 3 * q + 3, o3);
     }
-    store_ov(t1 - 1);
 }
 
 // ---- skinning, sparse weights (and the VALU reference form of the dense case) ------------------------------------------------
