@@ -91,7 +91,19 @@ int rohm_layernorm_f32(float* x, const float* gamma, const float* beta, int M, i
  * this call advances on the device.  A scratch the library has not seen (no magic: uninitialised or recycled memory) is zeroed by the
  * call itself.  The slots are tagged with that device-side counter, so the launch may be recorded into a hipGraph: every replay
  * draws a fresh tag.  The partner tiles must be co-resident on one XCD: on a device that is not a whole MI355X (partitioned, CU
- * mask, probe launch failed -- see rohm_posenet_exchange_mode) the call returns ROHM_ERR_UNSUPPORTED. */
+ * mask, probe launch failed -- see rohm_posenet_exchange_mode) the call returns ROHM_ERR_UNSUPPORTED.
+ * The device in question is the one that owns `scratch`.  Its layout verdict comes from rohm_exchange_probe (below) or from an
+ * earlier rohm_posenet_create on that device; on a device nobody has probed yet, the FIRST call of this function (and of
+ * rohm_output_process_f32 with a scratch) runs the probe itself -- a hipMalloc, a null-stream launch and a device synchronisation,
+ * once -- unless `stream` is recording a graph: then nothing is probed or cached, this call returns ROHM_ERR_UNSUPPORTED and
+ * rohm_output_process_f32 uses plain tiles.  Call rohm_exchange_probe(device) before a capture (or before a latency-critical first
+ * call) and these entry points never synchronise. */
+/* Layout probe of `device`, always run afresh: properties, the CU-mask environment, 256 one-per-CU workgroups that must be resident
+ * together with block b on XCD b % 8.  Returns 1 if the exchanging launches may be used there, 0 if not; `why` (optional) receives a
+ * static string.  Allocates, launches on the null stream and synchronises the device: a set-up call.  A verdict about the device is
+ * cached for the later launch calls; "the probe could not run" (set-up / launch failed) is returned but never cached.  Probes are
+ * serialised across the processes of a host (advisory file lock), so the ranks of a node do not time each other out. */
+int rohm_exchange_probe(int device, const char** why);
 size_t rohm_gemm_res_layernorm_scratch_bytes(int M, int N);
 int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                                 const float* bias, const float* R, int ldr, const float* gamma, const float* beta, float eps,
@@ -242,12 +254,17 @@ size_t rohm_posenet_status_offset(const rohm_posenet_t* h, int B, int T);
  * failed); bit 3: switched off after a failed exchange (rohm_posenet_set_exchange(h, 0)); bit 4: where the shape allows it (whole
  * 144-token clips, d_model 512, d_ff 1024) the four GEMMs between two attention launches -- out-projection + norm1, linear1 + GELU,
  * linear2 + norm2, the next layer's in-projection -- run as ONE launch whose workgroups hand tiles to each other per clip
- * (ROHM_POSENET_CHAIN=0: one launch per GEMM).  ROHM_EXCHANGE_GUARD=off skips the guard, =probe skips its environment shortcut. */
+ * (ROHM_POSENET_CHAIN=0: one launch per GEMM); bit 5: ... and attention too -- the whole encoder stack of a forward is one launch
+ * (`encoder_stack_kernel`, the default from 32 clips on; ROHM_POSENET_CHAIN=layer keeps bit 4 without bit 5).  Bits 4 / 5 say what
+ * the handle WOULD launch where the shape qualifies (whole clips, B >= 32 or ROHM_POSENET_CHAIN_ANY=1); they need bit 0.
+ * ROHM_EXCHANGE_GUARD=off skips the guard, =probe skips its environment shortcut. */
 int rohm_posenet_exchange_mode(const rohm_posenet_t* h);
 const char* rohm_posenet_exchange_guard(const rohm_posenet_t* h);
 /* on = 0: from now on this handle runs the exchange-free launches (GEMM + LayerNorm kernel pair, plain output-head tiles) -- what the
  * sampling loops do, before re-running the chunk, when rohm_posenet_exchange_status reports a failure.  on = 1: back to what the
- * environment asked for and the guard allowed.  Not to be called while launches of this handle are being issued by another thread. */
+ * environment asked for and the guard allows -- the guard is asked AGAIN if it had refused at create or the handle had fallen back
+ * (a tenant that was resident then may have gone): that re-probe synchronises the device, so on = 1 is a control call between runs.
+ * Not to be called while launches of this handle are being issued by another thread. */
 int rohm_posenet_set_exchange(rohm_posenet_t* h, int on);
 /* Test hook: the next `n_launches` LayerNorm-carrying GEMM launches of this handle publish one column tile's statistics under a
  * wrong tag, so its partners' waits expire (~0.2 s, once) and the error word is set -- a real failed exchange for the fallback tests. */

@@ -62,6 +62,7 @@ SIGNATURES = {
     'rohm_profile_detail': (C.c_int, [C.c_int]),
     'rohm_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'rohm_exchange_probe': (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     'rohm_gemm_res_layernorm_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'rohm_gemm_res_layernorm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,

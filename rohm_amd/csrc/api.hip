@@ -119,6 +119,22 @@ int rohm_gemm_f32(const float* A, int lda, const float* W, int ldw, float* C, in
     return launch_gemm(g, epi, (hipStream_t)stream);
 }
 
+// Host part of the launch tags of the stand-alone exchanging entry points: a hash of the scratch ADDRESS (low six bits clear: the
+// kernels add the launch index and the XCD field there).  A recycled allocator block whose old header survives (magic set) while its
+// slot region overlaps what used to be ANOTHER scratch's slots cannot produce a matching tag: that scratch lived at another address.
+static unsigned standalone_salt(const void* scratch) {
+    unsigned v = (unsigned)(uintptr_t)scratch ^ (unsigned)((uintptr_t)scratch >> 32) ^ 0x5a17c0u;
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v & ~63u;
+}
+
+int rohm_exchange_probe(int device, const char** why) {
+    const char* w = "";
+    const bool ok = exchange_layout_ok(device, &w, true);
+    if (why) *why = w;
+    return ok ? 1 : 0;
+}
+
 size_t rohm_gemm_res_layernorm_scratch_bytes(int M, int N) { return gemm_ln_supported(M, N, 32) ? gemm_ln_scratch_bytes(M, N) : 0; }
 
 int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
@@ -133,16 +149,27 @@ int rohm_gemm_res_layernorm_f32(const float* A, int lda, const float* W, int ldw
     GemmParams g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.R = R; g.ldr = ldr; g.ln_gamma = gamma; g.ln_beta = beta; g.ln_dim = N; g.ln_eps = eps;
-    // the column tiles meet in L2 while they run: only on a device laid out as the kernel's block -> tile map assumes (exchange.hip)
-    int dev = 0;
-    ROHM_HIP_CHECK(hipGetDevice(&dev));
+    // the column tiles meet in L2 while they run: only on a device laid out as the kernel's block -> tile map assumes (exchange.hip).
+    // The device is the one that owns the scratch (not whatever hipGetDevice says); an un-probed device is probed HERE only when the
+    // stream is not recording a graph -- the probe allocates and synchronises -- and a capturing call on an un-probed device is
+    // refused without caching anything (rohm_exchange_probe(device) up front avoids both).
+    const int dev = device_of_pointer(scratch);
     const char* why = "";
-    if (!exchange_layout_ok(dev, &why)) {
+    int st = exchange_layout_state(dev, &why);
+    if (st == 0) {
+        if (stream_is_capturing((hipStream_t)stream)) {
+            set_error("gemm_res_layernorm: device %d has not been probed and the stream is recording a graph: call rohm_exchange_probe(%d) "
+                      "before the capture, or use rohm_gemm_f32(epi 2) + rohm_layernorm_f32", dev, dev);
+            return ROHM_ERR_UNSUPPORTED;
+        }
+        st = exchange_layout_ok(dev, &why) ? 1 : 2;
+    }
+    if (st != 1) {
         set_error("gemm_res_layernorm: the in-kernel LayerNorm needs a whole MI355X (%s): use rohm_gemm_f32(epi 2) + rohm_layernorm_f32", why);
         return ROHM_ERR_UNSUPPORTED;
     }
     gemm_ln_bind(g, scratch);
-    g.xln_epoch = 0x5a17c0u;      // + 64 x the scratch's pass counter, advanced by exchange_arm
+    g.xln_epoch = standalone_salt(scratch);      // + 64 x the scratch's pass counter, advanced by exchange_arm
     int rc = exchange_arm(static_cast<unsigned*>(scratch), static_cast<char*>(scratch) + 64, gemm_ln_scratch_bytes(M, N) - 64, nullptr, 0, true,
                           (hipStream_t)stream);
     if (rc) return rc;
@@ -169,11 +196,12 @@ int rohm_output_process_f32(const float* h, const float* w, const float* b, floa
     if (scratch) {
         ROHM_ARG_CHECK(scratch_bytes >= rohm_output_process_scratch_bytes() && (((uintptr_t)scratch) & 255) == 0,
                        "output_process: scratch too small / misaligned");
-        int dev = 0;
-        ROHM_HIP_CHECK(hipGetDevice(&dev));
-        if (exchange_layout_ok(dev, nullptr)) {      // else: plain tiles, like a call without scratch
+        const int dev = device_of_pointer(scratch);
+        int st = exchange_layout_state(dev, nullptr);
+        if (st == 0 && !stream_is_capturing((hipStream_t)stream)) st = exchange_layout_ok(dev, nullptr) ? 1 : 2;
+        if (st == 1) {      // else (refused, or un-probed under a graph capture -- not cached): plain tiles, like a call without scratch
             gemm_sk_bind(g, static_cast<char*>(scratch) + 256, static_cast<unsigned*>(scratch));
-            g.xln_epoch = 0x5a17c0u + 1u;
+            g.xln_epoch = standalone_salt(scratch) + 1u;
             int rc = exchange_arm(static_cast<unsigned*>(scratch), static_cast<char*>(scratch) + 256, 256 * sizeof(unsigned long long), nullptr, 0,
                                   true, (hipStream_t)stream);
             if (rc) return rc;

@@ -174,7 +174,14 @@ int exchange_arm(unsigned* header, void* za, size_t za_bytes, void* zb, size_t z
 // b % 8 (a whole MI355X in SPX mode, no CU mask, nobody else's kernels resident)?  Queried once per device: properties, the CU-mask
 // environment variables and a probe launch (256 one-per-CU workgroups that must all be resident at once and report their XCD).
 // ROHM_EXCHANGE_GUARD=off trusts the device, =probe skips the environment shortcut.  `why` receives a static reason string.
-bool exchange_layout_ok(int device, const char** why);
+// The probe allocates, launches on the null stream and synchronises the device: it belongs to handle creation / rohm_exchange_probe,
+// never to a launch path that may be recording a hipGraph.  `reprobe` asks again even if a verdict is cached (after a fallback, or
+// when a tenant that was there at first create has gone); a verdict that only says the probe could not run is never cached.
+bool exchange_layout_ok(int device, const char** why, bool reprobe = false);
+// The cached verdict without ever probing: 0 not probed yet, 1 fine, 2 refused.
+int exchange_layout_state(int device, const char** why);
+// The device that owns the allocation `ptr` points into (hipPointerGetAttributes); the current device if that cannot be told.
+int device_of_pointer(const void* ptr);
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 

@@ -7,8 +7,11 @@
 //     the exchange-free launches and re-run the chunk).
 // Reference work this protects: the post-norm tails of nn.TransformerEncoderLayer, model/posenet.py:63-69, and OutputProcess,
 // model/heads.py:171-176.
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <mutex>
 #include "common.h"
 
@@ -78,6 +81,11 @@ static const char* probe_device(int device) {
     }
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return "hipSetDevice failed"; }
+    // One probe at a time per HOST, across processes: the ranks of a node create their handles at the same moment, each next to
+    // its RCCL initialisation; eight 256-workgroup probes are cheap but their bounded waits should not be timed against a host
+    // that is busy launching seven others.  Advisory lock, best effort (no lock file = no serialisation, never an error).
+    int lock_fd = open("/tmp/.rohm_exchange_probe.lock", O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (lock_fd >= 0 && flock(lock_fd, LOCK_EX) != 0) { close(lock_fd); lock_fd = -1; }
     const char* verdict = nullptr;
     unsigned* buf = nullptr;
     unsigned host[1 + 2 * kProbeWgs];
@@ -105,25 +113,59 @@ static const char* probe_device(int device) {
     }
     if (buf) (void)hipFree(buf);
     (void)hipGetLastError();
+    if (lock_fd >= 0) { (void)flock(lock_fd, LOCK_UN); close(lock_fd); }
     (void)hipSetDevice(prev);
     return verdict;
 }
 
-bool exchange_layout_ok(int device, const char** why) {
-    static const char* reason[64];
-    static int state[64];      // 0 unknown, 1 fine, 2 refused
+// A verdict that says something about the DEVICE is kept; one that only says the probe itself could not run (set-up / launch failed:
+// out of memory at that moment, a capturing null stream, a transient runtime error) is returned but not cached, so a later call
+// probes again.
+static bool verdict_is_transient(const char* v) {
+    return v && (!strcmp(v, "probe set-up failed") || !strcmp(v, "probe launch failed") || !strcmp(v, "hipSetDevice failed") ||
+                 !strcmp(v, "hipGetDeviceProperties failed"));
+}
+
+static std::mutex g_probe_mutex;      // handles may be created from several host threads: one probe launch per device at a time
+static const char* g_reason[64];
+static int g_state[64];               // 0 unknown, 1 fine, 2 refused
+
+int exchange_layout_state(int device, const char** why) {
+    const char* guard = getenv("ROHM_EXCHANGE_GUARD");
+    if (guard && !strcmp(guard, "off")) { if (why) *why = "guard off"; return 1; }
+    if (device < 0 || device >= 64) { if (why) *why = "device index >= 64"; return 2; }
+    std::lock_guard<std::mutex> lock(g_probe_mutex);
+    if (why) *why = g_state[device] == 0 ? "not probed yet" : (g_reason[device] ? g_reason[device] : "whole device, block b on XCD b % 8");
+    return g_state[device];
+}
+
+bool exchange_layout_ok(int device, const char** why, bool reprobe) {
     static const char* const kOutOfRange = "device index >= 64";
     const char* guard = getenv("ROHM_EXCHANGE_GUARD");
     if (guard && !strcmp(guard, "off")) { if (why) *why = "guard off"; return true; }
     if (device < 0 || device >= 64) { if (why) *why = kOutOfRange; return false; }
-    static std::mutex probe_mutex;      // handles may be created from several host threads: one probe launch per device, ever
-    std::lock_guard<std::mutex> lock(probe_mutex);
-    if (state[device] == 0) {
-        reason[device] = probe_device(device);
-        state[device] = reason[device] ? 2 : 1;
+    std::lock_guard<std::mutex> lock(g_probe_mutex);
+    if (g_state[device] == 0 || reprobe) {
+        const char* v = probe_device(device);
+        if (verdict_is_transient(v)) {      // says nothing about the device: answer "no" now, ask again next time
+            if (why) *why = v;
+            g_state[device] = 0;
+            return false;
+        }
+        g_reason[device] = v;
+        g_state[device] = v ? 2 : 1;
     }
-    if (why) *why = reason[device] ? reason[device] : "whole device, block b on XCD b % 8";
-    return state[device] == 1;
+    if (why) *why = g_reason[device] ? g_reason[device] : "whole device, block b on XCD b % 8";
+    return g_state[device] == 1;
+}
+
+int device_of_pointer(const void* ptr) {
+    hipPointerAttribute_t attr;
+    if (ptr && hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.device >= 0) return attr.device;
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return dev;
 }
 
 }  // namespace rohm

@@ -895,7 +895,11 @@ const char* rohm_posenet_exchange_guard(const rohm_posenet_t* h) { return h ? h-
 
 int rohm_posenet_set_exchange(rohm_posenet_t* h, int on) {
     ROHM_ARG_CHECK(h != nullptr, "posenet_set_exchange: null handle");
-    if (on) {      // back to what the environment asked for and the guard allowed
+    if (on) {      // back to what the environment asked for and the guard allows -- asked AGAIN: a tenant that made the probe at
+                   // create fail may have gone, a handle that fell back may be on a device that is whole again.  The
+                   // probe synchronises the device: this is a control call, never part of a launch path.
+        if ((h->ln_fused_env || h->head_sk_env) && 2 * h->L + 1 <= 60 && (!h->exch_allowed || h->exch_fallback))
+            h->exch_allowed = exchange_layout_ok(h->device, &h->exch_reason, true);
         h->exch_fallback = false;
         h->ln_fused = h->ln_fused_env && h->exch_allowed;
         h->head_sk = h->head_sk_env && h->exch_allowed;

@@ -101,6 +101,7 @@ class DDPMSampler:
         self.original_num_steps = self.num_timesteps
         self.noise_source = None     # optional callable (loop_step, like_tensor) -> noise; tests inject here
         self.fused_chunk = 50        # loop steps per rohm_posenet_sample_loop call / noise chunk
+        self.guided_poll = 10        # guided (step-wise) tail: steps between two polls of the in-kernel exchange status
 
     # ------------------------------------------------------------------ schedule tables
     def host_tables(self):
@@ -141,21 +142,26 @@ class DDPMSampler:
         assert t.shape == (B,)
         batch['x_t'] = x
         pred_xstart = raw(batch, self._mapped(t), **(model_kwargs or {}))
+        if self._exchange_failed(raw):                     # as in _step: the forward is pure, run it again exchange-free
+            pred_xstart = raw(batch, self._mapped(t), **(model_kwargs or {}))
+            self._check_exchange(raw)
         tab = self.device_tables(x.device)
         mean = ops.ddpm_step_table(x.contiguous(), pred_xstart, None, tab, t.contiguous())
         shape = (B,) + (1,) * (x.dim() - 1)
         return {'mean': mean, 'variance': tab[t, 2].view(shape), 'log_variance': tab[t, 3].view(shape),
                 'pred_xstart': pred_xstart}
 
-    def _step(self, model, batch, x, t, step, grad_type=None, t_int=None):
-        """One ancestral step: network -> (guidance) -> fused update kernel."""
+    def _step(self, model, batch, x, t, step, grad_type=None, t_int=None, noise=None, poll=True):
+        """One ancestral step: network -> (guidance) -> fused update kernel.  `poll=False`: the caller checks the in-kernel
+        exchanges itself, every few steps, and re-runs from its checkpoint (the guided tail of `_fused_loop`); `noise`: pre-drawn."""
         raw = getattr(model, 'model', model)
         batch['x_t'] = x
         x0 = raw(batch, self._mapped(t))
-        if self._exchange_failed(raw):                     # the forward is a pure function of (x, cond, t): run it again, exchange-free
+        if poll and self._exchange_failed(raw):            # the forward is a pure function of (x, cond, t): run it again, exchange-free
             x0 = raw(batch, self._mapped(t))
             self._check_exchange(raw)
-        noise = self._noise(step, x)                       # drawn BEFORE guidance (…posenet.py:458)
+        if noise is None:
+            noise = self._noise(step, x)                   # drawn BEFORE guidance (…posenet.py:458)
         grads = []
         if grad_type is not None:
             if not self.supports_guidance or grad_type not in GUIDANCE:
@@ -179,11 +185,16 @@ class DDPMSampler:
                  model_kwargs=None, const_noise=False):
         if cond_fn is not None or const_noise:
             raise NotImplementedError('cond_fn / const_noise are never used by the RoHM drivers')
+        self._new_run(getattr(model, 'model', model))       # a directly driven step has no run boundary: nothing per-run is reused
         with torch.no_grad():
             return self._step(model, batch, x, t, step=None)
 
     def p_sample_with_grad(self, model, batch, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
                            grad_type=None, model_kwargs=None, const_noise=False):
+        # driven step by step (the reference API allows it) there is no run boundary to key the guidance's per-run cache on: drop it,
+        # so the global batch size is all-reduced by EVERY rank at EVERY directly driven guided step (8 bytes) -- never stale, never
+        # a collective that only some ranks enter
+        self._new_run(getattr(model, 'model', model))
         with torch.no_grad():
             return self._step(model, batch, x, t, step=None, grad_type=grad_type)
 
@@ -200,6 +211,9 @@ class DDPMSampler:
         if skip_timesteps or init_image is not None or const_noise or cond_fn is not None:
             raise NotImplementedError('skip_timesteps / init_image / const_noise / cond_fn are unused by RoHM')
         raw = getattr(model, 'model', model)
+        # a sampling run starts here whoever drives the generator (p_sample_loop, or a caller of the public generator as in the
+        # reference API): per-run guidance caches are dropped before step 0 so every rank enters the same collectives
+        self._new_run(raw)
         if device is None:
             device = next(raw.parameters()).device
         img = noise if noise is not None else self._x_T(shape, device)
@@ -298,6 +312,7 @@ class DDPMSampler:
 
     def _fused_loop(self, raw, batch, shape, noise, device, cond_fn_with_grad, grad_type, early_stop):
         """Device-resident runs of un-guided steps + per-step execution of the guided tail."""
+        self._new_run(raw)
         if device is None:
             device = next(raw.parameters()).device
         x = (noise if noise is not None else self._x_T(shape, device)).to(torch.float32).contiguous().clone()
@@ -343,12 +358,27 @@ class DDPMSampler:
                     x0_last = x0
                 pos += n
             B = shape[0]
-            for step in range(n_free, len(indices)):
+            # Guided tail, step by step.  The in-kernel exchanges are polled (one stream synchronisation) every `guided_poll`
+            # steps instead of after every forward: the steps since the last clean poll are kept re-runnable -- their input and
+            # their noise -- so a failed exchange still costs a warning and a repeat, never wrong samples.
+            exchanging = getattr(raw, 'uses_exchange', lambda: False)()
+            step, ck_step, ck_x, ck_in, ck_x0, saved = n_free, n_free, x, x_in_last, x0_last, []
+            while step < len(indices):
                 i = indices[step]
                 t = torch.full((B,), i, device=x.device, dtype=torch.int64)
+                k = step - ck_step
+                if k == len(saved):
+                    saved.append(self._noise(step, x))
                 x_in_last = x
-                out = self._step(raw, batch, x, t, step, grad_type=grad_type, t_int=i)
+                out = self._step(raw, batch, x, t, step, grad_type=grad_type, t_int=i, noise=saved[k], poll=not exchanging)
                 x, x0_last = out['sample'], out['pred_xstart']
+                step += 1
+                if exchanging and (step - ck_step >= self.guided_poll or step == len(indices)):
+                    if self._exchange_failed(raw):          # the handle now runs its exchange-free launches: repeat from the checkpoint
+                        exchanging = False
+                        step, x, x_in_last, x0_last = ck_step, ck_x, ck_in, ck_x0
+                        continue
+                    ck_step, ck_x, ck_in, ck_x0, saved = step, x, x_in_last, x0_last, []
         # the reference leaves the INPUT of the last executed step in batch['x_t'] (p_mean_variance, :264)
         batch['x_t'] = x_in_last if x_in_last is not None else x
         return x0_last if early_stop else x

@@ -251,7 +251,15 @@ class PoseNet(nn.Module):
         the current stream.  MANDATORY after direct `forward` calls whose output matters (the status is not polled per forward: that
         would be a host synchronisation on the hot path); the diffusion loops use `recover_exchange` instead."""
         if self._native is not None:
-            self._native.check_exchange()
+            msg = self._native.poll_exchange()
+            if msg is not None:
+                if self._native.exchange_mode & 3 == 0:
+                    msg += ' -- and the handle was not using the exchanging launches'
+                raise _lib.RohmHipError(msg)
+
+    def uses_exchange(self):
+        """True while the native handle launches kernels whose workgroups exchange data (rohm_posenet_exchange_mode bits 0 / 1)."""
+        return self._native is not None and self._native.exchange_mode & 3 != 0
 
     def recover_exchange(self):
         """What the diffusion loops call after every fused chunk of steps and after every step-wise forward: False if every
@@ -260,13 +268,13 @@ class PoseNet(nn.Module):
         tells the caller to RE-RUN what it computed since the last check (noise is injected or pre-drawn, so the re-run is exact).
         A failure while the exchange-free launches were already in use cannot come from them and raises."""
         nat = self._native
-        if nat is None:
+        if nat is None or nat.exchange_mode & 3 == 0:
+            # nothing exchanges: no D2H copy, no stream synchronisation on the step-wise paths (ADVICE r5).  The once-per-run
+            # `check_exchange` at the end of a sampling run still reads the word.
             return False
         msg = nat.poll_exchange()
         if msg is None:
             return False
-        if nat.exchange_mode & 3 == 0:
-            raise _lib.RohmHipError(msg + ' -- and the handle was not using the exchanging launches')
         nat.set_exchange(False)
         warnings.warn('PoseNet: ' + msg + '.  The device is shared, partitioned or masked in a way the layout guard did not see at '
                       'create; this handle now runs the GEMM + LayerNorm kernel pair and plain output-head tiles (a few percent '

@@ -67,6 +67,16 @@ def output_process(h, w, b, B, T, ch_off=0, c_total=None, out=None, stream_k=Tru
     return (out, scratch) if return_scratch else out
 
 
+def exchange_probe(device=None):
+    """rohm_exchange_probe: (re-)run the layout probe of `device` -> (ok, reason).  A set-up call (it synchronises the device): run it
+    before recording a graph that contains gemm_res_layernorm / output_process launches, or after a tenant has left the device."""
+    import ctypes as C
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    why = C.c_char_p()
+    ok = lib().rohm_exchange_probe(dev.index or 0, C.byref(why))
+    return bool(ok), (why.value.decode() if why.value else '')
+
+
 def layernorm_(x, gamma, beta):
     _lib.require_hip(x)
     M, D = x.shape
