@@ -451,7 +451,10 @@ def brief(d):
                              'time_share_of_kernels': rf.get('gemm_time_share_of_kernels')},
            'child_wall_s': d.get('child_wall_s')}
     if rf.get('attention'):
-        out['attention_roofline'] = {k: rf['attention'][k] for k in ('achieved', 'frac', 'avg_launch_us')}
+        out['attention_roofline'] = {k: rf['attention'].get(k) for k in ('achieved', 'frac', 'avg_launch_us', 'share_of_launch',
+                                                                           'frac_incl_meeting')}
+        out['attention_roofline']['measured'] = ('inside the encoder-stack launch (phase stamps)' if 'share_of_launch' in rf['attention']
+                                                 else 'attention kernel launches')
     return out
 
 
@@ -518,6 +521,27 @@ def standalone_attention(B, dev, reps=40):
                         f'its own launch, {reps} back-to-back launches after the timed region'}
     except Exception as e:      # never lose the record over a side measurement
         return {'error': f'{type(e).__name__}: {e}'}
+
+
+def in_stack_attention(net, B, dev):
+    """The attention phase INSIDE the encoder-stack launch, measured by the kernel's own phase stamps right after the timed region
+    (rohm_amd/stack_timeline.py: lane 0 of every workgroup writes the 100 MHz wall clock at every seam of a few stamped launches).
+    Falls back to the stand-alone kernel where no stack launch exists (B < 32, plane modes, a refused layout)."""
+    try:
+        from rohm_amd import stack_timeline
+        rec = stack_timeline.measure(net, B, reps=4, device=dev)
+        if 'error' in rec:
+            raise RuntimeError(rec['error'])
+        out = dict(rec['attention_in_stack'])
+        out['avg_launch_us'] = out['us_per_launch']
+        out['stack_phases'] = rec['phases']
+        out['stack_launch_span_us'] = rec['launch_span_us']
+        out['meetings_share_of_launch'] = rec['meetings_share_of_launch']
+        return out
+    except Exception as e:      # diagnostics must never cost the record
+        sa = standalone_attention(B, dev)
+        sa['in_stack_error'] = repr(e)[:200]
+        return sa
 
 
 def exchange_note(net):
@@ -930,7 +954,9 @@ def main(argv=None):
                                'frac': prof['attention']['flops'] / (prof['attention']['total_ms'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                'avg_launch_us': prof['attention']['total_ms'] / prof['attention']['launches'] * 1e3,
                                'unit': 'TFLOP/s', 'peak': PEAK_F32_MFMA_TFLOPS}
-                              if prof.get('attention', {}).get('total_ms') else standalone_attention(B, dev)),
+                              if prof.get('attention', {}).get('total_ms') else in_stack_attention(net, B, dev)),
+                # ... and the stand-alone attention kernel (the launch shape of the launch-per-GEMM path) for comparison
+                'attention_standalone': (None if prof.get('attention', {}).get('total_ms') or _PRODUCTS else standalone_attention(B, dev)),
                 # the dominant kernel on its own (VERDICT convention: algorithmic flops per launch / average launch duration)
                 'dominant': ({'kernel': 'encoder_stack_kernel (label gemm_stack: the whole encoder of one denoising step)',
                               'launches_timed': prof['gemm_stack']['launches'],

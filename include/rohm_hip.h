@@ -269,6 +269,16 @@ int rohm_posenet_set_exchange(rohm_posenet_t* h, int on);
 /* Test hook: the next `n_launches` LayerNorm-carrying GEMM launches of this handle publish one column tile's statistics under a
  * wrong tag, so its partners' waits expire (~0.2 s, once) and the error word is set -- a real failed exchange for the fallback tests. */
 int rohm_posenet_inject_exchange_fault(rohm_posenet_t* h, int n_launches);
+/* Diagnostics: phase timeline of the encoder stack (the one launch that carries nn.TransformerEncoder, model/posenet.py:63-69,92, from
+ * 32 clips on).  With a device buffer of rohm_posenet_stack_timeline_bytes(B) bytes set, lane 0 of every workgroup of the following
+ * stack launches of this handle (forwards / loop steps at batch size <= B) writes the 100 MHz wall clock at the seams of its phases:
+ * buf[(block * 9 + layer) * 12 + k], k = 0 layer entered, 1 qkv of the clip complete (attention starts), 2 attention done, 3 ctx
+ * complete, 4 out-projection + norm1 done, 5 met, 6 linear1 + GELU done, 7 met, 8 linear2 + norm2 done, 9 met, 10 next layer's
+ * in-projection done; layer 8 = the leading phases (0 entered, 1 embedding done, 2 met, 3 in-projection of layer 0 done, 4 met).
+ * Every launch overwrites the stamps.  buf = NULL switches it off (the default; the kernels then pay one scalar test per seam).
+ * scripts/stack_timeline.py turns the stamps into per-phase spans and the in-stack attention rate (bench.py roofline.attention). */
+size_t rohm_posenet_stack_timeline_bytes(int B);
+int rohm_posenet_set_stack_timeline(rohm_posenet_t* h, void* buf, size_t bytes, int B);
 
 /* Device-resident DDPM loop without guidance: p_sample_loop over `n_steps` descending timesteps
  * (diffusion/gaussian_diffusion_posenet.py:578-662, 388-434).

@@ -97,6 +97,8 @@ SIGNATURES = {
     'rohm_posenet_exchange_guard': (C.c_char_p, [C.c_void_p]),
     'rohm_posenet_set_exchange': (C.c_int, [C.c_void_p, C.c_int]),
     'rohm_posenet_inject_exchange_fault': (C.c_int, [C.c_void_p, C.c_int]),
+    'rohm_posenet_stack_timeline_bytes': (C.c_size_t, [C.c_int]),
+    'rohm_posenet_set_stack_timeline': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     'rohm_output_process_scratch_bytes': (C.c_size_t, []),
     'rohm_output_process_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'rohm_output_process_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -155,7 +157,12 @@ def lib():
                 f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
                 f'Build it with `python -m rohm_amd.build` (needs hipcc, --offload-arch=gfx950).')
         handle = C.CDLL(LIB_PATH)
+        # the shipped library must export every declared symbol; an experiment library selected through ROHM_HIP_LIB (same-box A/B
+        # runs against an older tree, scripts/build_variant.py) may lack the newest ones -- they then fail where they are used
+        strict = not os.environ.get('ROHM_HIP_LIB')
         for name, (res, args) in SIGNATURES.items():
+            if not strict and not hasattr(handle, name):
+                continue
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args

@@ -218,7 +218,15 @@ struct StackParams {
     int front;
     const float* apack; int lda_pack; const float* w_embed; int ldw_embed; int k_embed;
     int S; const float* tab; const float* tab0; int ldtab, ldtab0, tab_by_row;
+    // Diagnostics (null on every product path): when set, lane 0 of every workgroup stamps the 100 MHz wall clock (s_memrealtime) at the
+    // seams of its phases into timeline[(block * kStackTimelineLayers + layer) * kStackTimelineStamps + k]
+    // (rohm_posenet_set_stack_timeline; scripts/stack_timeline.py turns the stamps into per-phase spans and the in-stack attention rate).
+    unsigned long long* timeline;
 };
+// stamps of one layer: 0 layer entered, 1 qkv complete (attention starts), 2 attention done, 3 ctx complete (out-projection starts),
+// 4 out-projection + norm1 done, 5 y complete, 6 linear1 + GELU done, 7 ff complete, 8 linear2 + norm2 done, 9 h complete,
+// 10 next in-projection done; "layer" 8 = the leading phases: 0 entered, 1 embed done, 2 h complete, 3 in-projection of layer 0 done, 4 met
+constexpr int kStackTimelineLayers = 9, kStackTimelineStamps = 12;
 int launch_encoder_stack(const StackParams& p, hipStream_t s);
 int encoder_chain_parts(int M, int D, int F);      // column tiles per clip (4 or 8), 0 = no chain form for this shape
 size_t encoder_chain_flag_bytes(int M);

@@ -641,6 +641,11 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
     a.row_stats = p.xln_stats + ((size_t)g * G * BM) * 4;
     a.eps = p.ln_eps; a.ln_dim = p.D;
     a.qcols = p.D; a.qscale = p.qscale;
+    // diagnostics only (p.timeline is null on every product path: one scalar test per seam)
+    unsigned long long* const tl = p.timeline ? p.timeline + (size_t)blockIdx.x * kStackTimelineLayers * kStackTimelineStamps : nullptr;
+    auto stamp = [&](int layer, int k) __attribute__((always_inline)) {
+        if (tl != nullptr && threadIdx.x == 0) tl[layer * kStackTimelineStamps + k] = __builtin_amdgcn_s_memrealtime();
+    };
     if (p.front) {
         // ---- E: h = [x_t | cond] . We^T + table rows;  D0: qkv = in_proj_0(h) -- flags of "layer" 8 ------------------------------------
         int tid = tid0;
@@ -649,12 +654,17 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
         unsigned long long* const fl = p.flags + ((size_t)g * 9 + 8) * 5 * 8;
         a.A = p.apack; a.lda = p.lda_pack; a.W = p.w_embed; a.ldw = p.ldw_embed; a.C = p.h; a.ldc = p.D; a.K = p.k_embed; a.n0 = tn * BNL;
         a.S = p.S; a.tab = p.tab; a.tab0 = p.tab0; a.ldtab = p.ldtab; a.ldtab0 = p.ldtab0; a.tab_by_row = p.tab_by_row;
+        stamp(8, 0);
         gemm_phase<BNL, EPI_EMBED, false, false, G == 8>(a, smem, tid, [&]() { prefetch_w<BNQ>(p.layer[0].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+        stamp(8, 1);
         group_sync(fl, tn, G, ep, xcc1, p.xln_err, tid);
+        stamp(8, 2);
         a.A = p.h; a.lda = p.D; a.W = p.layer[0].in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.layer[0].in_b;
         a.n0 = tn * BNQ;
         gemm_phase<BNQ, EPI_QKV, true, true, G == 8>(a, smem, tid, []() {});
+        stamp(8, 3);
         group_sync(fl + 8, tn, G, ep, xcc1, p.xln_err, tid);
+        stamp(8, 4);
     }
 #pragma unroll 1
     for (int l = 0; l < p.L; ++l) {
@@ -666,32 +676,43 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
         const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
         const StackLayerW& w = p.layer[l];
         unsigned long long* const fl = p.flags + ((size_t)g * 9 + l) * 5 * 8;
+        stamp(l, 0);
         if (l > 0) group_sync(fl, tn, G, ep, xcc1, p.xln_err, tid);                  // the clip's qkv of this layer is complete
+        stamp(l, 1);
         if constexpr (G == 4) attention_item<4, 0, kSc1, 2>(p.qkv, p.ctx, p.n_head, g * p.n_head + tn, 0, AT_NB, smem, tid);
         else attention_item<4, 0, kSc1, 1>(p.qkv, p.ctx, p.n_head, g * p.n_head + (tn >> 1), (tn & 1) ? 5 : 0, (tn & 1) ? 4 : 5, smem, tid);
+        stamp(l, 2);
         group_sync(fl + 8, tn, G, ep, xcc1, p.xln_err, tid);                         // ... its ctx
+        stamp(l, 3);
 
         a.A = p.ctx; a.lda = p.D; a.W = w.out_w; a.ldw = p.D; a.C = p.y; a.ldc = p.D; a.K = p.D; a.bias = w.out_b;
         a.R = p.h; a.ldr = p.D; a.gamma = w.n1_w; a.beta = w.n1_b; a.n0 = tn * BNL; a.tag28 = (ep + 4u * l) & 0x0fffffffu;
         a.fault = (l == 0) ? (p.fault & 1) : 0;
         gemm_phase<BNL, EPI_BIAS_RES_LN, false, true, G == 8>(a, smem, tid, [&]() { prefetch_w<BNF>(w.l1_w, p.D, tn * BNF, smem, tid, wave_u); });
+        stamp(l, 4);
         group_sync(fl + 16, tn, G, ep, xcc1, p.xln_err, tid);
+        stamp(l, 5);
 
         a.A = p.y; a.lda = p.D; a.W = w.l1_w; a.ldw = p.D; a.C = p.ff; a.ldc = p.F; a.K = p.D; a.bias = w.l1_b; a.n0 = tn * BNF;
         gemm_phase<BNF, EPI_BIAS_GELU, true, true, G == 8>(a, smem, tid, [&]() { prefetch_w<BNL>(w.l2_w, p.F, tn * BNL, smem, tid, wave_u); });
+        stamp(l, 6);
         group_sync(fl + 24, tn, G, ep, xcc1, p.xln_err, tid);
+        stamp(l, 7);
 
         const bool more = l + 1 < p.L;
         a.A = p.ff; a.lda = p.F; a.W = w.l2_w; a.ldw = p.F; a.C = p.h; a.ldc = p.D; a.K = p.F; a.bias = w.l2_b;
         a.R = p.y; a.ldr = p.D; a.gamma = w.n2_w; a.beta = w.n2_b; a.n0 = tn * BNL; a.tag28 = (ep + 4u * l + 1u) & 0x0fffffffu;
         a.fault = (l == 0) ? ((p.fault >> 1) & 1) : 0;
         gemm_phase<BNL, EPI_BIAS_RES_LN, true, true, G == 8>(a, smem, tid, [&]() { if (more) prefetch_w<BNQ>(p.layer[l + 1].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
+        stamp(l, 8);
         if (!more) break;
         group_sync(fl + 32, tn, G, ep, xcc1, p.xln_err, tid);
+        stamp(l, 9);
 
         a.A = p.h; a.lda = p.D; a.W = p.layer[l + 1].in_w; a.ldw = p.D; a.C = p.qkv; a.ldc = 3 * p.D; a.K = p.D; a.bias = p.layer[l + 1].in_b;
         a.n0 = tn * BNQ;
         gemm_phase<BNQ, EPI_QKV, true, true, G == 8>(a, smem, tid, []() {});
+        stamp(l, 10);
     }
 }
 

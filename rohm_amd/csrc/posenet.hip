@@ -75,6 +75,7 @@ struct rohm_posenet {
     const char* exch_reason;              // why the guard refused (static string), or what it saw
     unsigned salt;                        // host part of this handle's launch tags
     mutable int fault_left;               // test hook (rohm_posenet_inject_exchange_fault): LayerNorm launches still to sabotage
+    unsigned long long* stack_timeline;   // diagnostics (rohm_posenet_set_stack_timeline): phase stamps of the next stack launches, or null
     int nplane;                           // 0: exact fp32 MFMA (default); 3 / 2 / 16: split GEMMs on planes (bf16x6 / bf16x3 / fp16x3)
     char* wplanes;                        // one allocation holding the weight planes of every layer
     bool pp_fold;                         // plane modes: LayerNorm folded into the plane GEMMs (ROHM_PP_LNFOLD=1, two-plane modes)
@@ -477,6 +478,7 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         c.epoch = p->salt;
         c.flags = reinterpret_cast<unsigned long long*>(w.chain_flags);
         if (p->fault_left > 0) { --p->fault_left; c.fault = 1; }
+        c.timeline = p->stack_timeline;
         if ((rc = launch_encoder_stack(c, s))) return rc;
     }
     const float qscale = qscale_of(p);
@@ -697,6 +699,7 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         p->ln_fused_env = p->ln_fused; p->head_sk_env = p->head_sk;
         p->exch_fallback = false;
         p->fault_left = 0;
+        p->stack_timeline = nullptr;
         p->exch_reason = "not asked for";
         p->exch_allowed = (p->ln_fused || p->head_sk) && 2 * n_layer + 1 <= 60 && exchange_layout_ok(device, &p->exch_reason);
         if (!p->exch_allowed) p->ln_fused = p->head_sk = false;
@@ -907,6 +910,19 @@ int rohm_posenet_set_exchange(rohm_posenet_t* h, int on) {
         h->exch_fallback = h->ln_fused || h->head_sk || h->exch_fallback;
         h->ln_fused = h->head_sk = false;
     }
+    return ROHM_OK;
+}
+
+size_t rohm_posenet_stack_timeline_bytes(int B) {
+    const int groups8 = (B + kNumXCD - 1) / kNumXCD * kNumXCD;
+    return B > 0 ? (size_t)groups8 * 8 * kStackTimelineLayers * kStackTimelineStamps * sizeof(unsigned long long) : 0;
+}
+
+int rohm_posenet_set_stack_timeline(rohm_posenet_t* h, void* buf, size_t bytes, int B) {
+    ROHM_ARG_CHECK(h != nullptr, "posenet_set_stack_timeline: null handle");
+    ROHM_ARG_CHECK(buf == nullptr || (B > 0 && bytes >= rohm_posenet_stack_timeline_bytes(B) && (((uintptr_t)buf) & 7) == 0),
+                   "posenet_set_stack_timeline: buffer too small for %d clips / misaligned", B);
+    h->stack_timeline = static_cast<unsigned long long*>(buf);
     return ROHM_OK;
 }
 
