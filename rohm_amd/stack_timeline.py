@@ -58,7 +58,7 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
             e1.record()
             torch.cuda.synchronize(dev)
             wall.append(e0.elapsed_time(e1) * 1e3 / 2)
-            recs.append(buf.cpu().numpy().reshape(groups8 * G, LAYERS, STAMPS).astype(np.float64) * TICK_US)
+            recs.append(buf.cpu().numpy().reshape(-1, LAYERS, STAMPS)[:groups8 * G].astype(np.float64) * TICK_US)      # sized for 8 parts per clip
     finally:
         check(lib().rohm_posenet_set_stack_timeline(nat.handle, None, 0, 0), 'rohm_posenet_set_stack_timeline')
     net.check_exchange()
