@@ -458,6 +458,7 @@ def scheme_bench(args, world, rank, dev, dist):
     elapsed, out, prof = timed_region(one_pass, args, world, dev, dist, drain=gather.drain)
     finite = bool(torch.isfinite(out).all())
     assert finite, 'non-finite samples'
+    report = rank_report(args, world, rank, dev, dist, gather, pnet)
     if rank == 0:
         clips = world * B * args.steps
         all_ms = sum(v['total_ms'] for v in prof.values())
@@ -481,6 +482,7 @@ def scheme_bench(args, world, rank, dev, dist):
                             'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': None,
                             'launches_timed': g_n, 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
                             'kernels': kernels}}
+        rec['rank_report'] = report
         if world == 1 and not args.no_cpu_baseline:
             try:
                 rec['cpu_baseline'] = cpu_baseline_config(args.workload, B)
@@ -817,18 +819,64 @@ def timed_region(one_pass, args, world, dev, dist, profile=True, drain=None):
     if profile and dev.type == 'cuda':
         from rohm_amd import _lib
         _lib.profile_start(args.profile_stride)
+    gobj = getattr(drain, '__self__', None)          # the ResultGather whose collective waits are NOT this rank's own time
+    drained0 = getattr(gobj, 'drain_s', 0.0)
     t0 = time.perf_counter()
+    enqueue = []
     for _ in range(args.steps):
+        tp, d0 = time.perf_counter(), getattr(gobj, 'drain_s', 0.0)
         out = one_pass()
+        enqueue.append(time.perf_counter() - tp - (getattr(gobj, 'drain_s', 0.0) - d0))
+    t_loop = time.perf_counter() - t0
+    if dev.type == 'cuda':      # this rank's OWN compute: an event on the compute stream (a device-wide synchronize would also wait
+        ev = torch.cuda.Event()      # for the all-gather in flight on RCCL's stream, i.e. for the slowest peer)
+        ev.record()
+        ev.synchronize()
+    own_done = time.perf_counter() - t0
+    own = own_done - (getattr(gobj, 'drain_s', 0.0) - drained0)          # ... minus the time its passes spent inside collectives
     sync()
     elapsed = time.perf_counter() - t0
     if profile and dev.type == 'cuda':
         prof = _lib.profile_stop()
+    # what this rank saw (rank_report gathers it): its own time for the K passes, how long the host needed to enqueue a pass (the
+    # TrajNet loops are host-bound: eight ranks on shared cores show up here first) and how long it then waited for the slowest rank
+    args.rank_timing = {'own_ms_per_step': own / args.steps * 1e3, 'host_enqueue_ms_per_step': sum(enqueue) / args.steps * 1e3,
+                        'host_loop_ms_per_step': t_loop / args.steps * 1e3, 'wait_for_slowest_ms': (elapsed - own) * 1e3}
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, out, prof
+
+
+def rank_report(args, world, rank, dev, dist, gather=None, net=None):
+    """Per-rank diagnostics of a multi-rank run, gathered to rank 0 (None on the others; a one-entry list at world size 1): own
+    ms_per_step (before the MAX over ranks), host enqueue time per pass, time spent draining the result all-gather, the wait for the
+    slowest rank, which launch forms the PoseNet handle ended with and what the layout guard said, the CPU binding, the device.  The
+    first 8-GPU run of this code has to be diagnosable from its one JSON line: which rank was slow, whether a rank fell back to the
+    exchange-free launches, whether the host or the device was the straggler."""
+    me = {'rank': rank, 'device': str(dev), **getattr(args, 'rank_timing', {}), 'cpu_binding': getattr(args, 'cpu_binding', None)}
+    if gather is not None:
+        me['allgather_drain_ms_per_step'] = gather.drain_s / max(1, gather.drains) * 1e3
+        me['allgather_drains'] = gather.drains
+    if net is not None:
+        me['exchange_mode'] = exchange_note(net)
+    if dev.type == 'cuda':
+        try:
+            me['gpu'] = torch.cuda.get_device_name(dev)
+        except Exception:
+            pass
+    if dist is None or world == 1:
+        ranks = [me]
+    else:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    if rank != 0:
+        return None
+    own = [r['own_ms_per_step'] for r in ranks if r and 'own_ms_per_step' in r]
+    skew = ({'max_own_ms_per_step': max(own), 'min_own_ms_per_step': min(own), 'skew_frac': (max(own) - min(own)) / max(own),
+             'slowest_rank': int(max(range(len(own)), key=lambda i: own[i]))} if own else None)
+    return {'ranks': ranks, 'skew': skew}
 
 
 class ResultGather:
@@ -840,6 +888,7 @@ class ResultGather:
 
     def __init__(self, n_total, dist):
         self.n_total, self.dist, self.pending, self.last = n_total, dist, None, None
+        self.drain_s, self.drains = 0.0, 0          # host time spent completing the collective (rank_report)
 
     def submit(self, x0):
         from rohm_amd import sharding
@@ -850,8 +899,11 @@ class ResultGather:
 
     def drain(self):
         if self.pending is not None:
+            t0 = time.perf_counter()
             self.last = self.pending.result()
             self.pending = None
+            self.drain_s += time.perf_counter() - t0
+            self.drains += 1
 
 
 def finish(world, dist):
@@ -878,6 +930,7 @@ def selftest_bench(args, world, rank, dev, dist):
     elapsed, out, _ = timed_region(one_pass, args, world, dev, dist, profile=False, drain=gather.drain)
     if world > 1:
         out = gather.last
+    report = rank_report(args, world, rank, dev, dist if world > 1 else None, gather)
     if rank == 0:
         ranks_seen = sorted(set(int(v) for v in out[:, 0].tolist()))
         # what the measuring path would call this launch (same helper functions), so that a dry run of e.g.
@@ -887,7 +940,7 @@ def selftest_bench(args, world, rank, dev, dist):
         print(json.dumps({'metric': 'bench launcher self-test (NOT a measurement: stub sampler on CPU/gloo)', 'value': 0.0,
                           'unit': 'none', 'n_gpus': world, 'world_size': world, 'backend': 'gloo', 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'data': 'selftest-stub',
-                          'gathered_clips': int(out.shape[0]), 'ranks_seen': ranks_seen,
+                          'gathered_clips': int(out.shape[0]), 'ranks_seen': ranks_seen, 'rank_report': report,
                           'config': {'workload': 'selftest', 'stands_for_metric': stands_for[0], 'stands_for_workload': stands_for[1],
                                      'clips_per_gpu': B, 'sharding': sharding_note(args, world, B, dist),
                                      'cpu_binding': args.cpu_binding}}), flush=True)
@@ -989,6 +1042,7 @@ def main(argv=None):
     elapsed, out, prof = timed_region(one_pass, args, world, dev, dist, drain=gather.drain)
     finite = bool(torch.isfinite(out).all())
     assert finite, 'non-finite samples'
+    report = rank_report(args, world, rank, dev, dist, gather, net)
 
     if rank == 0:
         clips = world * B * args.steps
@@ -1090,6 +1144,7 @@ def main(argv=None):
                 'kernels': kernels,
             },
         }
+        rec['rank_report'] = report
         if dist is not None:
             rec['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'forced': bool(args.force_dist)}
         if world == 1 and not args.no_cpu_baseline and not prox:

@@ -46,6 +46,18 @@ def test_gpus_4_and_8_spawn_that_many_ranks(world):
     assert rec['n_gpus'] == world and rec['world_size'] == world and rec['ranks_seen'] == list(range(world))
     assert rec['gathered_clips'] == 2 * world
     assert rec['ms_per_step'] >= 10.0 * world - 1.0          # MAX over ranks: the last rank sleeps 10 ms x world per pass
+    # round 6: the first multi-GPU run must be diagnosable from its one line -- every rank reports its OWN time per pass, the host
+    # time to enqueue a pass, the all-gather drain, its wait for the slowest rank and its CPU binding; rank 0 adds the skew
+    rep = rec['rank_report']
+    assert [r['rank'] for r in rep['ranks']] == list(range(world))
+    for r in rep['ranks']:
+        assert {'own_ms_per_step', 'host_enqueue_ms_per_step', 'wait_for_slowest_ms', 'allgather_drain_ms_per_step', 'cpu_binding',
+                'device'} <= set(r)
+        assert r['own_ms_per_step'] >= 10.0 * (r['rank'] + 1) - 1.0          # rank r sleeps 10 ms x (r + 1) per pass
+    sk = rep['skew']
+    assert sk['slowest_rank'] == world - 1 and sk['max_own_ms_per_step'] >= sk['min_own_ms_per_step'] and 0.0 < sk['skew_frac'] < 1.0
+    assert rep['ranks'][0]['wait_for_slowest_ms'] >= rep['ranks'][world - 1]['wait_for_slowest_ms'] - 2.0      # the fast rank waits longest
+    assert rep['ranks'][0]['allgather_drain_ms_per_step'] >= rep['ranks'][world - 1]['allgather_drain_ms_per_step'] - 2.0
 
 
 @pytest.mark.parametrize('workload,world,cfg', [('scheme', 8, 'configs[2]'), ('egobody', 4, 'configs[4]')])
