@@ -222,10 +222,22 @@ struct StackParams {
     // seams of its phases into timeline[(block * kStackTimelineLayers + layer) * kStackTimelineStamps + k]
     // (rohm_posenet_set_stack_timeline; scripts/stack_timeline.py turns the stamps into per-phase spans and the in-stack attention rate).
     unsigned long long* timeline;
+    // tail != 0 (sampling loop, single-round launches only): the launch does not end with the encoder's output but carries on, per clip,
+    // with OutputProcess (model/heads.py:171-176: x0[:, traj:] = h . Wout^T + bout, x0[:, :traj] = cond[:, :traj], model/posenet.py:94-96),
+    // the ancestral update x_prev = c1 x0 + c2 x_t + sigma noise (gaussian_diffusion_posenet.py:212-234,426-434) written over x in place,
+    // and the x_t half of the NEXT step's token-major pack -- one launch per denoising step.  The 17 x 9 (16 x 16) output blocks of a
+    // clip are dealt to the 16 / 32 waves of its workgroups (<= 10 / 5 blocks per wave).
+    int tail;
+    const float* t_out_w; const float* t_out_b;      // [c_out, D], [c_out]
+    float* t_x; const float* t_cond; const float* t_noise;      // [B, C, 1, T]; noise may be null (sigma == 0)
+    float* t_x0; float* t_apack;                     // optional outputs: x0 [B, C, 1, T]; the next step's pack [M, t_lda] (x_t columns)
+    float t_c1, t_c2, t_sigma;
+    int t_traj, t_C, t_T, t_lda;
+    unsigned* t_pass_ctr;                            // advanced by one thread at the very end (= the first kernel of the next pass would)
 };
 // stamps of one layer: 0 layer entered, 1 qkv complete (attention starts), 2 attention done, 3 ctx complete (out-projection starts),
 // 4 out-projection + norm1 done, 5 y complete, 6 linear1 + GELU done, 7 ff complete, 8 linear2 + norm2 done, 9 h complete,
-// 10 next in-projection done; "layer" 8 = the leading phases: 0 entered, 1 embed done, 2 h complete, 3 in-projection of layer 0 done, 4 met
+// 10 next in-projection done (layer 7 with a tail: 9 h complete, 10 head + update + pack done); "layer" 8 = the leading phases: 0 entered, 1 embed done, 2 h complete, 3 in-projection of layer 0 done, 4 met
 constexpr int kStackTimelineLayers = 9, kStackTimelineStamps = 12;
 int launch_encoder_stack(const StackParams& p, hipStream_t s);
 int encoder_chain_parts(int M, int D, int F);      // column tiles per clip (4 or 8), 0 = no chain form for this shape

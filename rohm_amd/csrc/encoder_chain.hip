@@ -568,6 +568,147 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
     }
 }
 
+// The stack's closing phase in the sampling loop (StackParams::tail): OutputProcess + DDPM update + the next step's pack for clip g.
+// out^T is not formed: the MFMAs take the TOKENS on their row side, so a lane ends with four consecutive tokens of one channel --
+// contiguous in the [B, C, 1, T] tensors that x_t, the noise, x_prev and x0 live in.  Work split: the clip's 17 column blocks (272
+// channels) x 9 row blocks of 16 x 16 outputs; every wave owns one column block over 9 (G = 4) or 5 / 4 (G = 8) row blocks, and the
+// 17th column block's nine blocks go one each to the waves with the lightest load -- at most 10 (5) blocks per wave.  Staging like
+// gemm_phase (h by sc1 LDS-DMA: the partners wrote it in this launch), a plain two-barrier double-buffered loop: the phase is ~1 %
+// of the launch.
+template <int G>
+__device__ __forceinline__ void head_tail_phase(const StackParams& p, const int g, const int tn, float* smem, const int tid) {
+    constexpr int NC_OWN = 16 / G;                 // own column blocks of this workgroup
+    constexpr int NW = NC_OWN * 16 + 16;           // weight rows staged per chunk: own + the shared 17th block
+    constexpr int NRMAX = (G == 4) ? 9 : 5;
+    constexpr int W_UNITS = NW * 8, W_ITERS = (W_UNITS + 255) / 256;
+    constexpr int PIECES = A_ITERS + W_ITERS;
+    float* As = smem;
+    float* Bs = smem + 2 * BM * BK;
+    float* lds_dummy = smem + kZone;
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_u = wave * 64;
+    const int D = p.D, m0 = g * BM;
+    int c_loc, r0, nr, e;
+    if constexpr (G == 4) { c_loc = wave; r0 = 0; nr = 9; e = tn * 4 + wave; }
+    else { c_loc = wave >> 1; r0 = (wave & 1) ? 5 : 0; nr = (wave & 1) ? 4 : 5; e = (wave & 1) ? tn * 2 + (wave >> 1) : 99; }
+    const bool has_e = e < NRB;
+
+    const float* a_src[A_ITERS];
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int u = tid + i * 256;
+        const int row = (u < A_UNITS) ? (u >> 3) : 0;
+        const int slot = (u & 7) ^ ((row >> 1) & 7);
+        a_src[i] = p.h + (size_t)(m0 + row) * D + slot * 4;
+    }
+    const float* w_src[W_ITERS];
+#pragma unroll
+    for (int i = 0; i < W_ITERS; ++i) {
+        const int u = tid + i * 256;
+        const int lrow = (u < W_UNITS) ? (u >> 3) : 0;
+        const int slot = (u & 7) ^ ((lrow >> 1) & 7);
+        const int grow = (lrow < NC_OWN * 16) ? tn * NC_OWN * 16 + lrow : 256 + (lrow - NC_OWN * 16);
+        w_src[i] = p.t_out_w + (size_t)grow * D + slot * 4;
+    }
+    auto dma = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            float* dst = As + buf * (BM * BK) + (i * 256 + wave_u) * 4;
+            if (i == A_ITERS - 1 && A_UNITS % 256 != 0)
+                dst = (wave_u < A_UNITS - (A_ITERS - 1) * 256) ? dst : lds_dummy + (wave_u & 64) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, kSc1);
+        }
+#pragma unroll
+        for (int i = 0; i < W_ITERS; ++i) {
+            float* dst = Bs + buf * (NW * BK) + (i * 256 + wave_u) * 4;
+            if (i == W_ITERS - 1 && W_UNITS % 256 != 0)
+                dst = (wave_u < W_UNITS - (W_ITERS - 1) * 256) ? dst : lds_dummy + (wave_u & 64) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[NRMAX], acc_e = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NRMAX; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = D / BK;
+    dma(0, 0);
+    dma(1, BK);
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        // chunk kc has landed once at most the pieces of chunk kc + 1 are outstanding (loads retire in order)
+        if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* as = As + buf * (BM * BK);
+        const float* ws = Bs + buf * (NW * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ks * 4 + lg;
+            const f32x4 w_own = *reinterpret_cast<const f32x4*>(ws + lds_off(c_loc * 16 + li, slot));
+#pragma unroll
+            for (int r = 0; r < NRMAX; ++r) {
+                if (r < nr) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(as + lds_off((r0 + r) * 16 + li, slot));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w_own[j], acc[r], 0, 0, 0);
+                }
+            }
+            if (has_e) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(as + lds_off(e * 16 + li, slot));
+                const f32x4 w_sh = *reinterpret_cast<const f32x4*>(ws + lds_off(NC_OWN * 16 + li, slot));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc_e = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w_sh[j], acc_e, 0, 0, 0);
+            }
+        }
+        __syncthreads();                               // every wave is done with this buffer
+        if (kc + 2 < nk) dma(buf, (kc + 2) * BK);
+    }
+
+    // ---- epilogue: bias, x0, the ancestral update in place, the next step's pack -------------------------------------------------
+    const int C = p.t_C, T = p.t_T, traj = p.t_traj, S = BM;
+    const float c1 = p.t_c1, c2 = p.t_c2, sg = p.t_sigma;
+    float* const x = p.t_x;
+    const float* const nzp = p.t_noise;
+    float* const x0o = p.t_x0;
+    float* const apk = p.t_apack;
+    auto emit = [&](int rblk, int cblk, const f32x4& a) __attribute__((always_inline)) {
+        const int ch = cblk * 16 + li;                 // 0 .. 271
+        const float bias = p.t_out_b[ch];
+        const size_t row = ((size_t)g * C + traj + ch) * T;
+        const int tok0 = rblk * 16 + 4 * lg;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int tok = tok0 + v;
+            if (tok == 0) continue;                    // the timestep token has no output
+            const size_t idx = row + (size_t)(tok - 1);
+            const float val = a[v] + bias;
+            if (x0o) x0o[idx] = val;
+            float o = c1 * val + c2 * x[idx];
+            if (nzp) o += sg * nzp[idx];
+            x[idx] = o;
+            if (apk) apk[((size_t)g * S + tok) * p.t_lda + traj + ch] = o;
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < NRMAX; ++r)
+        if (r < nr) emit(r0 + r, tn * NC_OWN + c_loc, acc[r]);
+    if (has_e) emit(e, 16, acc_e);
+    // trajectory channels: x0 = cond there (model/posenet.py:94-95); the clip's traj x T elements are dealt over its G workgroups
+    for (int i = tn * 256 + tid; i < traj * T; i += G * 256) {
+        const int ch = i / T, t = i - ch * T;
+        const size_t idx = ((size_t)g * C + ch) * T + t;
+        const float val = p.t_cond[idx];
+        if (x0o) x0o[idx] = val;
+        float o = c1 * val + c2 * x[idx];
+        if (nzp) o += sg * nzp[idx];
+        x[idx] = o;
+        if (apk) apk[((size_t)g * S + t + 1) * p.t_lda + ch] = o;
+    }
+}
+
 }  // namespace chain
 
 // G = column tiles per clip of every phase = partner workgroups of a clip: 4 (B = 64: tiles 144 x 128 / 256 / 128 / 384) or 8 (B = 32:
@@ -705,7 +846,17 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
         a.fault = (l == 0) ? ((p.fault >> 1) & 1) : 0;
         gemm_phase<BNL, EPI_BIAS_RES_LN, true, true, G == 8>(a, smem, tid, [&]() { if (more) prefetch_w<BNQ>(p.layer[l + 1].in_w, p.D, tn * BNQ, smem, tid, wave_u); });
         stamp(l, 8);
-        if (!more) break;
+        if (!more) {
+            if (p.tail) {      // sampling loop: head + DDPM update + the next step's pack close the launch (uniform over the launch)
+                group_sync(fl + 32, tn, G, ep, xcc1, p.xln_err, tid);                // the clip's h is complete
+                stamp(l, 9);
+                head_tail_phase<G>(p, g, tn, smem, tid);
+                stamp(l, 10);
+                // the next pass's tags: every workgroup of this (single-round) launch read the counter when it started, long ago
+                if (p.t_pass_ctr != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *p.t_pass_ctr += 1u;
+            }
+            break;
+        }
         group_sync(fl + 32, tn, G, ep, xcc1, p.xln_err, tid);
         stamp(l, 9);
 
@@ -727,6 +878,9 @@ int launch_encoder_stack(const StackParams& p, hipStream_t s) {
     StackParams q = p;
     q.tiles_m = p.M / chain::BM;
     const int groups8 = (q.tiles_m + kNumXCD - 1) / kNumXCD * kNumXCD;
+    ROHM_ARG_CHECK(!p.tail || (groups8 * G <= 256 && p.D == 512 && p.t_out_w && p.t_out_b && p.t_x && p.t_cond && p.t_C - p.t_traj == 272 &&
+                               p.t_T == chain::BM - 1 && p.t_traj > 0 && (!p.t_apack || p.t_lda >= p.t_C)),
+                   "encoder_stack: the closing head / update / pack phase needs a single-round launch of whole 144-token clips, 272 predicted channels");
     constexpr int kFloats = AT_LDS_FLOATS > chain::kLdsFloats ? AT_LDS_FLOATS : chain::kLdsFloats;
     const size_t lds = (size_t)kFloats * sizeof(float);
     static bool attr_set[64][2] = {};
@@ -742,7 +896,8 @@ int launch_encoder_stack(const StackParams& p, hipStream_t s) {
     const double flops = L * (4.0 * 144.0 * 128.0 * MM * p.n_head + 2.0 * MM * (D * D + 2.0 * D * F)) + (L - 1.0 + (p.front ? 1.0 : 0.0)) * 2.0 * MM * 3.0 * D * D +
                          (p.front ? 2.0 * MM * D * p.k_embed : 0.0);
     const double bytes = 4.0 * (L * (MM * (3.0 * D + D + 4.0 * D + 2.0 * F + D) + D * D + 2.0 * D * F) + (L - 1.0) * (MM * 3.0 * D + 3.0 * D * D));
-    prof::Scope ps("gemm_stack", flops, bytes, s);
+    const double tail_flops = p.tail ? 2.0 * MM * D * (p.t_C - p.t_traj) : 0.0;
+    prof::Scope ps(p.tail ? "gemm_stack_tail" : "gemm_stack", flops + tail_flops, bytes, s);
     if (G == 4) hipLaunchKernelGGL(encoder_stack_kernel<4>, dim3(groups8 * 4), dim3(256), lds, s, q);
     else hipLaunchKernelGGL(encoder_stack_kernel<8>, dim3(groups8 * 8), dim3(256), lds, s, q);
     ROHM_LAUNCH_CHECK();

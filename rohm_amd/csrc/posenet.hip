@@ -67,6 +67,9 @@ struct rohm_posenet {
     bool chain_any;                       // chain at every batch size (tests: ROHM_POSENET_CHAIN_ANY=1)
     bool stack_front;                     // stack: input embedding + layer 0's in-projection as leading phases (ROHM_POSENET_STACK_FRONT=0: own launches)
     bool finish_pack;                     // sampling loop: DDPM update + the next step's pack as one kernel (ROHM_POSENET_FINISH_PACK=0: two)
+    bool stack_tail;                      // sampling loop: output head + DDPM update + the next step's pack as the stack's closing phase -- ONE
+                                          // launch per denoising step (single-round launches: B = 64 / 32; ROHM_POSENET_STACK_TAIL=0: head and
+                                          // finish_pack as their own launches)
     int chain;                            // 0: one launch per GEMM; 1: the four GEMMs between two attention launches as ONE launch; 2 (default):
                                           // the whole encoder stack, attention included, as one launch (encoder_chain.hip; both need ln_fused;
                                           // ROHM_POSENET_CHAIN=0 | layer | stack)
@@ -345,9 +348,20 @@ static int check_shape(const rohm_posenet* p, int B, int T) {
 
 static inline float qscale_of(const rohm_posenet* p) { return 1.0f / sqrtf((float)(p->D / p->H)); }
 
-// Network body: from packed input (w.apack complete) to x0 channels [traj, Cin) in `x0_out`.
+// What the sampling loop hands run_network so that a stacked launch can close the step itself (StackParams::tail, common.h).
+struct TailArgs {
+    float* x; const float* cond; const float* noise; float* x0; float* apack_next;
+    float c1, c2, sigma;
+    unsigned* pass_ctr;
+};
+
+// Network body: from packed input (w.apack complete) to x0 channels [traj, Cin) in `x0_out`.  With `tail` (sampling loop) and a launch
+// plan that allows it -- the encoder stack with its leading phases, a single round of workgroups -- the stack launch also runs the
+// output head, the DDPM update and the next step's pack; `*tail_ran` says whether it did (x0_out is then NOT written: tail->x0 is).
 static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t* t_dev, int64_t t_host,
-                       const float* tok_pre, float* x0_out, int B, int T, hipStream_t s, bool cond_done = false) {
+                       const float* tok_pre, float* x0_out, int B, int T, hipStream_t s, bool cond_done = false,
+                       const TailArgs* tail = nullptr, bool* tail_ran = nullptr) {
+    if (tail_ran) *tail_ran = false;
     const int S = T + 1, D = p->D, M = B * S;
     // timestep token(s): per sample from device timesteps, or one precomputed row shared by the batch
     if (!tok_pre) {
@@ -479,7 +493,20 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         c.flags = reinterpret_cast<unsigned long long*>(w.chain_flags);
         if (p->fault_left > 0) { --p->fault_left; c.fault = 1; }
         c.timeline = p->stack_timeline;
+        {
+            const int Gp = encoder_chain_parts(M, D, p->F), groups8 = (B + kNumXCD - 1) / kNumXCD * kNumXCD;
+            if (tail && tail_ran && front && p->stack_tail && groups8 * Gp <= 256 && D == 512 && p->Cout == 272 && !fold) {
+                c.tail = 1;
+                c.t_out_w = p->out_w; c.t_out_b = p->out_b;
+                c.t_x = tail->x; c.t_cond = tail->cond; c.t_noise = tail->sigma == 0.f ? nullptr : tail->noise;
+                c.t_x0 = tail->x0; c.t_apack = tail->apack_next;
+                c.t_c1 = tail->c1; c.t_c2 = tail->c2; c.t_sigma = tail->sigma;
+                c.t_traj = p->traj; c.t_C = p->Cin; c.t_T = T; c.t_lda = p->KP; c.t_pass_ctr = tail->pass_ctr;
+                *tail_ran = true;
+            }
+        }
         if ((rc = launch_encoder_stack(c, s))) return rc;
+        if (c.tail) return ROHM_OK;      // the launch ended with x_prev in x (and the next step's pack): nothing left of the step
     }
     const float qscale = qscale_of(p);
     for (int l = 0; l < ((planes || !chained || stacked) ? 0 : p->L); ++l) {
@@ -696,6 +723,8 @@ int rohm_posenet_create(rohm_posenet_t** out, const rohm_posenet_weights* w, int
         p->stack_front = !(e11 && e11[0] == '0');
         const char* e12 = getenv("ROHM_POSENET_FINISH_PACK");
         p->finish_pack = !(e12 && e12[0] == '0');
+        const char* e13 = getenv("ROHM_POSENET_STACK_TAIL");
+        p->stack_tail = !(e13 && e13[0] == '0');
         p->ln_fused_env = p->ln_fused; p->head_sk_env = p->head_sk;
         p->exch_fallback = false;
         p->fault_left = 0;
@@ -1021,8 +1050,13 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
         // finish_pack (which also advanced the pass counter)
         if ((i == 0 || !h->finish_pack) && (rc = launch_pack(h, x, w.apack, B, T, 0, s, pass_counter(w)))) return rc;
         float* x0 = (x0_last && i == n_steps - 1) ? x0_last : w.x0;
-        if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s, hoist))) return rc;
         const float* nz = noise ? noise + (size_t)i * n : nullptr;
+        // one launch per step where the plan allows (run_network decides): the stack closes with head + update + the next step's pack
+        TailArgs tail{x, cond, nz, (x0_last && i == n_steps - 1) ? x0_last : nullptr, (i + 1 < n_steps) ? w.apack : nullptr,
+                      c1, c2, sigma, pass_counter(w)};
+        bool tail_ran = false;
+        if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s, hoist, h->finish_pack ? &tail : nullptr, &tail_ran))) return rc;
+        if (tail_ran) continue;
         if (i + 1 < n_steps && h->finish_pack) {
             if ((rc = launch_finish_pack(h, x0, cond, x, nz, w.apack, c1, c2, sigma, B, T, pass_counter(w), s))) return rc;
         } else if ((rc = launch_finish(x0, cond, x, nz, x, c1, c2, sigma, h->traj, h->Cin, T, n, s))) {

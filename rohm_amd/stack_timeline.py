@@ -73,21 +73,25 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
     for Tm in recs:
         Tm = Tm[valid]
         front = Tm[:, 8, 0].min() > 0
+        tail = Tm[:, 7, 10].min() > 0          # the launch closes with head + DDPM update + pack (StackParams::tail)
         t0 = Tm[:, 8, 0].min() if front else Tm[:, 0, 0].min()
-        t1 = Tm[:, 7, 8].max()
+        last = Tm[:, 7, 10] if tail else Tm[:, 7, 8]
+        t1 = last.max()
         launch.append(t1 - t0)
         for name, a, b in SPANS:
             tot = 0.0
             for l in range(8):
-                if (name == 'wait_qkv' and l == 0) or (name in ('wait_h', 'in_proj_next') and l == 7):
+                if (name == 'wait_qkv' and l == 0) or (name == 'in_proj_next' and l == 7) or (name == 'wait_h' and l == 7 and not tail):
                     continue
                 tot += float((Tm[:, l, b] - Tm[:, l, a]).mean())
             spans.setdefault(name, []).append(tot)
+        if tail:
+            spans.setdefault('head_update_pack', []).append(float((Tm[:, 7, 10] - Tm[:, 7, 9]).mean()))
         if front:
             for name, a, b in FRONT_SPANS:
                 spans.setdefault(name, []).append(float((Tm[:, 8, b] - Tm[:, 8, a]).mean()))
         # skew: how far apart the workgroups of the launch finish
-        spans.setdefault('finish_skew', []).append(float(Tm[:, 7, 8].max() - Tm[:, 7, 8].min()))
+        spans.setdefault('finish_skew', []).append(float(last.max() - last.min()))
     span = float(np.mean(launch))
     out['launch_span_us'] = span
     out['phases'] = {}
@@ -95,6 +99,9 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
         us = float(np.mean(vals))
         rec = {'us_per_launch': round(us, 2), 'share_of_launch': round(us / span, 4)}
         n_l = 7 if name == 'in_proj_next' else 8
+        if name == 'head_update_pack':
+            tf = 2.0 * B * 144 * 512 * 272 / (us * 1e-6) / 1e12
+            rec.update(tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
         if name in fl:
             tf = fl[name] * n_l / (us * 1e-6) / 1e12
             rec.update(tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4))

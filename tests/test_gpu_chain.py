@@ -157,3 +157,52 @@ def test_a_failed_exchange_inside_the_chain_is_survived(chain, monkeypatch):
         got = run(net)
     assert nat.exchange_mode & 51 == 0 and nat.exchange_mode & 8
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('B', [64, 32])
+def test_one_launch_per_denoising_step_matches_the_three_launch_step(B, monkeypatch):
+    """Round 6: in the sampling loop the stack closes with OutputProcess (model/heads.py:171-176), the ancestral update
+    (gaussian_diffusion_posenet.py:212-234,426-434) and the next step's pack -- ONE `rohm::` kernel per un-guided denoising step at
+    the configs' batch sizes (single-round launches).  Against the same library with ROHM_POSENET_STACK_TAIL=0 (stack + stream-K
+    head + finish_pack): the head sums K in another order, so agreement is to rounding (1e-5 after 7 steps on |x| ~ 4), the returned
+    sample, the last pred_xstart (early_stop) and the input of the last step (batch['x_t']) alike; bit-reproducible; and the launch
+    profiler sees exactly one label per step."""
+    from rohm_amd import _lib
+    steps = 7
+    x_T, noises = cpu_noise_sequence(17, (B, 294, 1, 143), steps)
+    cond = seeded(18, B, 294, 1, 143).to(DEV)
+
+    def run(tail, early_stop, chunk):
+        with monkeypatch.context() as m:
+            m.setenv('ROHM_POSENET_STACK_TAIL', tail)
+            net, _ = make_posenet(9)
+            nat = net.native(torch.device(DEV))
+        if nat.exchange_mode & 32 == 0:
+            pytest.skip(f'no encoder stack on this device: {nat.exchange_guard}')
+        diff = make_diffusion(steps)
+        diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+        diff.fused_chunk = chunk
+        diff._indices = lambda skip=0, early_stop=False: list(range(steps))[::-1]
+        batch = {'cond': cond}
+        _lib.profile_start(1)
+        y = diff.p_sample_loop(net, batch, [B, 294, 1, 143], early_stop=early_stop)
+        torch.cuda.synchronize()
+        prof = _lib.profile_stop()
+        return y.clone(), batch['x_t'].clone(), prof
+
+    for early_stop, chunk in ((False, 50), (True, 3)):
+        want, want_in, prof0 = run('0', early_stop, chunk)
+        got, got_in, prof1 = run('1', early_stop, chunk)
+        again, _, _ = run('1', early_stop, chunk)
+        err, err_in = max_abs(got, want), max_abs(got_in, want_in)
+        print(f'B={B} early_stop={early_stop} chunk={chunk}: max|one launch - three launches| = {err:.3e} (input of the last step {err_in:.3e})')
+        assert err < 1e-5 and err_in < 1e-5
+        assert torch.equal(got, again)
+        assert prof1['gemm_stack_tail']['launches'] == steps and 'finish_pack' not in prof1 and 'finish_ddpm' not in prof1
+        assert not any(k.startswith('gemm_out_t') for k in prof1), sorted(prof1)
+        assert prof0['gemm_stack']['launches'] == steps and 'gemm_stack_tail' not in prof0
+        n_launch = sum(v['launches'] for v in prof1.values())
+        n_calls = -(-steps // chunk)
+        # per call: cond pack + cond embed (+ memset) + the first x_t pack; per step: ONE launch
+        print('   launches with the closing phase:', {k: v['launches'] for k, v in prof1.items()}, '| without:', {k: v['launches'] for k, v in prof0.items()})
+        assert n_launch <= steps + 4 * n_calls
