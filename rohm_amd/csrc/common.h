@@ -163,7 +163,7 @@ void gemm_ln_bind(GemmParams& p, void* scratch);  // fills xln_* from a scratch 
 
 // ---- in-kernel exchanges: header words, first-use arming, layout guard (exchange.hip) -------------------------------------------
 // An exchange scratch starts with a 64-byte header: [0] error word (0 fine, 1 a bounded wait expired, 2 partners on different XCDs),
-// [1] kExchangeMagic once armed, [2] pass counter (the device part of the launch tags).  exchange_arm: on a scratch it sees for the
+// [1] kExchangeMagic once armed, [2] pass counter (the device part of the launch tags), [3] passes pending for it (StackParams::pass_add).  exchange_arm: on a scratch it sees for the
 // first time (magic missing: torch.empty memory, a recycled block) it zeroes the header AND the slot regions `za` / `zb` / `zc` -- a tag is
 // never 0 in its XCD field, so zeroed slots are stale by construction, whatever the block held before -- and, with `bump`, advances
 // the pass counter (callers whose own first kernel does that pass bump = false).  Two tiny launches, no host synchronisation.
@@ -233,7 +233,13 @@ struct StackParams {
     float* t_x0; float* t_apack;                     // optional outputs: x0 [B, C, 1, T]; the next step's pack [M, t_lda] (x_t columns)
     float t_c1, t_c2, t_sigma;
     int t_traj, t_C, t_T, t_lda;
-    unsigned* t_pass_ctr;                            // advanced by one thread at the very end (= the first kernel of the next pass would)
+    unsigned* t_pass_ctr;                            // the exchange header's pass counter [0] and its pending word [1]
+    // Tags of this launch: epoch + 64 x (*xln_pass + pass_add).  A launch with a tail is the only kernel of its step, so nobody
+    // advances the counter between steps: the host numbers the steps of a call (pass_add = 0, 1, ...), the launch leaves pass_add + 1
+    // in the pending word at its end, and the first kernel of the NEXT pass (the x_t pack) adds it to the counter.  The counter itself
+    // is never written while workgroups of an exchanging launch may still be starting (a launch of more than one round of workgroups,
+    // a CU mask): every workgroup of a launch reads the same value.
+    unsigned pass_add;
 };
 // stamps of one layer: 0 layer entered, 1 qkv complete (attention starts), 2 attention done, 3 ctx complete (out-projection starts),
 // 4 out-projection + norm1 done, 5 y complete, 6 linear1 + GELU done, 7 ff complete, 8 linear2 + norm2 done, 9 h complete,

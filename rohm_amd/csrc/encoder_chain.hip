@@ -636,9 +636,38 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
     const int nk = D / BK;
     dma(0, 0);
     dma(1, BK);
+
+    // The epilogue's operands -- x_t and the noise of this lane's outputs: four consecutive tokens of one channel per block, i.e. 16
+    // contiguous bytes of the [B, C, 1, T] tensors (rows of T = 143 floats: 4-byte aligned only, which global loads of this target
+    // accept) -- are requested HERE, behind the first two chunks' DMAs, and land underneath the main loop.  Block (0, lg 0) starts at
+    // token 0, which has no output: its first element is the float in front of the row (never stored).
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int C = p.t_C, T = p.t_T, traj = p.t_traj, S = BM;
+    float* const x = p.t_x;
+    const float* const nzp = p.t_noise;
+    const size_t row_own = ((size_t)g * C + traj + (tn * NC_OWN + c_loc) * 16 + li) * T;
+    const size_t row_sh = ((size_t)g * C + traj + 256 + li) * T;
+    f32x4 xt[NRMAX], nz[NRMAX], xt_e = f32x4{0.f, 0.f, 0.f, 0.f}, nz_e = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NRMAX; ++r) {
+        xt[r] = nz[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < nr) {
+            const size_t idx = row_own + (size_t)((r0 + r) * 16 + 4 * lg) - 1;
+            xt[r] = *reinterpret_cast<const f32x4u*>(x + idx);
+            if (nzp) nz[r] = *reinterpret_cast<const f32x4u*>(nzp + idx);
+        }
+    }
+    if (has_e) {
+        const size_t idx = row_sh + (size_t)(e * 16 + 4 * lg) - 1;
+        xt_e = *reinterpret_cast<const f32x4u*>(x + idx);
+        if (nzp) nz_e = *reinterpret_cast<const f32x4u*>(nzp + idx);
+    }
+    const float bias_own = p.t_out_b[(tn * NC_OWN + c_loc) * 16 + li], bias_sh = p.t_out_b[256 + li];
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        // chunk kc has landed once at most the pieces of chunk kc + 1 are outstanding (loads retire in order)
+        // chunk kc has landed once at most PIECES younger operations are outstanding (loads retire in order): the pieces of chunk
+        // kc + 1 -- at kc = 0 the youngest ones are the epilogue operands instead, which over-waits once (chunk 1 has to land too) and
+        // is never too little
         if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -668,34 +697,40 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
     }
 
     // ---- epilogue: bias, x0, the ancestral update in place, the next step's pack -------------------------------------------------
-    const int C = p.t_C, T = p.t_T, traj = p.t_traj, S = BM;
     const float c1 = p.t_c1, c2 = p.t_c2, sg = p.t_sigma;
-    float* const x = p.t_x;
-    const float* const nzp = p.t_noise;
     float* const x0o = p.t_x0;
     float* const apk = p.t_apack;
-    auto emit = [&](int rblk, int cblk, const f32x4& a) __attribute__((always_inline)) {
-        const int ch = cblk * 16 + li;                 // 0 .. 271
-        const float bias = p.t_out_b[ch];
-        const size_t row = ((size_t)g * C + traj + ch) * T;
+    auto emit = [&](int rblk, size_t row, int ch, float bias, const f32x4& a, const f32x4& xv, const f32x4& nv) __attribute__((always_inline)) {
         const int tok0 = rblk * 16 + 4 * lg;
+        f32x4 val, o;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int tok = tok0 + v;
-            if (tok == 0) continue;                    // the timestep token has no output
-            const size_t idx = row + (size_t)(tok - 1);
-            const float val = a[v] + bias;
-            if (x0o) x0o[idx] = val;
-            float o = c1 * val + c2 * x[idx];
-            if (nzp) o += sg * nzp[idx];
-            x[idx] = o;
-            if (apk) apk[((size_t)g * S + tok) * p.t_lda + traj + ch] = o;
+            val[v] = a[v] + bias;
+            o[v] = c1 * val[v] + c2 * xv[v];
+            if (nzp) o[v] += sg * nv[v];
+        }
+        const size_t idx = row + (size_t)tok0 - 1;
+        if (tok0 != 0) {
+            if (x0o) *reinterpret_cast<f32x4u*>(x0o + idx) = val;
+            *reinterpret_cast<f32x4u*>(x + idx) = o;
+        } else {                                       // token 0 (the timestep token) has no output: elements 1 .. 3 only
+#pragma unroll
+            for (int v = 1; v < 4; ++v) {
+                if (x0o) x0o[idx + v] = val[v];
+                x[idx + v] = o[v];
+            }
+        }
+        if (apk) {
+            float* const d = apk + ((size_t)g * S + tok0) * p.t_lda + traj + ch;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (tok0 + v != 0) d[(size_t)v * p.t_lda] = o[v];
         }
     };
 #pragma unroll
     for (int r = 0; r < NRMAX; ++r)
-        if (r < nr) emit(r0 + r, tn * NC_OWN + c_loc, acc[r]);
-    if (has_e) emit(e, 16, acc_e);
+        if (r < nr) emit(r0 + r, row_own, (tn * NC_OWN + c_loc) * 16 + li, bias_own, acc[r], xt[r], nz[r]);
+    if (has_e) emit(e, row_sh, 256 + li, bias_sh, acc_e, xt_e, nz_e);
     // trajectory channels: x0 = cond there (model/posenet.py:94-95); the clip's traj x T elements are dealt over its G workgroups
     for (int i = tn * 256 + tid; i < traj * T; i += G * 256) {
         const int ch = i / T, t = i - ch * T;
@@ -774,7 +809,7 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
     const int g = (j / G) * kNumXCD + x, tn = j % G;
     if (g >= p.tiles_m) return;
     const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
-    const unsigned ep = p.epoch + 64u * *p.xln_pass;
+    const unsigned ep = p.epoch + 64u * (*p.xln_pass + p.pass_add);
     if (tid0 == 0) p.xln_xcc[g * 8 + tn] = xcc1;
 
     PhaseArgs a{};
@@ -852,8 +887,9 @@ __global__ __launch_bounds__(256) void encoder_stack_kernel(StackParams p) {
                 stamp(l, 9);
                 head_tail_phase<G>(p, g, tn, smem, tid);
                 stamp(l, 10);
-                // the next pass's tags: every workgroup of this (single-round) launch read the counter when it started, long ago
-                if (p.t_pass_ctr != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *p.t_pass_ctr += 1u;
+                // the passes this call has consumed so far, for the first kernel of the next pass (the counter itself stays untouched:
+                // common.h StackParams::pass_add)
+                if (p.t_pass_ctr != nullptr && blockIdx.x == 0 && threadIdx.x == 0) p.t_pass_ctr[1] = p.pass_add + 1u;
             }
             break;
         }
@@ -878,9 +914,9 @@ int launch_encoder_stack(const StackParams& p, hipStream_t s) {
     StackParams q = p;
     q.tiles_m = p.M / chain::BM;
     const int groups8 = (q.tiles_m + kNumXCD - 1) / kNumXCD * kNumXCD;
-    ROHM_ARG_CHECK(!p.tail || (groups8 * G <= 256 && p.D == 512 && p.t_out_w && p.t_out_b && p.t_x && p.t_cond && p.t_C - p.t_traj == 272 &&
+    ROHM_ARG_CHECK(!p.tail || (p.D == 512 && p.t_out_w && p.t_out_b && p.t_x && p.t_cond && p.t_C - p.t_traj == 272 &&
                                p.t_T == chain::BM - 1 && p.t_traj > 0 && (!p.t_apack || p.t_lda >= p.t_C)),
-                   "encoder_stack: the closing head / update / pack phase needs a single-round launch of whole 144-token clips, 272 predicted channels");
+                   "encoder_stack: the closing head / update / pack phase needs whole 144-token clips, d_model 512 and 272 predicted channels");
     constexpr int kFloats = AT_LDS_FLOATS > chain::kLdsFloats ? AT_LDS_FLOATS : chain::kLdsFloats;
     const size_t lds = (size_t)kFloats * sizeof(float);
     static bool attr_set[64][2] = {};

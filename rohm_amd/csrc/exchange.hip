@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void exchange_zero_kernel(const unsigned* __re
 }
 
 __global__ void exchange_arm_kernel(unsigned* header, int bump) {
-    if (header[1] != kExchangeMagic) { header[0] = 0u; header[2] = 0u; header[1] = kExchangeMagic; }
+    if (header[1] != kExchangeMagic) { header[0] = 0u; header[2] = 0u; header[3] = 0u; header[1] = kExchangeMagic; }
     if (bump) header[2] += 1u;
 }
 

@@ -97,7 +97,9 @@ namespace rohm {
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                    int C, int T, int S, int KP, int col0, int zero_to, unsigned* pass_ctr) {
     __shared__ float tile[32][33];
-    if (pass_ctr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *pass_ctr += 1u;
+    // [0] the pass counter, [1] the passes a preceding run of one-launch steps consumed beyond it (StackParams::pass_add: those launches
+    // never write [0] -- their own late workgroups would read it -- they leave their count here for the next pass's first kernel)
+    if (pass_ctr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { *pass_ctr += 1u + pass_ctr[1]; pass_ctr[1] = 0u; }
     const int b = blockIdx.z;
     const int c0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(256) void finish_pack_kernel(float* __restrict__ x0
                                                           const float* __restrict__ noise, float* __restrict__ apack, float c1, float c2,
                                                           float sigma, int traj, int C, int T, int S, int KP, unsigned* pass_ctr) {
     __shared__ float tile[32][33];
-    if (pass_ctr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *pass_ctr += 1u;
+    // [0] the pass counter, [1] the passes a preceding run of one-launch steps consumed beyond it (StackParams::pass_add: those launches
+    // never write [0] -- their own late workgroups would read it -- they leave their count here for the next pass's first kernel)
+    if (pass_ctr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { *pass_ctr += 1u + pass_ctr[1]; pass_ctr[1] = 0u; }
     const int b = blockIdx.z;
     const int c0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -353,6 +357,7 @@ struct TailArgs {
     float* x; const float* cond; const float* noise; float* x0; float* apack_next;
     float c1, c2, sigma;
     unsigned* pass_ctr;
+    int step;      // index of the step within the call: the launch's tags use pass counter + step
 };
 
 // Network body: from packed input (w.apack complete) to x0 channels [traj, Cin) in `x0_out`.  With `tail` (sampling loop) and a launch
@@ -495,13 +500,15 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
         c.timeline = p->stack_timeline;
         {
             const int Gp = encoder_chain_parts(M, D, p->F), groups8 = (B + kNumXCD - 1) / kNumXCD * kNumXCD;
-            if (tail && tail_ran && front && p->stack_tail && groups8 * Gp <= 256 && D == 512 && p->Cout == 272 && !fold) {
+            (void)Gp; (void)groups8;
+            if (tail && tail_ran && front && p->stack_tail && D == 512 && p->Cout == 272 && !fold) {
                 c.tail = 1;
                 c.t_out_w = p->out_w; c.t_out_b = p->out_b;
                 c.t_x = tail->x; c.t_cond = tail->cond; c.t_noise = tail->sigma == 0.f ? nullptr : tail->noise;
                 c.t_x0 = tail->x0; c.t_apack = tail->apack_next;
                 c.t_c1 = tail->c1; c.t_c2 = tail->c2; c.t_sigma = tail->sigma;
                 c.t_traj = p->traj; c.t_C = p->Cin; c.t_T = T; c.t_lda = p->KP; c.t_pass_ctr = tail->pass_ctr;
+                c.pass_add = (unsigned)tail->step;
                 *tail_ran = true;
             }
         }
@@ -1053,7 +1060,7 @@ int rohm_posenet_sample_loop(const rohm_posenet_t* h, float* x, const float* con
         const float* nz = noise ? noise + (size_t)i * n : nullptr;
         // one launch per step where the plan allows (run_network decides): the stack closes with head + update + the next step's pack
         TailArgs tail{x, cond, nz, (x0_last && i == n_steps - 1) ? x0_last : nullptr, (i + 1 < n_steps) ? w.apack : nullptr,
-                      c1, c2, sigma, pass_counter(w)};
+                      c1, c2, sigma, pass_counter(w), i};
         bool tail_ran = false;
         if ((rc = run_network(h, w, nullptr, t_model[i], nullptr, x0, B, T, s, hoist, h->finish_pack ? &tail : nullptr, &tail_ran))) return rc;
         if (tail_ran) continue;
