@@ -582,8 +582,10 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
     constexpr int NRMAX = (G == 4) ? 9 : 5;
     constexpr int W_UNITS = NW * 8, W_ITERS = (W_UNITS + 255) / 256;
     constexpr int PIECES = A_ITERS + W_ITERS;
-    float* As = smem;
-    float* Bs = smem + 2 * BM * BK;
+    // three staging buffers [A: 144 x 32 | W: NW x 32] each: chunk kc + 2 is issued at the top of iteration kc into the buffer that
+    // iteration kc - 1 read, so ONE barrier per chunk orders everything (86 KB of the 135 KB the GEMM phases stage in)
+    constexpr int kBuf = (BM + NW) * BK;
+    static_assert(3 * kBuf <= kZone, "head phase: staging buffers overrun the zone");
     float* lds_dummy = smem + kZone;
     const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -614,7 +616,7 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
     auto dma = [&](int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            float* dst = As + buf * (BM * BK) + (i * 256 + wave_u) * 4;
+            float* dst = smem + buf * kBuf + (i * 256 + wave_u) * 4;
             if (i == A_ITERS - 1 && A_UNITS % 256 != 0)
                 dst = (wave_u < A_UNITS - (A_ITERS - 1) * 256) ? dst : lds_dummy + (wave_u & 64) * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
@@ -622,7 +624,7 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
         }
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i) {
-            float* dst = Bs + buf * (NW * BK) + (i * 256 + wave_u) * 4;
+            float* dst = smem + buf * kBuf + BM * BK + (i * 256 + wave_u) * 4;
             if (i == W_ITERS - 1 && W_UNITS % 256 != 0)
                 dst = (wave_u < W_UNITS - (W_ITERS - 1) * 256) ? dst : lds_dummy + (wave_u & 64) * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + k0),
@@ -663,16 +665,17 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
         if (nzp) nz_e = *reinterpret_cast<const f32x4u*>(nzp + idx);
     }
     const float bias_own = p.t_out_b[(tn * NC_OWN + c_loc) * 16 + li], bias_sh = p.t_out_b[256 + li];
+    int buf = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
         // chunk kc has landed once at most PIECES younger operations are outstanding (loads retire in order): the pieces of chunk
         // kc + 1 -- at kc = 0 the youngest ones are the epilogue operands instead, which over-waits once (chunk 1 has to land too) and
         // is never too little
         if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const float* as = As + buf * (BM * BK);
-        const float* ws = Bs + buf * (NW * BK);
+        __syncthreads();                               // chunk kc is visible to every wave; every wave is done with chunk kc - 1
+        if (kc + 2 < nk) dma(buf >= 1 ? buf - 1 : 2, (kc + 2) * BK);      // (kc + 2) % 3: the buffer chunk kc - 1 was read from
+        const float* as = smem + buf * kBuf;
+        const float* ws = as + BM * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = ks * 4 + lg;
@@ -692,8 +695,7 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
                 for (int j = 0; j < 4; ++j) acc_e = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w_sh[j], acc_e, 0, 0, 0);
             }
         }
-        __syncthreads();                               // every wave is done with this buffer
-        if (kc + 2 < nk) dma(buf, (kc + 2) * BK);
+        buf = buf == 2 ? 0 : buf + 1;
     }
 
     // ---- epilogue: bias, x0, the ancestral update in place, the next step's pack -------------------------------------------------

@@ -69,7 +69,7 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
     out = {'batch': B, 'parts_per_clip': G, 'workgroups': int(valid.sum()), 'launches_stamped': reps,
            'step_wall_us_by_events': float(np.mean(wall)),
            'clock': 's_memrealtime (100 MHz wall clock), lane 0 of every workgroup; spans are means over workgroups, summed over the 8 layers'}
-    spans, launch = {}, []
+    spans, launch, finish = {}, [], []
     for Tm in recs:
         Tm = Tm[valid]
         front = Tm[:, 8, 0].min() > 0
@@ -92,6 +92,7 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
                 spans.setdefault(name, []).append(float((Tm[:, 8, b] - Tm[:, 8, a]).mean()))
         # skew: how far apart the workgroups of the launch finish
         spans.setdefault('finish_skew', []).append(float(last.max() - last.min()))
+        finish.append(last - last.min())
     span = float(np.mean(launch))
     out['launch_span_us'] = span
     out['phases'] = {}
@@ -117,6 +118,21 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
         'note': 'attention phase of encoder_stack_kernel, measured inside the launch: algorithmic 4 S^2 d_h flop per (clip, head) x 8 layers / '
                 'the mean over workgroups of the phase span (stamp 1 -> 2), summed over the layers; "_incl_meeting" adds the wait for the '
                 'clip\'s other workgroups behind it (stamp 2 -> 3: the imbalance between the halves of a split item lands there)'}
+    # Is the finish skew systematic (the same workgroups / XCDs late in every launch) or random?  Systematic skew cannot be recovered
+    # by letting clips run ahead across step boundaries; random skew could.
+    F = np.stack(finish)                                       # [reps, workgroups]: us behind the first finisher
+    xcd = (blocks % 8)[valid]
+    per_xcd = np.array([[F[r][xcd == k].mean() for k in range(8)] for r in range(len(F))])
+    mean_wg = F.mean(axis=0)
+    cors = [float(np.corrcoef(F[a], F[b])[0, 1]) for a in range(len(F)) for b in range(a + 1, len(F))]
+    out['finish_skew_analysis'] = {
+        'per_xcd_mean_us_behind_first': [round(float(v), 2) for v in per_xcd.mean(axis=0)],
+        'per_xcd_std_over_launches_us': [round(float(v), 2) for v in per_xcd.std(axis=0)],
+        'mean_over_workgroups_us_behind_first': round(float(F.mean()), 2),
+        'correlation_of_workgroup_lateness_between_launches': round(float(np.mean(cors)), 3) if cors else None,
+        'max_of_mean_lateness_us': round(float(mean_wg.max()), 2),
+        'note': 'lateness = a workgroup\'s last stamp minus the launch\'s first finisher; correlation near 1 = the same workgroups are late in '
+                'every launch (systematic: placement, XCD), near 0 = random'}
     waits = sum(v['us_per_launch'] for k, v in out['phases'].items() if k.startswith('wait_'))
     out['meetings_us_per_launch'] = round(waits, 2)
     out['meetings_share_of_launch'] = round(waits / span, 4)
@@ -134,6 +150,11 @@ def text(rec):
                      f"{v.get('tflops', float('nan')):>10.1f}{v.get('frac_of_fp32_mfma_peak', float('nan')):>10.3f}")
     a = rec['attention_in_stack']
     lines.append(f"meetings (all waits): {rec['meetings_us_per_launch']:.1f} us = {rec['meetings_share_of_launch']:.3f} of the launch")
+    fa = rec.get('finish_skew_analysis')
+    if fa:
+        lines.append(f"finish skew: mean lateness {fa['mean_over_workgroups_us_behind_first']} us, per XCD {fa['per_xcd_mean_us_behind_first']} "
+                     f"(std over launches {fa['per_xcd_std_over_launches_us']}), lateness correlation between launches "
+                     f"{fa['correlation_of_workgroup_lateness_between_launches']}")
     lines.append(f"attention inside the stack: {a['achieved']:.1f} TFLOP/s = {a['frac']:.3f} of the fp32-MFMA peak "
                  f"({a['share_of_launch']:.3f} of the launch); with the meeting behind it {a['achieved_incl_meeting']:.1f} = {a['frac_incl_meeting']:.3f}")
     return '\n'.join(lines)
