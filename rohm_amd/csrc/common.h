@@ -247,6 +247,7 @@ struct StackParams {
 constexpr int kStackTimelineLayers = 9, kStackTimelineStamps = 12;
 int launch_encoder_stack(const StackParams& p, hipStream_t s);
 int encoder_chain_parts(int M, int D, int F);      // column tiles per clip (4 or 8), 0 = no chain form for this shape
+bool encoder_chain_pays(int B);                    // whole rounds of persistent workgroups: is the chain / stack the faster plan for B clips?
 size_t encoder_chain_flag_bytes(int M);
 int launch_encoder_chain(const ChainParams& p, hipStream_t s);
 // Is `s` recording a hipGraph?

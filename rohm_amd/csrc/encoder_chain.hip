@@ -945,7 +945,23 @@ int launch_encoder_stack(const StackParams& p, hipStream_t s) {
 int encoder_chain_parts(int M, int D, int F) {      // 0: this shape has no chain form
     if (D != 512 || F != 1024 || M <= 0 || M % chain::BM != 0) return 0;
     const int tm = M / chain::BM;
-    return tm * 4 >= 256 ? 4 : 8;      // the tile widths launch_gemm picks for these GEMMs (ln_tile_width: 144 x 128 while every CU gets a tile)
+    // 4 parts per clip (144 x 128 / 256 / 128 / 384 tiles) from 48 clips on, 8 (144 x 64 / 128 / 64 / 192) below: 48 .. 64 clips fit ONE
+    // round of 4-part workgroups (192 .. 256 of them), whose wider tiles beat two rounds of 8-part ones even with CUs left idle
+    // (measured, profiles/r6_f_*: B = 56 as 448 8-part workgroups 3.12 ms per step, as 224 4-part ones the 2.83 ms of B = 64)
+    return tm >= 48 ? 4 : 8;
+}
+
+// Does the chain / stack form pay at this batch size?  Its workgroups are persistent, one per CU, so a launch costs whole ROUNDS of 256
+// workgroups: B = 40 (320 8-part workgroups) or B = 72 (288 4-part ones) pay two rounds for little more than one round of work, and
+// one launch per GEMM -- which picks a tile width per GEMM -- is 7-27 % faster there (measured at B = 40 / 48 / 56 / 72 / 96 / 128,
+// profiles/r6_f_tail_ab_and_batch_sweep.json).  So: a single round of 4-part workgroups (48 .. 64 clips), a single round of
+// 8-part ones that fills the chip (25 .. 32 clips; the callers also ask for >= 32), or several rounds that are >= 95 % full.
+bool encoder_chain_pays(int B) {
+    if (B <= 0) return false;
+    if (B < 48) return B > 24 && B <= 32;
+    if (B <= 64) return true;
+    const int wgs = (B + kNumXCD - 1) / kNumXCD * kNumXCD * 4, rounds = (wgs + 255) / 256;
+    return 4 * B * 100 >= 95 * rounds * 256;
 }
 
 // [row tile][layer <= 8, + 1 for the leading embed / QKV phases][meeting point <= 5][part <= 8] (the per-layer chain uses the first 3 x 8

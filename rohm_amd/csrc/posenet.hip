@@ -383,7 +383,7 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     const bool planes = p->nplane && S == 144 && D / p->H == 128;
     // the launch plan of the encoder (below): decided here because the stack also takes the input embedding and layer 0's in-projection
     const bool lnf_plan = p->ln_fused && !(p->ln_fold && !planes) && !planes && gemm_ln_supported(M, D, D) && gemm_ln_supported(M, D, p->F);
-    const bool chained_plan = lnf_plan && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && (B >= 32 || p->chain_any);
+    const bool chained_plan = lnf_plan && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && ((B >= 32 && encoder_chain_pays(B)) || p->chain_any);
     const bool stacked_plan = chained_plan && p->chain == 2 && p->H == 4 && p->L <= 8 && S == 144 && D / p->H == 128;
     GemmParams ge{};      // fused input embed (+cond embed, + biases, + positional table)
     ge.A = w.apack; ge.lda = p->KP; ge.W = p->w_embed; ge.ldw = p->KP; ge.C = w.h; ge.ldc = D;
@@ -459,9 +459,10 @@ static int run_network(const rohm_posenet* p, const Workspace& w, const int64_t*
     // The four GEMMs between two attention launches as ONE launch (encoder_chain.hip): needs the in-kernel LayerNorm exchange (lnf) and
     // the released widths.  Layer l: [QKV of layer 0: its own launch] attention(l), chain(l) = out-proj + norm1, FF1, FF2 + norm2 and
     // the QKV projection of layer l + 1.  Tags: 4 l, 4 l + 1 (the chain's two LayerNorm exchanges and its flags); the head: 60.
-    // From 32 clips on (every phase then has >= 256 tiles): below that the launch-per-GEMM path picks narrower tiles per GEMM and keeps
-    // more CUs busy (ROHM_POSENET_CHAIN_ANY=1 chains every shape that has the form: tests).
-    const bool chained = lnf && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && (B >= 32 || p->chain_any);
+    // From 32 clips on where whole rounds of its persistent workgroups fit the batch (encoder_chain_pays: 32, 48 .. 64, 122 .. 128, ...):
+    // elsewhere the launch-per-GEMM path picks a tile width per GEMM and keeps more CUs busy (ROHM_POSENET_CHAIN_ANY=1 chains every
+    // shape that has the form: tests).
+    const bool chained = lnf && p->chain && encoder_chain_parts(M, D, p->F) != 0 && 4 * p->L + 2 <= 60 && ((B >= 32 && encoder_chain_pays(B)) || p->chain_any);
     const bool stacked = stacked_plan;
     if (stacked != (chained && p->chain == 2 && p->H == 4 && p->L <= 8 && S == 144 && D / p->H == 128)) {
         set_error("posenet: inconsistent launch plan");      // the two derivations of the plan must agree

@@ -37,7 +37,7 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
     nat = net.native(dev)
     if not nat.exchange_mode & 32 or B < 32:
         return {'error': f'no encoder-stack launch at B = {B} on this handle (exchange_mode {nat.exchange_mode}: {nat.exchange_guard})'}
-    G = 4 if B * 4 >= 256 else 8
+    G = 4 if B >= 48 else 8          # csrc/encoder_chain.hip encoder_chain_parts
     groups8 = (B + 7) // 8 * 8
     nbytes = lib().rohm_posenet_stack_timeline_bytes(B)
     buf = torch.zeros(nbytes // 8, dtype=torch.int64, device=dev)
@@ -67,7 +67,7 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
     valid = clip < B
     fl = _flops_per_layer(B)
     out = {'batch': B, 'parts_per_clip': G, 'workgroups': int(valid.sum()), 'launches_stamped': reps,
-           'step_wall_us_by_events': float(np.mean(wall)),
+           'step_wall_us_by_events': float(np.median(wall)),
            'clock': 's_memrealtime (100 MHz wall clock), lane 0 of every workgroup; spans are means over workgroups, summed over the 8 layers'}
     spans, launch, finish = {}, [], []
     for Tm in recs:
@@ -93,11 +93,11 @@ def measure(net, B, T=143, reps=5, device='cuda:0', seed=0):
         # skew: how far apart the workgroups of the launch finish
         spans.setdefault('finish_skew', []).append(float(last.max() - last.min()))
         finish.append(last - last.min())
-    span = float(np.mean(launch))
+    span = float(np.median(launch))          # medians over the stamped launches: one disturbed launch must not move the record
     out['launch_span_us'] = span
     out['phases'] = {}
     for name, vals in spans.items():
-        us = float(np.mean(vals))
+        us = float(np.median(vals))
         rec = {'us_per_launch': round(us, 2), 'share_of_launch': round(us / span, 4)}
         n_l = 7 if name == 'in_proj_next' else 8
         if name == 'head_update_pack':

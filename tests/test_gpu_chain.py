@@ -60,11 +60,12 @@ def test_chain_forward_matches_one_launch_per_gemm(B, chain, monkeypatch):
 
 
 @pytest.mark.parametrize('chain', ['layer', 'stack'])
-@pytest.mark.parametrize('B', [40, 33, 3, 1])
+@pytest.mark.parametrize('B', [56, 48, 40, 33, 3, 1])
 def test_chain_at_other_batch_sizes(B, chain, monkeypatch):
     """Row tiles that are not a multiple of 8 (surplus workgroups leave), more than one round of workgroups (B = 40: 320), tiny
-    batches (forced: by default they keep the launch-per-GEMM path, whose narrower tiles fill more CUs).  The launch-per-GEMM path
-    picks other tile widths here, so agreement is to summation order."""
+    batches (forced: by default they keep the launch-per-GEMM path, whose narrower tiles fill more CUs), and -- round 6 -- 48 / 56
+    clips as ONE part-filled round of 4-part workgroups (192 / 224 of 256).  The launch-per-GEMM path picks other tile widths here,
+    so agreement is to summation order."""
     plain, net = _pair(monkeypatch, chain=chain, any_batch=True)
     x, c, t = _inputs(B)
     want = plain({'x_t': x, 'cond': c}, t)
@@ -206,3 +207,24 @@ def test_one_launch_per_denoising_step_matches_the_three_launch_step(B, monkeypa
         # per call: cond pack + cond embed (+ memset) + the first x_t pack; per step: ONE launch
         print('   launches with the closing phase:', {k: v['launches'] for k, v in prof1.items()}, '| without:', {k: v['launches'] for k, v in prof0.items()})
         assert n_launch <= steps + 4 * n_calls
+
+
+def test_the_stack_is_used_where_whole_rounds_of_its_workgroups_fit():
+    """ADVICE r5 / profiles/r6_f_tail_ab_and_batch_sweep.json: the persistent one-per-CU workgroups of the stack cost whole rounds of
+    256, so by default it runs at B = 32 (256 8-part workgroups), 48 .. 64 (one round of 4-part ones), 128 (two full rounds) -- and
+    NOT at 40, 72 or 96, where one launch per GEMM is 7-27 % faster."""
+    from rohm_amd import _lib
+    net, _ = make_posenet(5)
+    nat = net.native(torch.device(DEV))
+    if nat.exchange_mode & 32 == 0:
+        pytest.skip(f'no encoder stack on this device: {nat.exchange_guard}')
+    for B, stacked in ((32, True), (40, False), (48, True), (56, True), (64, True), (72, False), (96, False), (128, True)):
+        x, c, t = _inputs(B)
+        net({'x_t': x, 'cond': c}, t)
+        _lib.profile_start(1)
+        y = net({'x_t': x, 'cond': c}, t)
+        torch.cuda.synchronize()
+        prof = _lib.profile_stop()
+        assert torch.isfinite(y).all()
+        assert ('gemm_stack' in prof) == stacked, (B, sorted(prof))
+    net.check_exchange()
