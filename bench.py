@@ -1128,7 +1128,12 @@ def main(argv=None):
                               'time_share_of_kernels': prof[dom]['total_ms'] / all_ms,
                               'traffic': pmc_traffic_of('encoder_stack_kernel') if B == 64 else None,
                               'traffic_note': 'ARCHIVED HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 PMC passes of the '
-                                              'B = 64 workload); algorithmic: activations once + weights once per XCD = 3.3 GB'}
+                                              'B = 64 workload).  Two yardsticks: what a fused stack MUST move -- the weights once (8 x 101 MB), the '
+                                              'packed input and the output: ~0.85 GB -- and what THIS design moves by construction -- every '
+                                              'inter-phase activation written and read once through L2 / HBM, the weights once per XCD: 3.3 GB.  The '
+                                              'measured figure is ~4x the first and ~1.02x the second: no re-reads beyond the design, but the design '
+                                              'itself is far from traffic-minimal; at 1.2 TB/s (15 % of HBM peak) on an MFMA-bound kernel that is '
+                                              'not what limits it'}
                              if dom else None),
                 'launches_timed': g_n, 'avg_launch_us': g_ms / g_n * 1e3 if g_n else None,
                 'alg_gflop_per_launch': g_fl / g_n / 1e9 if g_n else None,

@@ -955,13 +955,14 @@ int encoder_chain_parts(int M, int D, int F) {      // 0: this shape has no chai
 // workgroups: B = 40 (320 8-part workgroups) or B = 72 (288 4-part ones) pay two rounds for little more than one round of work, and
 // one launch per GEMM -- which picks a tile width per GEMM -- is 7-27 % faster there (measured at B = 40 / 48 / 56 / 72 / 96 / 128,
 // profiles/r6_f_tail_ab_and_batch_sweep.json).  So: a single round of 4-part workgroups (48 .. 64 clips), a single round of
-// 8-part ones that fills the chip (25 .. 32 clips; the callers also ask for >= 32), or several rounds that are >= 95 % full.
+// 8-part ones that fills the chip (25 .. 32 clips; the callers also ask for >= 32), or several rounds that are >= 93 % full
+// (profiles/r6_g_stack_gate_sweep.json).
 bool encoder_chain_pays(int B) {
     if (B <= 0) return false;
     if (B < 48) return B > 24 && B <= 32;
     if (B <= 64) return true;
     const int wgs = (B + kNumXCD - 1) / kNumXCD * kNumXCD * 4, rounds = (wgs + 255) / 256;
-    return 4 * B * 100 >= 95 * rounds * 256;
+    return 4 * B * 100 >= 93 * rounds * 256;      // B = 120 (two rounds, 94 % full): the stack is 2.4 % faster; B = 112 stays per GEMM
 }
 
 // [row tile][layer <= 8, + 1 for the leading embed / QKV phases][meeting point <= 5][part <= 8] (the per-layer chain uses the first 3 x 8
