@@ -483,7 +483,7 @@ def scheme_bench(args, world, rank, dev, dist):
                             'launches_timed': g_n, 'gemm_time_share_of_kernels': g_ms / all_ms if all_ms else None,
                             'kernels': kernels}}
         rec['rank_report'] = report
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and (not args.no_cpu_baseline or args.config_cpu_baseline):
             try:
                 rec['cpu_baseline'] = cpu_baseline_config(args.workload, B)
             except Exception as e:      # a side measurement never costs the record
@@ -601,7 +601,8 @@ def extras(args, budget_s=420.0):
     cfg = {}
     for key, argv in (('b32', ['--workload', 'posenet', '--batch', '32']), ('scheme_b32', ['--workload', 'scheme', '--batch', '32']),
                       ('prox_b32', ['--workload', 'prox', '--batch', '32']), ('egobody_b32', ['--workload', 'egobody', '--batch', '32'])):
-        cfg[key] = brief(child(argv + ['--ddpm-steps', S, '--steps', '2', '--warmup', '1']))
+        cfg[key] = brief(child(argv + ['--ddpm-steps', S, '--steps', '2', '--warmup', '1'] +
+                               ([] if args.no_cpu_baseline else ['--config-cpu-baseline'])))
     return second, cfg
 
 
@@ -955,6 +956,8 @@ def main(argv=None):
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--ddpm-steps', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config-cpu-baseline', action='store_true',
+                    help='attach the CPU baseline of THIS workload even under --no-cpu-baseline (what the parent record asks of its configs children)')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                     help="'nccl' (= RCCL on ROCm) is the only measuring backend; 'gloo' runs the launcher self-test")
     ap.add_argument('--workload', choices=['posenet', 'scheme', 'prox', 'egobody'], default='posenet',
@@ -1156,9 +1159,9 @@ def main(argv=None):
         rec['rank_report'] = report
         if dist is not None:
             rec['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'forced': bool(args.force_dist)}
-        if world == 1 and not args.no_cpu_baseline and not prox:
+        if world == 1 and (not args.no_cpu_baseline or args.config_cpu_baseline) and not prox:
             rec['cpu_baseline'] = cpu_baseline(batch=B)
-        if world == 1 and not args.no_cpu_baseline and prox:
+        if world == 1 and (not args.no_cpu_baseline or args.config_cpu_baseline) and prox:
             try:
                 rec['cpu_baseline'] = cpu_baseline_config('prox', B)
             except Exception as e:
