@@ -505,6 +505,9 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
                     if (!same_xcd) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
+#ifdef ROHM_CHAIN_NO_LN_WAIT      // TIMING experiment only (WRONG statistics: whatever the slots hold): what does waiting for the partners' statistics cost?
+                break;
+#endif
                 __builtin_amdgcn_s_sleep(1);
                 if ((it & 127) == 127 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 if (it > (1 << 19)) {

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round 6, call H: TIMING experiment -- what does waiting for the partners' LayerNorm statistics cost inside the stack?  "nolnwait" = a library whose
+# RES_LN epilogues do not wait (wrong statistics, timing only) against the shipped library, same box, two rounds, B = 64 and 32.
+TAG=${1:-r6_h}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $R
+leg() {   # name lib batch
+  if [ $2 = default ]; then unset ROHM_HIP_LIB; else export ROHM_HIP_LIB=$R/rohm_amd/librohm_hip_$2.so; fi
+  timeout 400 python bench.py --no-extras --no-cpu-baseline --batch $3 --ddpm-steps 300 > $OUT/bench_$1.json 2> $OUT/bench_$1.err
+  python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench_$1.json').read().strip().splitlines()[-1])
+    ph = (d['roofline'].get('attention') or {}).get('stack_phases') or {}
+    print('$1', round(d['value'], 3), 'ms/pass', round(d['ms_per_step'], 1), {k: v['avg_us'] for k, v in list(d['roofline']['kernels'].items())[:2]}, {k: ph[k]['us_per_launch'] for k in ('out_proj_norm1', 'linear2_norm2', 'wait_y', 'wait_h') if k in ph})
+except Exception as e:
+    print('$1 failed', e); print(open('$OUT/bench_$1.err').read()[-800:])
+PY
+  unset ROHM_HIP_LIB
+}
+for round in 1 2; do
+  leg nolnwait64_$round nolnwait 64
+  leg default64_$round default 64
+  leg nolnwait32_$round nolnwait 32
+  leg default32_$round default 32
+done
