@@ -84,6 +84,7 @@ __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, in
     __syncthreads();
     if (tid == 0)
         __hip_atomic_store(flags + tn, ((unsigned long long)xcc1 << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef ROHM_CHAIN_NO_MEET      // TIMING experiment only (results may be stale): what do the meetings cost?
     if (tid < G && tid != tn) {
         for (int it = 0;; ++it) {
             const unsigned long long f = __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -101,6 +102,7 @@ __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, in
             }
         }
     }
+#endif
     __syncthreads();
     // No acquire fence here: at agent scope it is `buffer_inv sc1`, which on this multi-XCD part also drops the L2's lines of ordinary
     // memory -- weights and activations come back from HBM, measured +5 us per meeting (gemm_chain 322 -> 344 us per layer,
@@ -427,6 +429,14 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[q] = (a[q] + col[c].bias[q]) + rr[q];
             }
+#ifdef ROHM_CHAIN_NO_LN_EPI      // TIMING experiment only (WRONG results: no LayerNorm): what does the LayerNorm part of the epilogue cost?
+#pragma unroll
+        for (int r = 0; r < NRB; ++r)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+                *reinterpret_cast<f32x4*>(p.C + (size_t)(m0 + r * 16 + li) * p.ldc + nw + c * 16 + lg * 4) = acc16[r * NCB + c];
+        return;
+#endif
         typedef unsigned rohm_u2 __attribute__((ext_vector_type(2)));
         auto merge_swap = [](float& m, float& q2, float n, bool far) __attribute__((always_inline)) {
             rohm_u2 tm, tq;
@@ -556,10 +566,12 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
             f32x4 v;
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = a[q] + col[cg].bias[q];
+#ifndef ROHM_CHAIN_NO_GELU      // TIMING experiment only (WRONG results): what does the erf-form GELU cost in linear1's epilogue?
             if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
             }
+#endif
             if constexpr (EPI == EPI_QKV) {
                 if (nb < p.qcols) {
 #pragma unroll
