@@ -16,9 +16,14 @@
  *     (*_workspace_bytes).  Weights are copied and re-laid-out at *_create time, so
  *     the caller may free its copies afterwards.
  *   - every launch goes on the caller-supplied hipStream_t (passed as void*);
- *     no hidden device synchronisation.
- *   - handles are immutable after create (one documented exception: rohm_posenet_set_exchange);
- *     calls are re-entrant across streams given distinct workspaces.  One handle per device.
+ *     no hidden device synchronisation in forward / step / loop calls.  Set-up calls say so where they
+ *     synchronise: *_create, rohm_exchange_probe, rohm_posenet_set_exchange(h, 1), the status read
+ *     rohm_posenet_exchange_status; the stand-alone rohm_gemm_res_layernorm_f32 / rohm_output_process_f32
+ *     probe an un-probed device on their FIRST call unless the stream records a graph (see there).
+ *   - handles are immutable after create (documented exceptions, all control calls that must not race with
+ *     launches of the same handle: rohm_posenet_set_exchange, rohm_posenet_inject_exchange_fault,
+ *     rohm_posenet_set_stack_timeline); calls are re-entrant across streams given distinct workspaces.
+ *     One handle per device.
  */
 #ifndef ROHM_HIP_H
 #define ROHM_HIP_H
