@@ -172,7 +172,21 @@ __device__ __forceinline__ void gemm_phase(const PhaseArgs& p, float* smem, cons
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, AUX);
         }
     };
+#ifdef ROHM_CHAIN_W_DEAD64        // TIMING experiment only (WRONG results): the 64-wide tiles' weight chunks as ordinary global loads into registers
+    f32x4 wdead[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // that nobody multiplies: what does the register path cost to ISSUE?
+#endif
     auto dma_b = [&](int buf, int k0) {
+#ifdef ROHM_CHAIN_NO_W_DMA64      // TIMING experiment only (WRONG results: stale weights in LDS): what would taking W off the LDS-DMA path of the 64-wide tiles buy?
+        if constexpr (BN == 64) return;
+#endif
+#ifdef ROHM_CHAIN_W_DEAD64
+        if constexpr (BN == 64) {
+            asm volatile("" ::"v"(wdead[0]), "v"(wdead[1]));      // "use" of the previous chunk's loads (they have landed: vmcnt(0) + barrier just above)
+#pragma unroll
+            for (int i = 0; i < B_ITERS; ++i) wdead[i] = *reinterpret_cast<const f32x4*>(b_src[i] + k0);
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
