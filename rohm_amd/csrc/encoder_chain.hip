@@ -694,37 +694,68 @@ __device__ __forceinline__ void head_tail_phase(const StackParams& p, const int 
         if (nzp) nz_e = *reinterpret_cast<const f32x4u*>(nzp + idx);
     }
     const float bias_own = p.t_out_b[(tn * NC_OWN + c_loc) * 16 + li], bias_sh = p.t_out_b[256 + li];
+    // Software pipeline (gemm_phase's order): the fragments of the NEXT half chunk are requested before the MFMAs of the current one, so
+    // no MFMA group waits for LDS: chunk kc: [reads of half 1 | MFMAs of half 0]  wait + barrier  [DMA of chunk kc + 2, reads of chunk
+    // kc + 1's half 0 | MFMAs of half 1].  hipcc left to itself emits read - wait - 4 MFMAs - read - wait ... (every fragment's LDS latency
+    // exposed: the phase ran at 0.55 of its MFMA floor); the waits go through the builtin so that it sees the queue drain, sched_barrier
+    // keeps the stages apart.
+    struct HFrag { f32x4 a[NRMAX]; f32x4 ae, w, wsh; };
+    auto read_h = [&](HFrag& f, int b, int ks) __attribute__((always_inline)) {
+        const float* as = smem + b * kBuf;
+        const float* ws = as + BM * BK;
+        const int slot = ks * 4 + lg;
+        f.w = *reinterpret_cast<const f32x4*>(ws + lds_off(c_loc * 16 + li, slot));
+#pragma unroll
+        for (int r = 0; r < NRMAX; ++r)
+            if (r < nr) f.a[r] = *reinterpret_cast<const f32x4*>(as + lds_off((r0 + r) * 16 + li, slot));
+        if (has_e) {
+            f.ae = *reinterpret_cast<const f32x4*>(as + lds_off(e * 16 + li, slot));
+            f.wsh = *reinterpret_cast<const f32x4*>(ws + lds_off(NC_OWN * 16 + li, slot));
+        }
+    };
+    auto mma_h = [&](const HFrag& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < NRMAX; ++r)
+            if (r < nr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r][j], f.w[j], acc[r], 0, 0, 0);
+            }
+        if (has_e) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc_e = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ae[j], f.wsh[j], acc_e, 0, 0, 0);
+        }
+    };
+    HFrag f0, f1;
+    f0.ae = f0.wsh = f1.ae = f1.wsh = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NRMAX; ++r) f0.a[r] = f1.a[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunks 0 and 1 (and the epilogue operands behind them) have landed
+    __syncthreads();
+    read_h(f0, 0, 0);
     int buf = 0;
     for (int kc = 0; kc < nk; ++kc) {
-        // chunk kc has landed once at most PIECES younger operations are outstanding (loads retire in order): the pieces of chunk
-        // kc + 1 -- at kc = 0 the youngest ones are the epilogue operands instead, which over-waits once (chunk 1 has to land too) and
-        // is never too little
-        if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // chunk kc is visible to every wave; every wave is done with chunk kc - 1
-        if (kc + 2 < nk) dma(buf >= 1 ? buf - 1 : 2, (kc + 2) * BK);      // (kc + 2) % 3: the buffer chunk kc - 1 was read from
-        const float* as = smem + buf * kBuf;
-        const float* ws = as + BM * BK;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = ks * 4 + lg;
-            const f32x4 w_own = *reinterpret_cast<const f32x4*>(ws + lds_off(c_loc * 16 + li, slot));
-#pragma unroll
-            for (int r = 0; r < NRMAX; ++r) {
-                if (r < nr) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(as + lds_off((r0 + r) * 16 + li, slot));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w_own[j], acc[r], 0, 0, 0);
-                }
-            }
-            if (has_e) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(as + lds_off(e * 16 + li, slot));
-                const f32x4 w_sh = *reinterpret_cast<const f32x4*>(ws + lds_off(NC_OWN * 16 + li, slot));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc_e = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w_sh[j], acc_e, 0, 0, 0);
-            }
+        AT_WAIT_LGKM0();                               // f0 is in registers (requested one MFMA stage ago)
+        __builtin_amdgcn_sched_barrier(0);
+        read_h(f1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_h(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        if (kc + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk kc + 1 (issued a whole chunk of MFMAs ago)
+            __syncthreads();                           // ... is visible to every wave; every wave has read chunk kc - 1 and half 0 of chunk kc
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc + 2 < nk) dma(buf >= 1 ? buf - 1 : 2, (kc + 2) * BK);      // (kc + 2) % 3: the buffer chunk kc - 1 lived in
+            AT_WAIT_LGKM0();                           // f1 is in registers
+            __builtin_amdgcn_sched_barrier(0);
+            read_h(f0, nbuf, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            AT_WAIT_LGKM0();
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        mma_h(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
     }
 
     // ---- epilogue: bias, x0, the ancestral update in place, the next step's pack -------------------------------------------------
