@@ -160,14 +160,15 @@ def test_a_failed_exchange_inside_the_chain_is_survived(chain, monkeypatch):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize('B', [64, 32])
+@pytest.mark.parametrize('B', [64, 32, 48, 128])
 def test_one_launch_per_denoising_step_matches_the_three_launch_step(B, monkeypatch):
     """Round 6: in the sampling loop the stack closes with OutputProcess (model/heads.py:171-176), the ancestral update
     (gaussian_diffusion_posenet.py:212-234,426-434) and the next step's pack -- ONE `rohm::` kernel per un-guided denoising step at
     the configs' batch sizes (single-round launches).  Against the same library with ROHM_POSENET_STACK_TAIL=0 (stack + stream-K
     head + finish_pack): the head sums K in another order, so agreement is to rounding (1e-5 after 7 steps on |x| ~ 4), the returned
     sample, the last pred_xstart (early_stop) and the input of the last step (batch['x_t']) alike; bit-reproducible; and the launch
-    profiler sees exactly one label per step."""
+    profiler sees exactly one label per step.  B = 48: one part-filled round of 4-part workgroups; B = 128: TWO rounds -- the pass
+    accounting (host-numbered steps + pending word) must hold when late workgroups of a launch start after early ones have finished."""
     from rohm_amd import _lib
     steps = 7
     x_T, noises = cpu_noise_sequence(17, (B, 294, 1, 143), steps)
