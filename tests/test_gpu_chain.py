@@ -229,3 +229,37 @@ def test_the_stack_is_used_where_whole_rounds_of_its_workgroups_fit():
         assert torch.isfinite(y).all()
         assert ('gemm_stack' in prof) == stacked, (B, sorted(prof))
     net.check_exchange()
+
+
+@pytest.mark.parametrize('B', [32, 64])
+def test_stack_phase_timeline_is_consistent(B):
+    """`rohm_posenet_set_stack_timeline` / rohm_amd.stack_timeline (bench.py `roofline.attention`): the stamps the kernel writes about
+    itself add up -- the phase spans of a workgroup tile its launch, the launch span is the step the events time, the attention phase's
+    rate is a plausible fraction of the fp32-MFMA peak -- and the switch really is off afterwards (no stamp is written by later launches)."""
+    from rohm_amd import stack_timeline
+    net, _ = make_posenet(5)
+    rec = stack_timeline.measure(net, B, reps=3, device=DEV)
+    if 'error' in rec:
+        pytest.skip(rec['error'])
+    ph = rec['phases']
+    covered = sum(v['us_per_launch'] for k, v in ph.items() if k != 'finish_skew')
+    print(f"B={B}: span {rec['launch_span_us']:.1f} us, phases sum to {covered:.1f} us, step by events {rec['step_wall_us_by_events']:.1f} us, "
+          f"attention {rec['attention_in_stack']['frac']:.3f} of peak")
+    assert 0.90 * rec['launch_span_us'] < covered <= 1.001 * rec['launch_span_us']            # mean workgroup: its phases + meetings, minus its lateness
+    assert 0.9 * rec['launch_span_us'] < rec['step_wall_us_by_events'] < 1.15 * rec['launch_span_us']
+    assert 0.3 < rec['attention_in_stack']['frac'] < 0.9 and 0.04 < rec['attention_in_stack']['share_of_launch'] < 0.15
+    assert 'head_update_pack' in ph and ph['in_proj_next']['frac_of_fp32_mfma_peak'] > ph['out_proj_norm1']['frac_of_fp32_mfma_peak']
+    # off again: a later forward leaves a poisoned buffer alone
+    from rohm_amd._lib import check, lib, ptr
+    nat = net.native(torch.device(DEV))
+    n = lib().rohm_posenet_stack_timeline_bytes(B)
+    buf = torch.full((n // 8,), -7, dtype=torch.int64, device=DEV)
+    x, c, t = _inputs(B)
+    net({'x_t': x, 'cond': c}, t)
+    torch.cuda.synchronize()
+    assert bool((buf == -7).all())
+    check(lib().rohm_posenet_set_stack_timeline(nat.handle, ptr(buf), n, B), 'rohm_posenet_set_stack_timeline')
+    net({'x_t': x, 'cond': c}, t)
+    torch.cuda.synchronize()
+    check(lib().rohm_posenet_set_stack_timeline(nat.handle, None, 0, 0), 'rohm_posenet_set_stack_timeline')
+    assert int((buf != -7).sum()) > 0

@@ -236,3 +236,21 @@ def test_fused_loop_reruns_a_chunk_whose_exchange_failed():
         # the repeated call started from the very input of the failed one
         k = min(fails)
         assert torch.equal(net.inputs[k - 1], net.inputs[k])
+
+
+def test_per_config_cpu_baseline_prices_a_pass_by_the_references_step_counts():
+    """bench.py `configs.*.cpu_baseline`: every KIND of step of a multi-stage workload is timed with the oracle
+    port and the pass is priced as sum(count x step time) with the reference's own step counts -- TrajNet 100, PoseNet 1000 (980 with
+    early_stop), guidance on t <= 50 ('amass') / t <= 100 ('prox') (gaussian_diffusion_posenet.py:461-477,625-626)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = bench.cpu_baseline_config('scheme', 2, budget_s=4.0)
+    assert rec['kind'] == 'port' and rec['unit'] == 'clips/s' and rec['value'] > 0
+    assert rec['step_counts'] == {'trajnet_step': 100, 'trajcontrol_step': 100, 'posenet_step': 2 * 949, 'posenet_guided_step': 2 * 51}
+    sec = sum(rec['step_ms'][k] * n for k, n in rec['step_counts'].items()) / 1e3
+    assert abs(sec - rec['seconds_per_pass']) < 0.1 * sec + 0.1 and abs(rec['value'] - 2 / sec) < 0.05 * rec['value']
+    ego = bench.cpu_baseline_config('egobody', 2, budget_s=4.0)
+    assert ego['step_counts'] == {'trajnet_step': 100, 'trajcontrol_step': 200, 'posenet_step': 3 * 899, 'posenet_guided_step': 3 * 81}
+    prox = bench.cpu_baseline_config('prox', 2, budget_s=3.0)
+    assert prox['step_counts'] == {'posenet_step': 899, 'posenet_guided_step': 81}
