@@ -263,3 +263,54 @@ def test_stack_phase_timeline_is_consistent(B):
     torch.cuda.synchronize()
     check(lib().rohm_posenet_set_stack_timeline(nat.handle, None, 0, 0), 'rohm_posenet_set_stack_timeline')
     assert int((buf != -7).sum()) > 0
+
+
+def test_one_launch_steps_recorded_into_a_graph_draw_fresh_tags_on_every_replay():
+    """The fused sampling loop with its closing phase, RECORDED: the host bakes each step's index into its launch (`pass_add`), the
+    device-side counter advances once per call by 1 + the steps the previous call consumed (the x_t pack folds the pending word in) --
+    so every replay of the recorded call draws tags no earlier launch used, and its samples equal the eager call's bit for bit."""
+    import numpy as np
+    from rohm_amd import _lib
+    B, T, n = 32, 143, 4
+    net, _ = make_posenet(5)
+    nat = net.native(torch.device(DEV))
+    if nat.exchange_mode & 32 == 0:
+        pytest.skip(f'no encoder stack on this device: {nat.exchange_guard}')
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x0 = torch.randn(B, 294, 1, T, device=DEV, generator=g)
+    cond = torch.randn(B, 294, 1, T, device=DEV, generator=g)
+    noise = torch.randn(n, B, 294, 1, T, device=DEV, generator=g)
+    coef = np.asarray([[0.05, 0.95, 0.1]] * n, np.float32)
+    ts = [400, 399, 398, 397]
+    eager = x0.clone()
+    net.sample_loop_native(eager, cond, ts, coef, noise)
+    eager2 = eager.clone()
+    net.sample_loop_native(eager2, cond, ts, coef, noise)          # a second call continues from the first one's output
+    net.check_exchange()
+    side = torch.cuda.Stream()
+    xs = x0.clone()
+    with torch.cuda.stream(side):
+        warm = x0.clone()
+        net.sample_loop_native(warm, cond, ts, coef, noise)        # this stream's workspace exists and is armed before the capture
+        ws = nat.workspace(B, T)
+    torch.cuda.synchronize()
+    assert torch.equal(warm, eager)
+    off = _lib.lib().rohm_posenet_status_offset(nat.handle, B, T)
+    word = ws[off:off + 16].view(torch.int32)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        net.sample_loop_native(xs, cond, ts, coef, noise)
+    passes = []
+    xs.copy_(x0)
+    for want in (eager, eager2):
+        graph.replay()
+        torch.cuda.synchronize()
+        passes.append((int(word[2]), int(word[3])))
+        if int(word[0]) != 0:      # a bounded wait expired on this box (a recorded call has no host loop to fall back and re-run): the caller's
+            pytest.skip(f'an in-kernel exchange failed during a replay (status {int(word[0])}): the documented remedy is the eager loop')      # check says so
+        assert torch.equal(xs, want), (len(passes), max_abs(xs, want), passes)
+    # per call: the pack advances the counter by 1 + the pending count of the call before it; the last launch leaves n pending
+    assert passes[1][0] - passes[0][0] == 1 + n and passes[0][1] == passes[1][1] == n, passes
+    assert int(word[0]) == 0
+    with torch.cuda.stream(side):
+        net.check_exchange()
