@@ -602,7 +602,7 @@ def extras(args, budget_s=420.0):
     for key, argv in (('b32', ['--workload', 'posenet', '--batch', '32']), ('scheme_b32', ['--workload', 'scheme', '--batch', '32']),
                       ('prox_b32', ['--workload', 'prox', '--batch', '32']), ('egobody_b32', ['--workload', 'egobody', '--batch', '32'])):
         cfg[key] = brief(child(argv + ['--ddpm-steps', S, '--steps', '2', '--warmup', '1'] +
-                               ([] if args.no_cpu_baseline else ['--config-cpu-baseline'])))
+                               ([] if getattr(args, 'no_cpu_baseline', False) else ['--config-cpu-baseline'])))
     return second, cfg
 
 

@@ -224,7 +224,7 @@ def test_extras_attach_second_line_and_configs_and_survive_a_failing_child(monke
                 'roofline': {'achieved': 1.0, 'peak': 2.0, 'frac': 0.5, 'unit': 'TFLOP/s', 'kernel': 'k', 'bound': 'mfma'},
                 'accuracy': {'max_abs_vs_reference': 5e-6}, 'child_wall_s': 1.0}
     monkeypatch.setattr(bench, 'run_child', fake_child)
-    second, cfg = bench.extras(types.SimpleNamespace(ddpm_steps=1000, batch=64))
+    second, cfg = bench.extras(types.SimpleNamespace(ddpm_steps=1000, batch=64, no_cpu_baseline=False))
     assert second['mode'] == 'fp16x3' and second['value'] == 30.0 and second['accuracy']['max_abs_vs_reference'] == 5e-6
     assert second['roofline']['frac'] == 0.5 and 'NEVER the headline' in second['label']
     assert second['also']['bf16x6']['value'] == 30.0
@@ -232,3 +232,8 @@ def test_extras_attach_second_line_and_configs_and_survive_a_failing_child(monke
     assert cfg['b32']['value'] == 18.0 and cfg['egobody_b32']['error'] == 'rc=1'
     # the precision variable reaches only the second-line children; every child runs without the extras and the CPU leg
     assert [c[1].get('ROHM_GEMM_PRECISION') for c in calls] == ['fp16x3', 'bf16x6', None, None, None, None]
+    # each config child is asked for its own CPU baseline (every config carries one) unless the run has none at all
+    assert all('--config-cpu-baseline' in c[0] for c in calls[2:]) and not any('--config-cpu-baseline' in c[0] for c in calls[:2])
+    calls.clear()
+    bench.extras(types.SimpleNamespace(ddpm_steps=1000, batch=64, no_cpu_baseline=True))
+    assert not any('--config-cpu-baseline' in c[0] for c in calls)
