@@ -112,6 +112,7 @@ SIGNATURES = {
                                       C.c_int, C.c_int, C.c_int]),
     'rohm_trajnet_destroy': (None, [C.c_void_p]),
     'rohm_trajnet_tune': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'rohm_trajnet_loop_mode': (C.c_int, []),
     'rohm_trajnet_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'rohm_trajnet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

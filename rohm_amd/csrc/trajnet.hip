@@ -16,63 +16,9 @@
 #include <string>
 #include <vector>
 #include <atomic>
-#include "common.h"
+#include "trajnet_priv.h"
 
 namespace rohm {
-
-constexpr int kPadC = 64;      // row width of <=32-channel activations that are GEMM inputs
-constexpr int kPadCtl = 320;   // 272 control channels padded to the 64-wide K chunk
-
-struct ConvW {          // re-laid-out conv weight: [cout, taps * cin_pad] + bias [cout]
-    float* w = nullptr;
-    float* b = nullptr;
-    int cin = 0, cin_pad = 0, cout = 0, taps = 0;
-};
-struct UpW { ConvW even, odd, both; };    // ConvTranspose1d(k4, s2, p1) as two 2-tap phases; `both` = the two phases as ONE
-                                          // 3-tap GEMM with 2 C output columns (phase 1 stored to the next output row)
-struct BlockW {                           // Conv1dBlock: conv5 + GroupNorm(8)
-    ConvW conv;
-    float *g = nullptr, *be = nullptr;
-};
-struct ResW {                             // ResidualTemporalBlock (b0res: block-0 conv and the 1x1 residual conv as ONE GEMM)
-    BlockW b0, b1;
-    ConvW res;                            // 1x1 when cin != cout (taps == 0 -> absent)
-    ConvW b0res;                          // [2 cout, 5 cin_pad]: rows [0, cout) = b0.conv, rows [cout, 2 cout) = res at the centre tap
-    bool has_res = false;
-    int tb_off = -1;                      // offset of this block's time bias inside tb_all, -1 = no time input
-    int cin = 0, cout = 0;
-};
-
-}  // namespace rohm
-
-struct rohm_trajnet {
-    int mid, tdim, ctraj, cctrl, control, device;
-    float* arena = nullptr;
-    size_t arena_floats = 0;
-    float* zero_page = nullptr;
-    // time path
-    float *t_w1T, *t_b1, *t_w3T, *t_b3;   // time_mlp.{1,3} stored [in][out]
-    float *tb_wT, *tb_b;                  // all per-block time Linears stacked: [tdim][tb_total], [tb_total]
-    int tb_total = 0;
-    rohm::ResW cond_enc[4], diff_enc[4], mid_blk[2], dec[4], c_enc[4], c_mid[2];
-    rohm::ConvW cond_down[3], diff_down[4], c_down[4];
-    rohm::UpW up[4];
-    rohm::BlockW final_blk;
-    rohm::ConvW final_conv, c_zero0, c_zero[4], c_zero_mid;
-};
-
-namespace rohm {
-
-__device__ __forceinline__ float mishf(float x) {
-    // x * tanh(softplus(x)), softplus with torch's threshold 20 (model/heads.py:104, nn.Mish).  With e = exp(x):
-    // tanh(log(1 + e)) = ((1 + e)^2 - 1) / ((1 + e)^2 + 1) = n / (n + 2), n = e (e + 2) -- one exp and one division instead
-    // of expf + log1pf + tanhf (~150 VALU instructions per value in the library form, the bulk of the GroupNorm
-    // kernel's time with one wave per SIMD); within 1 ulp of the library form over [-100, 100] (checked on the host).
-    const float e = __expf(fminf(x, 20.f));
-    const float n = e * (e + 2.f);
-    const float r = x * __fdividef(n, n + 2.f);
-    return (x > 20.f) ? x : r;
-}
 
 // ------------------------------------------------------------------------------------------------ kernels
 // pad [rows, cin] -> [rows, cpad] (zeros beyond cin)
@@ -419,8 +365,8 @@ static inline size_t al(size_t n) { return (n + 63) / 64 * 64; }
 // caller's workspace; forward() publishes it here for the launch helpers of this host thread.
 constexpr size_t kSplitKFloats = (size_t)256 * 144 * 128;
 constexpr size_t kFuseMaxWork = (size_t)64 * 144 * 64;   // rows x channels of a level up to which the fused conv forms pay (B <= 64)
-constexpr int kTbSteps = 128;             // loop steps whose time path is evaluated by one launch
 constexpr int kGraphMaxSteps = 1024;       // steps per sample-loop call that the captured-graph path accepts
+static thread_local int tl_loop_mode = 0;             // form the last sample loop of this host thread ran in (rohm_trajnet_loop_mode)
 static thread_local float* tl_splitk = nullptr;       // partial slabs of the conv feeding the next kernel
 static thread_local float* tl_splitk_res = nullptr;   // partial slabs of a block's 1x1 residual conv (alive until its 2nd GroupNorm)
 
@@ -573,7 +519,6 @@ static int gn(const BlockW& bw, const float* y, int ldy, const SplitInfo& sy, in
     return ROHM_OK;
 }
 
-struct Scratch { float *ya, *hb, *rc; };   // conv output, block-0 activation, 1x1 residual
 
 // ResidualTemporalBlock (heads.py:43-54)
 static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int ldx, int B, int T, const float* tb_all,
@@ -612,28 +557,6 @@ static int res_block(const rohm_trajnet* h, const ResW& r, const float* x, int l
     return gn(r.b1, sc.ya, co, s1, B, T, nullptr, 0, res, ldres, sr, r.res.b, add2, ldadd2, dst, lddst, dst2, lddst2, s);
 }
 
-// ---- workspace ---------------------------------------------------------------------------------------------
-struct TWs {
-    float *xin, *cin, *ctl;                 // padded inputs [M,32], [M,32], [M,288]
-    float *cat[4], *dcat[4], *ccat[4];      // concat buffers (see forward)
-    float *cdn[3], *ddn[4], *kdn[4];        // outputs of the down convs (cond / diff / control)
-    float *mid_a, *mid_b, *kmid_a, *kmid_b;
-    float *d[4];                            // decoder block outputs
-    float *cz, *ctrl[4], *ctrl_mid;         // control residuals
-    float *ctrl_b[4], *ctrl_mid_b;          // ... second set: the ControlNet branch of the sample loop runs one step ahead on its own stream
-    Scratch sc_ctl;                         // ... with its own block scratch and split-K slabs
-    float *splitk_ctl, *splitk_res_ctl;
-    float *fin;                             // final conv block output [M, 32]
-    float *tb_all;                          // [B or 1][tb_total]
-    float *tb_steps;                        // [kTbSteps][tb_total]: time biases of a run of loop steps (one launch)
-    Scratch sc;
-    float *x0, *cond_keep;                  // loop: network output [B,T,13]
-    float *splitk, *splitk_res;             // split-K partial tiles (plan_split)
-    float *step_coef;                       // graph replay: (c1, c2, sigma) per step, timesteps, step counter
-    int64_t* step_t;
-    int* step_ctr;
-    size_t floats;
-};
 
 static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     const int m = h->mid;
@@ -681,6 +604,7 @@ static TWs carve_t(const rohm_trajnet* h, int B, int T, float* base) {
     w.step_coef = take(3 * (size_t)kGraphMaxSteps);
     w.step_t = reinterpret_cast<int64_t*>(take(2 * (size_t)kGraphMaxSteps));
     w.step_ctr = reinterpret_cast<int*>(take(16));
+    w.resident = take(resident_floats(B, T));
     w.floats = off;
     return w;
 }
@@ -823,6 +747,17 @@ static int run_time_path(const rohm_trajnet* h, const TWs& w, const int64_t* t_d
     prof::Scope ps("time_path", 0.0, 4.0 * h->tb_total * h->tdim, s);
     hipLaunchKernelGGL(time_path_kernel, dim3(rows), dim3(256), 0, s, t_dev, t_host, t_tab, step_ctr, h->tdim, h->t_w1T, h->t_b1, h->t_w3T,
                        h->t_b3, h->tb_wT, h->tb_b, h->tb_total, w.tb_all);
+    ROHM_LAUNCH_CHECK();
+    return ROHM_OK;
+}
+
+// the time path depends on t only (trajnet.py:120-125, heads.py:35-38): one launch covers a run of loop steps (37 us per step before)
+int launch_time_path_steps(const rohm_trajnet* h, const TWs& w, const int64_t* t, int run, hipStream_t s) {
+    ROHM_HIP_CHECK(hipMemcpyAsync(w.step_t, t, (size_t)run * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    prof::Scope ps("time_path", 0.0, 4.0 * h->tb_total * h->tdim * run, s);
+    hipLaunchKernelGGL(time_path_kernel, dim3(run), dim3(256), 0, s, w.step_t, (int64_t)0, (const int64_t*)nullptr,
+                       (const int*)nullptr, h->tdim, h->t_w1T, h->t_b1, h->t_w3T, h->t_b3, h->tb_wT, h->tb_b,
+                       h->tb_total, w.tb_steps);
     ROHM_LAUNCH_CHECK();
     return ROHM_OK;
 }
@@ -1170,6 +1105,9 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
     }
     hipError_t se = hipDeviceSynchronize();
     for (float* d : staged) (void)hipFree(d);
+    // the clip-resident sample loop meets through L2 inside a launch: is this device laid out the way it assumes?  (probe launch, once
+    // per device and process: exchange.hip; a refusal only means the launch-per-layer loop is used)
+    { const char* why = nullptr; (void)exchange_layout_ok(device, &why); }
     if (ok && se != hipSuccess) { ok = false; err = hipGetErrorString(se); }
     if (!ok) {
         set_error("trajnet_create: %s", err.c_str());
@@ -1180,6 +1118,8 @@ int rohm_trajnet_create(rohm_trajnet_t** out, const rohm_trajnet_weights* wts, i
     *out = h;
     return ROHM_OK;
 }
+
+int rohm_trajnet_loop_mode(void) { return tl_loop_mode; }
 
 int rohm_trajnet_tune(int conv_wg_per_cu, int split_min_chunks, int split_pow2) {
     ROHM_ARG_CHECK(conv_wg_per_cu >= 1 && conv_wg_per_cu <= 2 && split_min_chunks >= 1 && split_min_chunks <= 64,
@@ -1252,6 +1192,7 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
     }
     tl_splitk = w.splitk;
     tl_splitk_res = w.splitk_res;
+    tl_loop_mode = 0;
     { const char* e = getenv("ROHM_TRAJ_RES_TAP"); g_res_centre_tap.store(!(e && e[0] == '0'), std::memory_order_relaxed); }
     const size_t M = (size_t)B * T, n = M * h->ctraj;
     // cond / control_cond do not change over the loop: pad them and run the (time-free) cond encoder once
@@ -1268,12 +1209,23 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
         // the per-step values (timestep, c1 / c2 / sigma, noise slice) from device tables through a device-side step
         // counter, and the graph is replayed for the remaining steps.
         rc = sample_loop_graph(h, w, x, noise, t_model, coef, x0_last, x_in_last, n_steps, B, T, M, n, s);
+        if (rc == ROHM_OK) tl_loop_mode = 2;
         if (rc != ROHM_ERR_UNSUPPORTED) return rc;
         // capture not available on this stream / runtime: fall through to the plain loop
     }
     if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;     // x_T; the tail kernel keeps the padded copy current
+    bool control_pre_done = false;
+    if (resident_ok(h, B, T, n_steps, s)) {
+        // clip-resident form (trajnet_resident.hip): ONE launch per step, the XCD's workgroups stay with its clips through the whole
+        // U-Net (+ ControlNet branch).  A wait that expired (another tenant, a CU mask set after the probe) hands the call back: x is x_T again.
+        if (h->control) { if ((rc = run_control_pre(h, w, B, T, s))) return rc; control_pre_done = true; }
+        rc = resident_loop(h, w, x, noise, t_model, coef, x0_last, x_in_last, n_steps, B, T, s);
+        if (rc == ROHM_OK) tl_loop_mode = 1;
+        if (rc != ROHM_ERR_UNSUPPORTED) return rc;
+        if ((rc = pad_rows(x, w.xin, M, h->ctraj, kPadC, s))) return rc;
+    }
     SideStream* ss = h->control ? side_stream(h->device) : nullptr;
-    if (ss && (rc = run_control_pre(h, w, B, T, s))) return rc;           // control_zero_conv_0(control_cond): once per loop
+    if (ss && !control_pre_done && (rc = run_control_pre(h, w, B, T, s))) return rc;           // control_zero_conv_0(control_cond): once per loop
     // an early return must not leave side-stream work behind that still reads / writes the caller-owned workspace un-ordered
     // against the caller's stream: join s2 into s first
     auto fail = [&](int code) {
@@ -1290,12 +1242,7 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
             // the time path depends on t only (trajnet.py:120-125, heads.py:35-38): one launch covers the next run of
             // steps (37 us per step before)
             const int run = (n_steps - i < kTbSteps) ? n_steps - i : kTbSteps;
-            ROHM_HIP_CHECK(hipMemcpyAsync(w.step_t, t_model + i, (size_t)run * sizeof(int64_t), hipMemcpyHostToDevice, s));
-            prof::Scope ps("time_path", 0.0, 4.0 * h->tb_total * h->tdim * run, s);
-            hipLaunchKernelGGL(time_path_kernel, dim3(run), dim3(256), 0, s, w.step_t, (int64_t)0, (const int64_t*)nullptr,
-                               (const int*)nullptr, h->tdim, h->t_w1T, h->t_b1, h->t_w3T, h->t_b3, h->tb_wT, h->tb_b,
-                               h->tb_total, w.tb_steps);
-            ROHM_LAUNCH_CHECK();
+            if ((rc = launch_time_path_steps(h, w, t_model + i, run, s))) return rc;
         }
         const float* tb_row = w.tb_steps + (size_t)(i % kTbSteps) * h->tb_total;
         if (ss) {

@@ -1,0 +1,775 @@
+// TrajNet / TrajControl sample loop, CLIP-RESIDENT form: one launch per denoising step (model/trajnet.py:177-275, model/heads.py:12-106,
+// diffusion/gaussian_diffusion_trajnet.py:440-466, 559-627).
+//
+// Why: the launch-per-layer loop (trajnet.hip) is 59 (TrajNet) / 86 (TrajControl) DEPENDENT kernels per step, each a few microseconds
+// of work behind ~4 us of dispatch + drain -- 41 ms per 100 steps for one clip, 56 ms for 32 (profiles/r6_z_trajnet_loop.json).  A
+// grid-wide barrier costs what a kernel boundary costs on this part (8 L2s, MI355X_MICROARCH.md "barrier-xcd" 4-5 us), so the step
+// is NOT one grid-synchronised kernel.  Instead the dependency structure is used: clips never talk to each other, only the layers of
+// ONE clip do.  An XCD owns a contiguous run of clips for the whole step; its 32 workgroups (block b runs on XCD b % 8) compute every
+// layer of those clips and meet between layers through the flags of encoder_chain.hip's group_sync -- one L2, no cache maintenance:
+// ~1 us per meeting.  Weights are read by every XCD (8 x 90 MB per step at the outside, served by the memory-side cache); activations
+// never leave the owner's L2.
+//
+// Work item of a layer = (a run of q clips of the XCD, one block of 16 output channels): the GEMM  rows = q x T_level conv positions,
+// 16 columns, K = taps x C_in.  The INPUT rows of the item are staged once per 64-channel K chunk with a two-row zero halo per clip
+// (LDS-DMA, sc1: partners wrote them in this launch), and the taps are row offsets into that image -- no gathered operand, the five
+// taps of a conv re-use one staged tile.  The four waves split K (wave w takes channels 16 w .. 16 w + 15 of every chunk and tap), the
+// partial accumulators meet in LDS, and the epilogue -- bias, GroupNorm(8) over (C/8 channels x T) per clip, Mish, time bias, residual,
+// control residual (heads.py:43-54, 98-104) -- runs on the summed tile: a GroupNorm group is inside the item for C <= 128 and shared by
+// 2 / 4 neighbouring items for C = 256 / 512, which exchange (mean, M2) granules through L2 and merge them in a fixed tree (Chan), the
+// discipline of gemm_f32.hip's EPI_BIAS_RES_LN.  A ResidualTemporalBlock is two layers (its 1x1 residual conv rides along the first as
+// a sixth "tap" on the centre row), the transposed conv two tap-pairs on one staged tile, the head + ancestral update the closing
+// layer: 30 meetings per TrajNet step instead of 59 launches, 32 instead of 86 for TrajControl (its ControlNet branch runs in the same
+// slots as the U-Net encoder, on other workgroups).
+//
+// Guards: exchange.hip's layout probe (whole device, block b on XCD b % 8), bounded waits that report into an error word; the host
+// checks it at the end of the loop, restores x_T and hands the call to the launch-per-layer loop if a wait expired.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "trajnet_priv.h"
+
+namespace rohm {
+namespace res {
+
+constexpr int kWG = 32;                        // workgroups per XCD
+constexpr int kMaxRB = 10;                     // 16-row blocks of conv positions per item
+constexpr int kMaxRows = kMaxRB * 16;
+constexpr int kMaxLdsRows = 176;               // staged input rows per item: clips x (T_in + 4), rounded up to the 16 rows of a DMA pass
+constexpr int kAIters = kMaxLdsRows / 16;
+constexpr int kKC = 64;                        // input channels per K chunk
+constexpr int kMaxTaps = 5;
+constexpr int kWRows = (kMaxTaps + 1) * 16;    // weight rows per chunk: taps x 16 columns, + 16 of the 1x1 residual conv
+constexpr int kABuf = kMaxLdsRows * kKC;       // floats
+constexpr int kWBuf = kWRows * kKC;
+constexpr int kStage = 2 * (kABuf + kWBuf);    // two staging buffers; after the K loop the same floats hold the waves' partial tiles
+constexpr int kRed = 4 * kMaxRows * 16;        // [wave][row][16]
+static_assert(2 * kRed <= kStage, "the partial tiles of conv + residual must fit the staging buffers");
+constexpr int kLdsFloats = kStage + 1024;      // + row sums [160][4], statistics [16][4] x 2
+constexpr int kMaxSync = 64, kMaxItems = 256, kMaxOps = 96, kMaxQ = 16, kMaxStages = 8;
+
+struct ROp {
+    int kind;                                  // 0 conv layer, 1 head + update
+    int cout, cin_pad, t_in, t_out, stride, ntaps;
+    int off[kMaxTaps];
+    int lda, ldw, omul, oadd, t_dst;
+    int gn;                                    // GroupNorm group width in channels (0: none -> y = conv + bias)
+    int tb_off;                                // time bias columns inside the step's row (-1: none)
+    int ldres, ldadd2, lddst, lddst2, ld_res_out;
+    int q, wg_off, sync_after;
+    int slot_base;                             // first statistics slot of this layer (layers between two meetings use disjoint slots)
+    const float* A; const float* W; const float* bias;
+    const float* Wres; const float* bres; float* res_out;      // fused 1x1 residual conv of the same input (null: none)
+    const float* gamma; const float* beta;
+    const float* res; const float* add2;
+    float* dst; float* dst2;
+};
+
+struct RParams {
+    const ROp* ops; int n_ops;
+    int B, T, n_per_xcd;
+    const float* tb_row;
+    const float* zero_page;
+    unsigned long long* flags;                 // [8 XCDs][kMaxSync][32]
+    unsigned long long* slots;                 // [8 XCDs][kMaxItems][kMaxQ][2]
+    unsigned* err;
+    unsigned tag_base;                         // (step + 1) << 8: tags of this launch = tag_base + meeting / layer index
+    // head + ancestral update (trajnet.hip traj_tail_kernel's arithmetic)
+    const float* fin; int ldfin; const float* hw; int ldhw; int hcin; const float* hb; int ctraj;
+    float* x; float* xin; int ldxin; float* x0_out; const float* noise; float c1, c2, sigma;
+    // diagnostics (null on every product path): lane 0 of every workgroup stamps the 100 MHz clock at the seams of every layer into
+    // timeline[(block * kMaxOps + layer) * 8 + k]: 0 layer entered, 1 operand addresses of its (last) item ready, 2 K loop done,
+    // 3 partial tiles summed, 4 epilogue done, 5 met (ROHM_TRAJ_RESIDENT_TIMELINE=1 prints the last step's table)
+    unsigned long long* timeline;
+    int fault;                                 // test hook (ROHM_TRAJ_RESIDENT_FAULT=1): workgroup 0 of XCD 0 stays away from the fourth meeting
+};
+
+__device__ __forceinline__ int lds_off64(int row, int slot) { return row * kKC + ((slot ^ (row & 15)) << 2); }
+
+__device__ __forceinline__ f32x4 ld16_l2(const float* p) {      // 16 bytes another workgroup of the XCD may have written in this launch: past the L1
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
+}
+
+// error word: low byte 1 = a bounded wait expired, 2 = a partner published from another XCD; bits 8.. = where (meeting index, or
+// 0x80 | layer index for a statistics exchange)
+__device__ __forceinline__ bool wait_tag(const unsigned long long* p, unsigned tag, unsigned* err, unsigned where, unsigned long long* out) {
+    for (int it = 0;; ++it) {
+        const unsigned long long f = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(f >> 32) == tag) { *out = f; return true; }
+        __builtin_amdgcn_s_sleep(1);
+        if ((it & 127) == 127 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if (it > (1 << 19)) { __hip_atomic_store(err, 1u | (where << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    }
+}
+
+// The 32 workgroups of an XCD meet: everybody's stores of the layer are in the XCD's L2 before anybody reads them (encoder_chain.hip
+// group_sync with 32 partners; no acquire: every partner-written operand is read past the L1 -- LDS-DMA sc1, ld16_l2).
+__device__ __forceinline__ void xcd_sync(unsigned long long* flags, int j, unsigned tag, unsigned xcc1, unsigned* err, unsigned where, int tid, bool absent) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && !absent) __hip_atomic_store(flags + j, ((unsigned long long)tag << 32) | xcc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < kWG && tid != j) {
+        unsigned long long f;
+        if (wait_tag(flags + tid, tag, err, where, &f) && (unsigned)f != xcc1) __hip_atomic_store(err, 2u | (where << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define ROHM_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        ROHM_VMC(0) ROHM_VMC(1) ROHM_VMC(2) ROHM_VMC(3) ROHM_VMC(4) ROHM_VMC(5) ROHM_VMC(6) ROHM_VMC(7) ROHM_VMC(8) ROHM_VMC(9)
+        ROHM_VMC(10) ROHM_VMC(11) ROHM_VMC(12) ROHM_VMC(13) ROHM_VMC(14) ROHM_VMC(15) ROHM_VMC(16) ROHM_VMC(17) ROHM_VMC(18) ROHM_VMC(19)
+        ROHM_VMC(20) ROHM_VMC(21) ROHM_VMC(22) ROHM_VMC(23) ROHM_VMC(24) ROHM_VMC(25) ROHM_VMC(26) ROHM_VMC(27) ROHM_VMC(28) ROHM_VMC(29)
+        ROHM_VMC(30) ROHM_VMC(31) ROHM_VMC(32) ROHM_VMC(33) ROHM_VMC(34) ROHM_VMC(35) ROHM_VMC(36) ROHM_VMC(37) ROHM_VMC(38) ROHM_VMC(39)
+        ROHM_VMC(40) ROHM_VMC(41) ROHM_VMC(42) ROHM_VMC(43) ROHM_VMC(44) ROHM_VMC(45) ROHM_VMC(46) ROHM_VMC(47) ROHM_VMC(48) ROHM_VMC(49)
+        ROHM_VMC(50) ROHM_VMC(51) ROHM_VMC(52) ROHM_VMC(53) ROHM_VMC(54) ROHM_VMC(55) ROHM_VMC(56) ROHM_VMC(57) ROHM_VMC(58) ROHM_VMC(59)
+        ROHM_VMC(60) ROHM_VMC(61) ROHM_VMC(62) ROHM_VMC(63)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef ROHM_VMC
+}
+
+__device__ __forceinline__ float sum16(float v) {      // all-lanes sum of a 16-lane row
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+// One (clip run, 16-column block) item of a conv layer.
+__device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const int oi, const int id, const int xcd, const int c_lo, const int nx,
+                                          float* smem, const int tid, unsigned long long* const tl) {
+    auto stamp = [&](int k) __attribute__((always_inline)) { if (tl != nullptr && threadIdx.x == 0) tl[k] = __builtin_amdgcn_s_memrealtime(); };
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+    const int ncb = op.cout >> 4;
+    const int cg = id / ncb, cb = id - cg * ncb;
+    const int k0 = cg * op.q;
+    const int qi = min(op.q, nx - k0);
+    const int clip0 = c_lo + k0;
+    const int t_in = op.t_in, t_out = op.t_out, stride = op.stride;
+    const int rows = qi * t_out, nrb = (rows + 15) >> 4, RM = nrb * 16;
+    const int rstride = t_in + 4, lrows = qi * rstride, a_iters = (lrows + 15) >> 4;
+    const int nt = op.ntaps;
+    const bool has_res = op.Wres != nullptr;
+    const int ntt = nt + (has_res ? 1 : 0);
+    const int nch = op.cin_pad / kKC;
+    const int col0 = cb * 16;
+
+    // staging ring: a stage = the item's input rows (whole 16-row DMA passes) + its weight rows of ONE 64-channel chunk; as many
+    // stages as the LDS holds (2 at level 0 .. 8 for a 1x1 conv at the deep levels): the weights stream from HBM / the memory-side
+    // cache at ~2.5 us a round trip, so a deep-level layer (8 .. 16 chunks of < 1 us of MFMAs each) lives on the chunks in flight
+    const int per_chunk = a_iters + ntt;               // DMA instructions per chunk and wave
+    const int stage_f = per_chunk * 16 * kKC;
+    int NS = min(kMaxStages, kStage / stage_f);
+    NS = min(NS, nch + 1);
+    while (NS > 2 && (NS - 2) * per_chunk > 63) --NS;  // s_waitcnt vmcnt counts to 63
+    const int pre = min(NS - 1, nch);                  // chunks in flight ahead of the one being multiplied
+    // ---- operand addresses of chunk 0 (16-byte units; unit u of a DMA pass lands at LDS position u: the global side is swizzled) ------
+    const float* a_src[kAIters];
+    unsigned a_real = 0u;                              // bit it: this lane's unit of pass it is a real input row (else: halo / padding -> zeros)
+#pragma unroll
+    for (int it = 0; it < kAIters; ++it) {
+        const int u = it * 256 + tid, row = u >> 4, slot = (u & 15) ^ (row & 15);
+        const int k = row / rstride, t = row - k * rstride - 2;
+        const bool real = row < lrows && t >= 0 && t < t_in;
+        a_src[it] = real ? op.A + ((size_t)(clip0 + k) * t_in + t) * op.lda + slot * 4 : p.zero_page + slot * 4;
+        a_real |= real ? (1u << it) : 0u;
+    }
+    const float* w_src[kMaxTaps + 1];
+    {
+        const int col = tid >> 4, slot = (tid & 15) ^ col;      // row of pass `tap` = tap * 16 + col: (row & 15) == col
+#pragma unroll
+        for (int tp = 0; tp < kMaxTaps + 1; ++tp) {
+            w_src[tp] = (tp < nt) ? op.W + (size_t)(col0 + col) * op.ldw + tp * op.cin_pad + slot * 4
+                                  : (has_res ? op.Wres + (size_t)(col0 + col) * op.cin_pad + slot * 4 : p.zero_page);
+        }
+    }
+    auto dma = [&](int stage, int kc) __attribute__((always_inline)) {
+        float* const Ab = smem + stage * stage_f;
+        float* const Wb = Ab + a_iters * 16 * kKC;
+#pragma unroll
+        for (int it = 0; it < kAIters; ++it)
+            if (it < a_iters)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[it] + (((a_real >> it) & 1u) ? kc * kKC : 0)),
+                                                 (__attribute__((address_space(3))) void*)(Ab + (it * 256 + wave * 64) * 4), 16, 0, 16);
+#pragma unroll
+        for (int tp = 0; tp < kMaxTaps + 1; ++tp)
+            if (tp < ntt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[tp] + kc * kKC),
+                                                 (__attribute__((address_space(3))) void*)(Wb + (tp * 256 + wave * 64) * 4), 16, 0, 0);
+    };
+
+    // ---- fragment rows: conv position o = 16 r + li of the item -> staged row of its centre tap ------------------------------------
+    int base[kMaxRB];
+#pragma unroll
+    for (int r = 0; r < kMaxRB; ++r) {
+        const int o = min(r * 16 + li, rows - 1);      // positions past the item's last repeat it (never stored, never counted)
+        const int k = o / t_out, tq = o - k * t_out;
+        base[r] = k * rstride + 2 + tq * stride;
+    }
+    f32x4 acc[kMaxRB], accr[kMaxRB];
+#pragma unroll
+    for (int r = 0; r < kMaxRB; ++r) acc[r] = accr[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stamp(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the previous item's stores: the counted waits below are about this item's DMAs only)
+    __syncthreads();                                   // the previous item's partial tiles (same LDS) have been consumed
+    for (int c = 0; c < pre; ++c) dma(c, c);
+    const int kslot = 4 * wave + lg;                   // this lane's 16-byte slot of a 64-channel row: wave w contracts channels 16 w ..
+    int st = 0;                                        // stage of chunk kc
+    for (int kc = 0; kc < nch; ++kc) {
+        wait_vmcnt(min(pre - 1, nch - 1 - kc) * per_chunk);      // chunk kc has landed; the younger ones may still be on their way
+        __syncthreads();                               // ... for everybody; everybody is done with chunk kc - 1
+        if (kc + pre < nch) { const int sn = st + pre; dma(sn >= NS ? sn - NS : sn, kc + pre); }      // pre == NS - 1: the stage of chunk kc - 1
+        const float* Ab = smem + st * stage_f;
+        const float* Wb = Ab + a_iters * 16 * kKC;
+        st = (st + 1 == NS) ? 0 : st + 1;
+#pragma unroll
+        for (int tp = 0; tp < kMaxTaps; ++tp) {
+            if (tp < nt) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(Wb + lds_off64(tp * 16 + li, kslot));
+                const int shift = op.off[tp];
+#pragma unroll
+                for (int r = 0; r < kMaxRB; ++r)
+                    if (r < nrb) {
+                        const f32x4 af = *reinterpret_cast<const f32x4*>(Ab + lds_off64(base[r] + shift, kslot));
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jj], af[jj], acc[r], 0, 0, 0);
+                    }
+            }
+        }
+        if (has_res) {
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(Wb + lds_off64(nt * 16 + li, kslot));
+#pragma unroll
+            for (int r = 0; r < kMaxRB; ++r)
+                if (r < nrb) {
+                    const f32x4 af = *reinterpret_cast<const f32x4*>(Ab + lds_off64(base[r], kslot));
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) accr[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jj], af[jj], accr[r], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();                                   // every wave is done with the staging buffers
+    stamp(2);
+
+    // ---- the four K slices meet: red[wave][row][16] ---------------------------------------------------------------------------------
+    float* const red = smem;
+    float* const redr = smem + kRed;
+#pragma unroll
+    for (int r = 0; r < kMaxRB; ++r)
+        if (r < nrb) {
+            *reinterpret_cast<f32x4*>(red + ((wave * RM + r * 16 + li) * 16 + lg * 4)) = acc[r];
+            if (has_res) *reinterpret_cast<f32x4*>(redr + ((wave * RM + r * 16 + li) * 16 + lg * 4)) = accr[r];
+        }
+    __syncthreads();
+    float* const rowsum = smem + kStage;               // [160][4]
+    float* const stat = rowsum + kMaxRows * 4;         // [16 pairs][2]: mean, rstd (or M2 on the way)
+    constexpr int NU = 3;                              // 16-byte units per thread: rows x 4 <= 640
+    f32x4 v[NU];
+    int urow[NU], uclip[NU];
+    bool uok[NU];
+    const int c4 = (tid & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int e = tid + 256 * i, o = e >> 2;
+        uok[i] = o < rows;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        urow[i] = 0; uclip[i] = 0;
+        if (uok[i]) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(op.bias + col0 + c4);
+            f32x4 s = *reinterpret_cast<const f32x4*>(red + ((0 * RM + o) * 16 + c4));
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(red + ((w * RM + o) * 16 + c4));
+#pragma unroll
+                for (int x = 0; x < 4; ++x) s[x] += t[x];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[i][x] = s[x] + b4[x];
+            const int k = o / t_out, tq = o - k * t_out;
+            uclip[i] = k;
+            urow[i] = (clip0 + k) * op.t_dst + tq * op.omul + op.oadd;
+            if (has_res) {      // the 1x1 residual conv of the block's input, raw: the block's second layer adds it
+                const f32x4 rb = *reinterpret_cast<const f32x4*>(op.bres + col0 + c4);
+                f32x4 sr = *reinterpret_cast<const f32x4*>(redr + ((0 * RM + o) * 16 + c4));
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(redr + ((w * RM + o) * 16 + c4));
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) sr[x] += t[x];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) sr[x] += rb[x];
+                *reinterpret_cast<f32x4*>(op.res_out + (size_t)((clip0 + k) * t_out + tq) * op.ld_res_out + col0 + c4) = sr;
+            }
+        }
+    }
+
+    stamp(3);
+    if (op.gn == 0) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+            if (uok[i]) *reinterpret_cast<f32x4*>(op.dst + (size_t)urow[i] * op.lddst + col0 + c4) = v[i];
+        stamp(4);
+        return;
+    }
+
+    // ---- GroupNorm over (group channels x T) per clip: two passes (mean, centred squares), fixed summation order ---------------------
+    const int gw = op.gn, gl = min(gw, 16), ngl = 16 / gl;       // local groups of this 16-column block: 4 / 2 / 1
+    const int ugrp = (gl == 4) ? (tid & 3) : (gl == 8 ? ((tid & 3) >> 1) : 0);
+    const int npairs = qi * ngl;                                 // <= 16: (clip, local group)
+    auto quad_sum = [&](float s) {                               // sum over the units of a row that share a local group
+        if (gl >= 8) s += __shfl_xor(s, 1);
+        if (gl >= 16) s += __shfl_xor(s, 2);
+        return s;
+    };
+    auto pair_total = [&]() {                                    // rowsum[row][local group] -> sum over the clip's rows, every lane of the pair's 16
+        const int pi = tid >> 4, l16 = tid & 15;
+        float s = 0.f;
+        if (pi < npairs) {
+            const int k = pi / ngl, g = pi - k * ngl;
+            for (int t = l16; t < t_out; t += 16) s += rowsum[(k * t_out + t) * 4 + g];
+        }
+        return sum16(s);
+    };
+    const float inv_n = 1.0f / (float)(t_out * gl);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const float s = quad_sum((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
+        if (uok[i]) rowsum[((tid + 256 * i) >> 2) * 4 + ugrp] = s;
+    }
+    __syncthreads();
+    {
+        const float tot = pair_total();
+        if ((tid >> 4) < npairs && (tid & 15) == 0) stat[(tid >> 4) * 2] = tot * inv_n;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const float m = stat[(uclip[i] * ngl + ugrp) * 2];
+        float s = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { const float d = v[i][x] - m; s += d * d; }
+        s = quad_sum(s);
+        if (uok[i]) rowsum[((tid + 256 * i) >> 2) * 4 + ugrp] = s;
+    }
+    __syncthreads();
+    {
+        const float tot = pair_total();
+        if ((tid >> 4) < npairs && (tid & 15) == 0) stat[(tid >> 4) * 2 + 1] = tot;      // M2
+    }
+    __syncthreads();
+    if (gw > 16) {
+        // the group spans nparts = gw / 16 neighbouring column blocks (items id - part .. of the same clip run, resident at the same time
+        // on other workgroups of the XCD): exchange (mean, M2) per clip, merge in a fixed tree -- every partner gets the same bits
+        const int nparts = gw >> 4, part = cb & (nparts - 1);
+        const unsigned tag = p.tag_base + (unsigned)oi;
+        if (tid < qi) {
+            unsigned long long* const mine = p.slots + (((size_t)xcd * kMaxItems + op.slot_base + id) * kMaxQ + tid) * 2;
+            const float m = stat[tid * 2], q2 = stat[tid * 2 + 1];
+            __hip_atomic_store(mine, ((unsigned long long)tag << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, ((unsigned long long)tag << 32) | __float_as_uint(q2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float mk[4], qk[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                mk[pp] = 0.f; qk[pp] = 0.f;
+                if (pp >= nparts) continue;
+                if (pp == part) { mk[pp] = m; qk[pp] = q2; continue; }
+                const unsigned long long* theirs = p.slots + (((size_t)xcd * kMaxItems + op.slot_base + (id - part + pp)) * kMaxQ + tid) * 2;
+                unsigned long long a = 0ull, b = 0ull;
+                if (wait_tag(theirs, tag, p.err, 0x80u | (unsigned)oi, &a) && wait_tag(theirs + 1, tag, p.err, 0x80u | (unsigned)oi, &b)) {
+                    mk[pp] = __uint_as_float((unsigned)a); qk[pp] = __uint_as_float((unsigned)b);
+                }
+            }
+            auto merge = [](float ma, float qa, float mb, float qb, float n, float& mo, float& qo) {
+                const float d = mb - ma;
+                mo = 0.5f * (ma + mb);
+                qo = (qa + qb) + 0.5f * n * d * d;
+            };
+            const float n1 = (float)(t_out * 16);
+            merge(mk[0], qk[0], mk[1], qk[1], n1, mk[0], qk[0]);
+            if (nparts > 2) {
+                merge(mk[2], qk[2], mk[3], qk[3], n1, mk[2], qk[2]);
+                merge(mk[0], qk[0], mk[2], qk[2], 2.0f * n1, mk[0], qk[0]);
+            }
+            stat[tid * 2] = mk[0];
+            stat[tid * 2 + 1] = qk[0];
+        }
+        __syncthreads();
+    }
+    const float inv_ng = 1.0f / (float)(t_out * gw);
+    const float* const tb = op.tb_off >= 0 ? p.tb_row + op.tb_off + col0 + c4 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        if (!uok[i]) continue;
+        const int pr = (uclip[i] * ngl + ugrp) * 2;
+        const float m = stat[pr], rstd = 1.0f / sqrtf(stat[pr + 1] * inv_ng + 1e-5f);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(op.gamma + col0 + c4);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(op.beta + col0 + c4);
+        f32x4 o;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) o[x] = mishf((v[i][x] - m) * rstd * g4[x] + b4[x]);
+        if (tb) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(tb);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] += t4[x];
+        }
+        if (op.res) {
+            const f32x4 r4 = ld16_l2(op.res + (size_t)urow[i] * op.ldres + col0 + c4);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] += r4[x];
+        }
+        if (op.add2) {
+            const f32x4 r4 = ld16_l2(op.add2 + (size_t)urow[i] * op.ldadd2 + col0 + c4);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] += r4[x];
+        }
+        *reinterpret_cast<f32x4*>(op.dst + (size_t)urow[i] * op.lddst + col0 + c4) = o;
+        if (op.dst2) *reinterpret_cast<f32x4*>(op.dst2 + (size_t)urow[i] * op.lddst2 + col0 + c4) = o;
+    }
+    stamp(4);
+}
+
+// Head Conv1d(32, c_traj, 1) + ancestral update + the padded copy of x_{t-1} for the next step (trajnet.py:158-161,
+// gaussian_diffusion_trajnet.py:440-466) for the XCD's clips: one thread per (row, channel).
+__device__ __forceinline__ void tail_op(const RParams& p, const int j, const int c_lo, const int nx, float* smem, const int tid) {
+    __syncthreads();
+    float* const ws = smem;      // [ctraj][hcin + 1]
+    for (int i = tid; i < p.ctraj * p.hcin; i += 256) ws[(i / p.hcin) * (p.hcin + 1) + i % p.hcin] = p.hw[(size_t)(i / p.hcin) * p.ldhw + i % p.hcin];
+    __syncthreads();
+    const float* noise = (p.sigma == 0.f) ? nullptr : p.noise;
+    const size_t m0 = (size_t)c_lo * p.T, n = (size_t)nx * p.T * p.ctraj;
+    for (size_t e = (size_t)j * 256 + tid; e < n; e += (size_t)kWG * 256) {
+        const size_t m = m0 + e / p.ctraj;
+        const int c = (int)(e % p.ctraj);
+        const size_t i = m * p.ctraj + c;
+        const float* f = p.fin + m * p.ldfin;
+        const float* wc = ws + c * (p.hcin + 1);
+        float acc = 0.f;
+        for (int k = 0; k < p.hcin; k += 4) {
+            const f32x4 fv = ld16_l2(f + k);
+            acc = fmaf(fv[0], wc[k], acc); acc = fmaf(fv[1], wc[k + 1], acc);
+            acc = fmaf(fv[2], wc[k + 2], acc); acc = fmaf(fv[3], wc[k + 3], acc);
+        }
+        const float x0 = acc + p.hb[c];
+        if (p.x0_out) p.x0_out[i] = x0;
+        float vv = p.c1 * x0 + p.c2 * p.x[i];
+        if (noise) vv += p.sigma * noise[i];
+        p.x[i] = vv;
+        p.xin[m * p.ldxin + c] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void traj_resident_kernel(RParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+    const int c_lo = xcd * p.n_per_xcd, nx = min(p.B - c_lo, p.n_per_xcd);
+    if (nx <= 0) return;
+    if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // an earlier step's wait expired: the host re-runs the loop
+    const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+    int sync_idx = 0;
+#pragma unroll 1
+    for (int oi = 0; oi < p.n_ops; ++oi) {
+        const ROp& op = p.ops[oi];
+        unsigned long long* const tl = p.timeline ? p.timeline + ((size_t)blockIdx.x * kMaxOps + oi) * 8 : nullptr;
+        if (tl != nullptr && threadIdx.x == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
+        if (op.kind == 1) {
+            tail_op(p, j, c_lo, nx, smem, tid);
+        } else {
+            const int n_items = ((nx + op.q - 1) / op.q) * (op.cout >> 4);
+#pragma unroll 1
+            for (int id = (j + kWG - op.wg_off) & (kWG - 1); id < n_items; id += kWG) {
+                int t = tid;
+                asm volatile("" : "+v"(t));      // per-item address arithmetic stays inside the item (no hoisting across the layer loop)
+                conv_item(p, op, oi, id, xcd, c_lo, nx, smem, t, tl);
+            }
+        }
+        if (op.sync_after) {
+            xcd_sync(p.flags + ((size_t)xcd * kMaxSync + sync_idx) * kWG, j, p.tag_base + (unsigned)sync_idx, xcc1, p.err, (unsigned)sync_idx, tid,
+                     p.fault != 0 && blockIdx.x == 0 && sync_idx == 3);
+            ++sync_idx;
+            if (tl != nullptr && threadIdx.x == 0) tl[5] = __builtin_amdgcn_s_memrealtime();
+            if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        }
+    }
+}
+
+// ---- host: the step as a list of layers --------------------------------------------------------------------------------------------
+struct Builder {
+    const rohm_trajnet* h; const TWs& w; int B, T, n;
+    std::vector<ROp> ops;
+    bool ok = true;
+
+    int pick_q(int t_in, int t_out, int ncb) const {
+        int qmax = std::min(std::min(n, kMaxQ), std::min(kMaxRows / t_out, kMaxLdsRows / (t_in + 4)));
+        if (qmax < 1) return 0;
+        for (int q = 1; q <= qmax; ++q)
+            if (((n + q - 1) / q) * ncb <= kWG) return q;      // fewest clips per item that keep the layer to one round of the XCD's workgroups
+        const int groups = (n + qmax - 1) / qmax;
+        return (n + groups - 1) / groups;
+    }
+    ROp conv(const ConvW& c, const float* A, int lda, int t_in, int t_out, int stride, int nt, const int* offs, float* dst, int lddst,
+             int t_dst, int omul = 1, int oadd = 0) {
+        ROp o;
+        memset(&o, 0, sizeof(o));
+        o.kind = 0; o.cout = c.cout; o.cin_pad = c.cin_pad; o.t_in = t_in; o.t_out = t_out; o.stride = stride; o.ntaps = nt;
+        for (int j = 0; j < nt; ++j) o.off[j] = offs[j];
+        o.lda = lda; o.ldw = (c.taps > 0 ? c.taps : 1) * c.cin_pad; o.omul = omul; o.oadd = oadd; o.t_dst = t_dst;
+        o.tb_off = -1; o.A = A; o.W = c.w; o.bias = c.b; o.dst = dst; o.lddst = lddst; o.sync_after = 1;
+        o.q = pick_q(t_in, t_out, c.cout / 16);
+        if (o.q < 1 || c.cout % 16 != 0 || c.cin_pad % kKC != 0 || ((n + o.q - 1) / o.q) * (c.cout / 16) > kMaxItems) ok = false;
+        return o;
+    }
+    // ResidualTemporalBlock (heads.py:43-54) as two layers
+    void res_block(const ResW& r, const float* x, int ldx, int Tl, const float* add2, int ldadd2, float* dst, int lddst, float* dst2, int lddst2,
+                   const Scratch& sc, std::vector<ROp>& out) {
+        static const int offs5[5] = {-2, -1, 0, 1, 2};
+        const int co = r.cout;
+        ROp a = conv(r.b0.conv, x, ldx, Tl, Tl, 1, 5, offs5, sc.hb, co, Tl);
+        a.gn = co / 8; a.gamma = r.b0.g; a.beta = r.b0.be; a.tb_off = r.tb_off;
+        if (r.has_res) { a.Wres = r.res.w; a.bres = r.res.b; a.res_out = sc.rc; a.ld_res_out = co; }
+        out.push_back(a);
+        ROp b = conv(r.b1.conv, sc.hb, co, Tl, Tl, 1, 5, offs5, dst, lddst, Tl);
+        b.gn = co / 8; b.gamma = r.b1.g; b.beta = r.b1.be;
+        if (r.has_res) { b.res = sc.rc; b.ldres = co; } else { b.res = x; b.ldres = ldx; }
+        b.add2 = add2; b.ldadd2 = ldadd2; b.dst2 = dst2; b.lddst2 = lddst2;
+        out.push_back(b);
+    }
+    void down(const ConvW& c, const float* x, int ldx, int Tl, float* dst, int lddst, std::vector<ROp>& out) {      // Conv1d(k3, s2, p1): heads.py:72-78
+        static const int offs[3] = {-1, 0, 1};
+        out.push_back(conv(c, x, ldx, Tl, Tl / 2, 2, 3, offs, dst, lddst, Tl / 2));
+    }
+    void conv1(const ConvW& c, const float* x, int ldx, int Tl, float* dst, int lddst, std::vector<ROp>& out) {
+        static const int offs[1] = {0};
+        out.push_back(conv(c, x, ldx, Tl, Tl, 1, 1, offs, dst, lddst, Tl));
+    }
+    void up(const UpW& u, const float* x, int ldx, int Tq, float* dst, int lddst, std::vector<ROp>& out) {      // ConvTranspose1d(k4, s2, p1): heads.py:81-87
+        static const int off_even[2] = {0, -1}, off_odd[2] = {1, 0};      // out[2t] = W1 x[t] + W3 x[t-1], out[2t+1] = W0 x[t+1] + W2 x[t]
+        ROp e = conv(u.even, x, ldx, Tq, Tq, 1, 2, off_even, dst, lddst, 2 * Tq, 2, 0);
+        e.sync_after = 0;
+        out.push_back(e);
+        out.push_back(conv(u.odd, x, ldx, Tq, Tq, 1, 2, off_odd, dst, lddst, 2 * Tq, 2, 1));
+    }
+
+    void build() {
+        const int m = h->mid;
+        const int ch[4] = {m / 8, m / 4, m / 2, m};
+        std::vector<ROp> U, C;
+        // U-Net encoder + first middle block (trajnet.py:211-237)
+        const float* x = w.xin;
+        int ldx = kPadC;
+        for (int i = 0; i < 4; ++i) {
+            const int Ti = T >> i;
+            res_block(h->diff_enc[i], x, ldx, Ti, nullptr, 0, w.cat[i], 2 * ch[i], w.dcat[i] + ch[i], 2 * ch[i], w.sc, U);
+            down(h->diff_down[i], w.cat[i], 2 * ch[i], Ti, w.ddn[i], 2 * ch[i], U);
+            x = w.ddn[i]; ldx = 2 * ch[i];
+        }
+        const int T16 = T >> 4;
+        res_block(h->mid_blk[0], w.ddn[3], 2 * m, T16, nullptr, 0, w.mid_a, m, nullptr, 0, w.sc, U);
+        const size_t u_before_ctrl = U.size() + 1;      // + the first layer of the second middle block: its second layer adds ctrl_mid
+        res_block(h->mid_blk[1], w.mid_a, m, T16, h->control ? w.ctrl_mid : nullptr, m, w.mid_b, m, nullptr, 0, w.sc, U);
+        x = w.mid_b; ldx = m;
+        for (int i = 3; i >= 0; --i) {
+            const int Ti = T >> i;
+            up(h->up[i], x, ldx, Ti / 2, w.dcat[i], 2 * ch[i], U);
+            const int co = (i == 0) ? 32 : ch[i - 1];
+            const int ldd = (i == 0) ? kPadC : co;
+            res_block(h->dec[i], w.dcat[i], 2 * ch[i], Ti, h->control ? w.ctrl[i] : nullptr, co, w.d[i], ldd, nullptr, 0, w.sc, U);
+            x = w.d[i]; ldx = ldd;
+        }
+        {   // head: Conv1dBlock(32, 32, k5), then Conv1d(32, c_traj, 1) + update (trajnet.py:158-161)
+            static const int offs5[5] = {-2, -1, 0, 1, 2};
+            ROp f = conv(h->final_blk.conv, w.d[0], kPadC, T, T, 1, 5, offs5, w.fin, kPadC, T);
+            f.gn = 4; f.gamma = h->final_blk.g; f.beta = h->final_blk.be;
+            U.push_back(f);
+            ROp t;
+            memset(&t, 0, sizeof(t));
+            t.kind = 1; t.q = 1; t.cout = 16;
+            U.push_back(t);
+        }
+        if (h->control) {      // ControlNet.forward (trajnet.py:43-75) behind control_zero_conv_0: depends on t and the conditions only
+            const float* cx = w.cz;
+            int ldc = kPadC;
+            for (int i = 0; i < 4; ++i) {
+                const int Ti = T >> i;
+                res_block(h->c_enc[i], cx, ldc, Ti, nullptr, 0, w.ccat[i], 2 * ch[i], nullptr, 0, w.sc_ctl, C);
+                conv1(h->c_zero[i], w.ccat[i], 2 * ch[i], Ti, w.ctrl[i], i == 0 ? 32 : ch[i - 1], C);
+                C.back().sync_after = 0;
+                down(h->c_down[i], w.ccat[i], 2 * ch[i], Ti, w.kdn[i], 2 * ch[i], C);
+                cx = w.kdn[i]; ldc = 2 * ch[i];
+            }
+            res_block(h->c_mid[0], w.kdn[3], 2 * m, T16, nullptr, 0, w.kmid_a, m, nullptr, 0, w.sc_ctl, C);
+            res_block(h->c_mid[1], w.kmid_a, m, T16, nullptr, 0, w.kmid_b, m, nullptr, 0, w.sc_ctl, C);
+            conv1(h->c_zero_mid, w.kmid_b, m, T16, w.ctrl_mid, m, C);
+        }
+        // merge: slot k = [ControlNet slot k | U-Net slot k] while the U-Net does not need the control residuals yet
+        size_t ui = 0, ci = 0;
+        auto take_slot = [&](std::vector<ROp>& src, size_t& i, bool sync, int wg_off) {      // ops up to and including the next sync_after op
+            int items = 0;
+            while (i < src.size()) {
+                ROp o = src[i++];
+                const bool last = o.sync_after != 0;
+                o.wg_off = (wg_off + items) & (kWG - 1) & ~3;
+                o.slot_base = wg_off + items;
+                items += o.kind == 0 ? ((n + o.q - 1) / o.q) * (o.cout / 16) : 0;
+                items = (items + 3) & ~3;
+                if (wg_off + items > kMaxItems) ok = false;
+                if (last) o.sync_after = sync ? 1 : 0;
+                ops.push_back(o);
+                if (last) break;
+            }
+            return items;
+        };
+        while (ci < C.size()) {
+            const bool pair = ui < u_before_ctrl;
+            const int used = take_slot(C, ci, !pair, 0);
+            if (pair) {
+                // count U ops consumed: a slot of U is one op here (the up-conv pairs come later)
+                take_slot(U, ui, true, used);
+            }
+        }
+        while (ui < U.size()) take_slot(U, ui, true, 0);
+        int syncs = 0;
+        for (const ROp& o : ops) syncs += o.sync_after;
+        if ((int)ops.size() > kMaxOps || syncs > kMaxSync) ok = false;
+    }
+};
+
+}  // namespace res
+
+// resident scratch (floats): [ops][flags][slots][error word + pad][x checkpoint]
+static size_t res_ops_floats() { return (sizeof(res::ROp) * res::kMaxOps + 255) / 256 * 64; }
+static size_t res_flags_floats() { return (size_t)kNumXCD * res::kMaxSync * res::kWG * 2; }
+static size_t res_slots_floats() { return (size_t)kNumXCD * res::kMaxItems * res::kMaxQ * 2 * 2; }
+
+size_t resident_floats(int B, int T) {
+    return res_ops_floats() + res_flags_floats() + res_slots_floats() + 64 + ((size_t)B * T * 32 + 63) / 64 * 64;
+}
+
+bool resident_ok(const rohm_trajnet* h, int B, int T, int n_steps, hipStream_t s) {
+    // Opt-in (ROHM_TRAJ_RESIDENT=1).  Measured on MI355X (profiles/r6_n_*): correct (3e-6 from the launch-per-layer loop, reference
+    // goldens green) but SLOWER -- 65 vs 41 ms per 100 steps for one clip, 81 vs 56 ms for 32, 107 vs 73 for 64: every XCD streams all
+    // 90 MB of weights per step for its own clips (8 x the traffic of the launch-per-layer loop, whose split-K slices read every
+    // weight once chip-wide), and one XCD pulls them at ~0.45 TB/s (eight together 2.3 TB/s): the deep levels -- 85 % of the weights,
+    // 9-18 rows per clip -- are bound by that stream, not by dispatch latency.  See the file header and NOTES section 12.4.
+    const char* e = getenv("ROHM_TRAJ_RESIDENT");
+    if (!(e && e[0] == '1')) return false;
+    if (n_steps < 1 || T % 16 != 0 || T > 160 || (T >> 4) < 1 || h->mid % 256 != 0 || h->final_conv.cin > 64 || h->final_conv.cin % 4 != 0) return false;
+    const int n = (B + kNumXCD - 1) / kNumXCD;
+    int bmax = 64;                     // clips per forward up to which the resident step is the faster plan (measured; ROHM_TRAJ_RESIDENT_MAX_B)
+    if (const char* m = getenv("ROHM_TRAJ_RESIDENT_MAX_B")) bmax = atoi(m);
+    if (B > bmax || n > res::kMaxQ) return false;
+    if (prof::enabled() || stream_is_capturing(s)) return false;      // the launch profiler's labels and graph capture belong to the launch-per-layer loop
+    const char* why = nullptr;
+    return exchange_layout_state(h->device, &why) == 1;
+}
+
+int resident_loop(const rohm_trajnet* h, const TWs& w, float* x, const float* noise, const int64_t* t_model, const float* coef,
+                  float* x0_last, float* x_in_last, int n_steps, int B, int T, hipStream_t s) {
+    using namespace res;
+    float* base = w.resident;
+    ROp* d_ops = reinterpret_cast<ROp*>(base);
+    unsigned long long* flags = reinterpret_cast<unsigned long long*>(base + res_ops_floats());
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(base + res_ops_floats() + res_flags_floats());
+    unsigned* err = reinterpret_cast<unsigned*>(base + res_ops_floats() + res_flags_floats() + res_slots_floats());
+    float* x_ckpt = base + res_ops_floats() + res_flags_floats() + res_slots_floats() + 64;
+    const size_t M = (size_t)B * T, n = M * h->ctraj;
+
+    Builder b{h, w, B, T, (B + kNumXCD - 1) / kNumXCD};
+    b.build();
+    if (!b.ok) return ROHM_ERR_UNSUPPORTED;
+    // the meeting flags and statistics slots start from zero (a tag is never 0), the error word too; x_T is kept for a re-run
+    ROHM_HIP_CHECK(hipMemsetAsync(flags, 0, (res_flags_floats() + res_slots_floats() + 64) * sizeof(float), s));
+    ROHM_HIP_CHECK(hipMemcpyAsync(d_ops, b.ops.data(), b.ops.size() * sizeof(ROp), hipMemcpyHostToDevice, s));
+    ROHM_HIP_CHECK(hipMemcpyAsync(x_ckpt, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // (the op list lives in pageable host memory: the copy above has been staged by the runtime when the call returns)
+
+    static bool attr_set[64] = {};
+    const size_t lds = (size_t)kLdsFloats * sizeof(float);
+    if (h->device >= 0 && h->device < 64 && !attr_set[h->device]) {
+        ROHM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[h->device] = true;
+    }
+    RParams p;
+    memset(&p, 0, sizeof(p));
+    p.ops = d_ops; p.n_ops = (int)b.ops.size(); p.B = B; p.T = T; p.n_per_xcd = b.n;
+    p.zero_page = h->zero_page; p.flags = flags; p.slots = slots; p.err = err;
+    p.fin = w.fin; p.ldfin = kPadC; p.hw = h->final_conv.w; p.ldhw = h->final_conv.cin_pad; p.hcin = h->final_conv.cin; p.hb = h->final_conv.b;
+    p.ctraj = h->ctraj; p.x = x; p.xin = w.xin; p.ldxin = kPadC;
+    { const char* f = getenv("ROHM_TRAJ_RESIDENT_FAULT"); p.fault = (f && f[0] == '1') ? 1 : 0; }
+    const bool want_tl = getenv("ROHM_TRAJ_RESIDENT_TIMELINE") != nullptr;
+    const size_t tl_words = (size_t)kNumXCD * kWG * kMaxOps * 8;
+    unsigned long long* d_tl = nullptr;
+    if (want_tl && hipMalloc(&d_tl, tl_words * 8) == hipSuccess) { (void)hipMemsetAsync(d_tl, 0, tl_words * 8, s); p.timeline = d_tl; }
+    for (int i = 0; i < n_steps; ++i) {
+        if (x_in_last && i == n_steps - 1) ROHM_HIP_CHECK(hipMemcpyAsync(x_in_last, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (i % kTbSteps == 0) {
+            const int run = (n_steps - i < kTbSteps) ? n_steps - i : kTbSteps;
+            int rc = launch_time_path_steps(h, w, t_model + i, run, s);
+            if (rc) return rc;
+        }
+        p.tb_row = w.tb_steps + (size_t)(i % kTbSteps) * h->tb_total;
+        p.tag_base = (unsigned)(i + 1) << 8;
+        p.c1 = coef[3 * i]; p.c2 = coef[3 * i + 1]; p.sigma = coef[3 * i + 2];
+        p.noise = noise ? noise + (size_t)i * n : nullptr;
+        p.x0_out = (x0_last && i == n_steps - 1) ? x0_last : nullptr;
+        hipLaunchKernelGGL(traj_resident_kernel, dim3(kNumXCD * kWG), dim3(256), lds, s, p);
+        ROHM_LAUNCH_CHECK();
+    }
+    // did every meeting complete?  (one host wait per loop call: 100 steps of work are behind it)
+    unsigned host_err = 0u;
+    ROHM_HIP_CHECK(hipMemcpyAsync(&host_err, err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    ROHM_HIP_CHECK(hipStreamSynchronize(s));
+    if (d_tl) {      // the last step's stamps of XCD 0 (100 MHz ticks -> us): per layer, means over the workgroups that had an item
+        std::vector<unsigned long long> tl(tl_words);
+        (void)hipMemcpy(tl.data(), d_tl, tl_words * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_tl);
+        unsigned long long t_first = ~0ull, t_last = 0ull;
+        fprintf(stderr, "[rohm] resident TrajNet step, B = %d: layer  cout cin taps t_out items | setup  kloop  reduce  epi  | busy-wg span  meet(max)  layer span [us]\n", B);
+        for (int oi = 0; oi < p.n_ops; ++oi) {
+            const ROp& o = b.ops[oi];
+            double su[4] = {0, 0, 0, 0}, meet_max = 0;
+            int busy = 0;
+            unsigned long long lo = ~0ull, hi = 0ull;
+            for (int j = 0; j < kWG; ++j) {
+                const unsigned long long* t = tl.data() + ((size_t)(j * kNumXCD) * kMaxOps + oi) * 8;      // block j * 8 = XCD 0, workgroup j
+                if (t[0] == 0) continue;
+                lo = std::min(lo, t[0]);
+                const unsigned long long end = o.sync_after ? t[5] : (t[4] ? t[4] : t[0]);
+                hi = std::max(hi, end);
+                if (t[4] > t[0] && t[1] >= t[0]) {
+                    ++busy;
+                    su[0] += (double)(t[1] - t[0]); su[1] += (double)(t[2] - t[1]); su[2] += (double)(t[3] - t[2]); su[3] += (double)(t[4] - t[3]);
+                }
+                if (o.sync_after && t[5]) meet_max = std::max(meet_max, (double)(t[5] - std::max(t[4], t[0])));
+            }
+            if (lo == ~0ull) continue;
+            t_first = std::min(t_first, lo); t_last = std::max(t_last, hi);
+            const double d = busy ? 100.0 * busy : 1.0;
+            const int items = o.kind == 0 ? ((b.n + o.q - 1) / o.q) * (o.cout / 16) : 0;
+            fprintf(stderr, "[rohm]   %2d %s %4d %4d %d %3d %3d | %5.2f %6.2f %6.2f %6.2f | %2d wgs  %6.2f  %6.2f%s\n", oi, o.kind ? "tail" : "conv", o.cout, o.cin_pad,
+                    o.ntaps, o.t_out, items, su[0] / d, su[1] / d, su[2] / d, su[3] / d, busy, meet_max / 100.0, (double)(hi - lo) / 100.0, o.sync_after ? "" : "  (no meeting)");
+        }
+        fprintf(stderr, "[rohm]   step span %.2f us\n", (double)(t_last - t_first) / 100.0);
+    }
+    if (host_err != 0u) {
+        ROHM_HIP_CHECK(hipMemcpyAsync(x, x_ckpt, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        set_error("trajnet_sample_loop: a wait of the clip-resident step did not complete (%s, %s %u); the loop is re-run launch per layer",
+                  (host_err & 0xffu) == 2u ? "partners on different XCDs" : "partner workgroups not co-resident or late",
+                  ((host_err >> 8) & 0x80u) ? "statistics exchange of layer" : "meeting", (host_err >> 8) & 0x7fu);
+        if (getenv("ROHM_TRAJ_RESIDENT_VERBOSE")) fprintf(stderr, "[rohm] resident TrajNet step fell back: error word 0x%x\n", host_err);
+        return ROHM_ERR_UNSUPPORTED;
+    }
+    return ROHM_OK;
+}
+
+}  // namespace rohm

@@ -121,6 +121,7 @@ def test_control_loop_vs_oracle():
 def test_graph_replay_loop_is_bit_identical(monkeypatch):
     """The opt-in hipGraph replay of the sampling loop (ROHM_TRAJNET_GRAPH=1: one captured step, per-step values read
     from device tables through a step counter) must reproduce the plain loop bit for bit."""
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '0')      # both legs are forms of the launch-per-layer loop (the clip-resident step is not recorded)
     net, _ = make_trajnet(81, True)
     B = 2
     cond, cc = seeded(5, B, 144, 13), seeded(6, B, 144, 272)
@@ -141,6 +142,7 @@ def test_control_side_stream_is_bit_identical(monkeypatch):
     """The ControlNet branch of the TrajControl loop runs on a second stream, one step ahead of the U-Net (two sets of residual
     buffers, events): ROHM_TRAJ_CTRL_STREAM=0 (everything on the caller's stream, in the reference's order) must give the same bits,
     run after run (a missing event would show up as a race)."""
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '0')      # the side stream belongs to the launch-per-layer loop
     net, _ = make_trajnet(82, True)
     B = 3
     cond, cc = seeded(15, B, 144, 13), seeded(16, B, 144, 272)
@@ -231,3 +233,75 @@ def test_large_batch_is_clip_independent():
         sl = slice(lo, lo + 64)
         ys = net({'x_t': x[sl].contiguous(), 'cond': c[sl].contiguous(), 'control_cond': cc[sl].contiguous()}, t[sl].contiguous())
         assert max_abs(y[sl], ys) < 2e-5, lo
+
+
+# ---- the clip-resident step (opt-in ROHM_TRAJ_RESIDENT=1, csrc/trajnet_resident.hip): one launch per denoising step ----------------
+
+def _loop(net, batch, shape, x_T, noises, fused_chunk=None):
+    diff = make_diffusion()
+    diff.noise_source = lambda step, like: (x_T if step == -1 else noises[step])
+    if fused_chunk:
+        diff.fused_chunk = fused_chunk
+    _, y = diff.eval_losses(model=net, batch=batch, shape=list(shape), progress=False, clip_denoised=False, timestep_respacing='',
+                            cond_fn_with_grad=False, compute_loss=False)
+    return y
+
+
+def test_resident_step_vs_reference_goldens(monkeypatch):
+    """The reference's own 100-step runs (TrajNet, one clip: BASELINE.json configs[0]; TrajControl, two clips) through the
+    clip-resident step: same bar as the launch-per-layer loop (1e-3), and the loop really ran in that form."""
+    from rohm_amd import _lib
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '1')
+    g = golden('trajnet_loop100.npz')
+    net, _ = make_trajnet(int(g['weight_seed']), False)
+    cond = seeded(int(g['cond_seed']), 1, 144, 13)
+    x_T, noises = cpu_noise_sequence(int(g['torch_seed']), (1, 144, 13), 100, trajnet_layout=True)
+    y = _loop(net, {'cond': cond.to(DEV)}, (1, 144, 13), x_T, noises)
+    assert _lib.lib().rohm_trajnet_loop_mode() == 1
+    assert max_abs(y.cpu(), torch.from_numpy(g['y'])) < 1e-3
+    g = golden('trajnet_control_loop100.npz')
+    net, _ = make_trajnet(int(g['weight_seed']), True)
+    cond, cc = seeded(int(g['cond_seed']), 2, 144, 13), seeded(int(g['control_seed']), 2, 144, 272)
+    x_T, noises = cpu_noise_sequence(int(g['torch_seed']), (2, 144, 13), 100, trajnet_layout=True)
+    y = _loop(net, {'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}, (2, 144, 13), x_T, noises)
+    assert _lib.lib().rohm_trajnet_loop_mode() == 1
+    assert max_abs(y.cpu(), torch.from_numpy(g['y'])) < 1e-3
+
+
+@pytest.mark.parametrize('B,ctrl', [(1, True), (8, False), (9, True), (13, False), (32, True), (64, False)])
+def test_resident_step_vs_launch_per_layer(monkeypatch, B, ctrl):
+    """Every way the clips fall onto the 8 XCDs -- one XCD busy, one clip each, a ragged last XCD (9 = 2 + 2 + 2 + 2 + 1, 13 = 6 x 2 + 1),
+    4 and 8 clips per XCD (several clips per work item at the deep levels, GroupNorm statistics exchanged between 2 / 4 items) -- against
+    the launch-per-layer loop on the same inputs and noise: fp32 summation order is all that differs (2e-5 after 100 steps), and the
+    resident loop repeats itself bit for bit."""
+    from rohm_amd import _lib
+    net, _ = make_trajnet(90 + B, ctrl)
+    cond, cc = seeded(5, B, 144, 13), seeded(6, B, 144, 272)
+    x_T, noises = cpu_noise_sequence(8, (B, 144, 13), 100)
+    batch = {'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '0')
+    ref = _loop(net, batch, (B, 144, 13), x_T, noises).clone()
+    assert _lib.lib().rohm_trajnet_loop_mode() == 0
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '1')
+    y = _loop(net, batch, (B, 144, 13), x_T, noises, fused_chunk=37).clone()      # chunks of 37 + 37 + 26 steps: three calls
+    assert _lib.lib().rohm_trajnet_loop_mode() == 1
+    assert torch.isfinite(y).all() and max_abs(y, ref) < 2e-5
+    assert torch.equal(y, _loop(net, batch, (B, 144, 13), x_T, noises, fused_chunk=37))
+
+
+def test_resident_step_survives_a_missing_partner(monkeypatch):
+    """Fault injection (ROHM_TRAJ_RESIDENT_FAULT=1: one workgroup stays away from a meeting): the partners' bounded waits expire, the
+    error word is set, the host restores x_T and re-runs the loop launch per layer -- the caller gets that loop's exact result."""
+    from rohm_amd import _lib
+    net, _ = make_trajnet(97, True)
+    B = 3
+    cond, cc = seeded(5, B, 144, 13), seeded(6, B, 144, 272)
+    x_T, noises = cpu_noise_sequence(8, (B, 144, 13), 100)
+    batch = {'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '0')
+    ref = _loop(net, batch, (B, 144, 13), x_T, noises).clone()
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '1')
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT_FAULT', '1')
+    y = _loop(net, batch, (B, 144, 13), x_T, noises)
+    assert _lib.lib().rohm_trajnet_loop_mode() == 0
+    assert torch.equal(y, ref)
