@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include "trajnet_priv.h"
 
@@ -47,8 +48,7 @@ constexpr int kWBuf = kWRows * kKC;
 constexpr int kStage = 2 * (kABuf + kWBuf);    // two staging buffers; after the K loop the same floats hold the waves' partial tiles
 constexpr int kRed = 4 * kMaxRows * 16;        // [wave][row][16]
 static_assert(2 * kRed <= kStage, "the partial tiles of conv + residual must fit the staging buffers");
-constexpr int kLdsFloats = kStage + 1024;      // + row sums [160][4], statistics [16][4] x 2
-constexpr int kMaxSync = 64, kMaxItems = 256, kMaxOps = 96, kMaxQ = 16, kMaxStages = 8;
+constexpr int kMaxSync = 64, kMaxItems = 256, kMaxOps = 64, kMaxQ = 16, kMaxStages = 8;
 
 struct ROp {
     int kind;                                  // 0 conv layer, 1 head + update
@@ -66,6 +66,11 @@ struct ROp {
     const float* res; const float* add2;
     float* dst; float* dst2;
 };
+
+static_assert(sizeof(ROp) % 4 == 0, "layer records are copied word by word");
+constexpr int kOpsFloats = (int)(sizeof(ROp) / 4) * kMaxOps;      // the step's layer records, copied into LDS once per launch
+constexpr int kLdsFloats = kStage + 1536 + kOpsFloats;            // + row statistics [160][4][2], pair statistics [16][2], layer records
+static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
 
 struct RParams {
     const ROp* ops; int n_ops;
@@ -85,6 +90,9 @@ struct RParams {
     unsigned long long* timeline;
     int fault;                                 // test hook (ROHM_TRAJ_RESIDENT_FAULT=1): workgroup 0 of XCD 0 stays away from the fourth meeting
 };
+
+// x / d for 0 <= x < 4096, d <= 256, inv = 1.0f / d: exact (x + 0.5 is never within float rounding of a multiple of d)
+__device__ __forceinline__ int idiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
 __device__ __forceinline__ int lds_off64(int row, int slot) { return row * kKC + ((slot ^ (row & 15)) << 2); }
 
@@ -112,7 +120,9 @@ __device__ __forceinline__ bool wait_tag(const unsigned long long* p, unsigned t
 __device__ __forceinline__ void xcd_sync(unsigned long long* flags, int j, unsigned tag, unsigned xcc1, unsigned* err, unsigned where, int tid, bool absent) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && !absent) __hip_atomic_store(flags + j, ((unsigned long long)tag << 32) | xcc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the flag by a PLAIN store: it stays in the XCD's L2, where the partners' device-scope polls are served (an sc1 store writes through
+    // to memory and drops the line: every poll then pays the trip to the memory side)
+    if (tid == 0 && !absent) { flags[j] = ((unsigned long long)tag << 32) | xcc1; asm volatile("" ::: "memory"); }
     if (tid < kWG && tid != j) {
         unsigned long long f;
         if (wait_tag(flags + tid, tag, err, where, &f) && (unsigned)f != xcc1) __hip_atomic_store(err, 2u | (where << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -144,76 +154,115 @@ __device__ __forceinline__ float sum16(float v) {      // all-lanes sum of a 16-
     return v;
 }
 
+// Shape of one (clip run, 16-column block) item and of its staging ring -- computed the same way by the item itself and by whoever
+// requests its first weight chunks ahead of time.
+struct Geom {
+    int ncb, cb, clip0, qi, rows, nrb, rstride, lrows, a_iters, nt, ntt, nch, col0, per_chunk, stage_f, NS, pre;
+    bool has_res;
+};
+__device__ __forceinline__ Geom item_geom(const ROp& op, int id, int c_lo, int nx) {
+    Geom g;
+    g.ncb = op.cout >> 4;
+    const int cg = idiv_small(id, 1.0f / (float)g.ncb);
+    g.cb = id - cg * g.ncb;
+    const int k0 = cg * op.q;
+    g.qi = min(op.q, nx - k0);
+    g.clip0 = c_lo + k0;
+    g.rows = g.qi * op.t_out; g.nrb = (g.rows + 15) >> 4;
+    g.rstride = op.t_in + 4; g.lrows = g.qi * g.rstride; g.a_iters = (g.lrows + 15) >> 4;
+    g.nt = op.ntaps; g.has_res = op.Wres != nullptr; g.ntt = g.nt + (g.has_res ? 1 : 0);
+    g.nch = op.cin_pad / kKC; g.col0 = g.cb * 16;
+    // staging ring: a stage = the item's input rows (whole 16-row DMA passes) + its weight rows of ONE 64-channel chunk; as many
+    // stages as the LDS holds (2 at level 0 .. 8 for a 1x1 conv at the deep levels): a deep-level layer (8 .. 16 chunks of < 1 us of
+    // MFMAs each) lives on the chunks in flight
+    g.per_chunk = g.a_iters + g.ntt;                   // DMA instructions per chunk and wave
+    g.stage_f = g.per_chunk * 16 * kKC;
+    int NS = min(kMaxStages, kStage / g.stage_f);
+    NS = min(NS, g.nch + 1);
+    while (NS > 2 && (NS - 2) * g.per_chunk > 63) --NS;      // s_waitcnt vmcnt counts to 63
+    g.NS = NS;
+    g.pre = min(NS - 1, g.nch);                        // chunks in flight ahead of the one being multiplied
+    return g;
+}
+// this lane's weight addresses of chunk 0: pass `tap` of a chunk = 16 columns x 64 channels of that tap (the 1x1 residual conv's last)
+__device__ __forceinline__ void weight_src(const RParams& p, const ROp& op, const Geom& g, int tid, const float** w_src) {
+    const int col = tid >> 4, slot = (tid & 15) ^ col;      // row of pass `tap` = tap * 16 + col: (row & 15) == col
+    const unsigned wrow = (unsigned)((g.col0 + col) * op.ldw + slot * 4);
+#pragma unroll
+    for (int tp = 0; tp < kMaxTaps + 1; ++tp) {
+        w_src[tp] = p.zero_page;
+        if (tp < g.nt) w_src[tp] = op.W + (wrow + (unsigned)(tp * op.cin_pad));
+        else if (tp == g.nt && g.has_res) w_src[tp] = op.Wres + (unsigned)((g.col0 + col) * op.cin_pad + slot * 4);
+    }
+}
+__device__ __forceinline__ void dma_w(const Geom& g, const float* const* w_src, float* smem, int stage, int kc, int wave) {
+    float* const Wb = smem + stage * g.stage_f + g.a_iters * 16 * kKC;
+#pragma unroll
+    for (int tp = 0; tp < kMaxTaps + 1; ++tp)
+        if (tp < g.ntt)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[tp] + kc * kKC),
+                                             (__attribute__((address_space(3))) void*)(Wb + (tp * 256 + wave * 64) * 4), 16, 0, 0);
+}
 // One (clip run, 16-column block) item of a conv layer.
 __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const int oi, const int id, const int xcd, const int c_lo, const int nx,
                                           float* smem, const int tid, unsigned long long* const tl) {
     auto stamp = [&](int k) __attribute__((always_inline)) { if (tl != nullptr && threadIdx.x == 0) tl[k] = __builtin_amdgcn_s_memrealtime(); };
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
-    const int ncb = op.cout >> 4;
-    const int cg = id / ncb, cb = id - cg * ncb;
-    const int k0 = cg * op.q;
-    const int qi = min(op.q, nx - k0);
-    const int clip0 = c_lo + k0;
+    const Geom g = item_geom(op, id, c_lo, nx);
+    const int cb = g.cb, qi = g.qi, clip0 = g.clip0, rows = g.rows, nrb = g.nrb, RM = g.nrb * 16, rstride = g.rstride, lrows = g.lrows;
+    const int a_iters = g.a_iters, nt = g.nt, ntt = g.ntt, nch = g.nch, col0 = g.col0, per_chunk = g.per_chunk, stage_f = g.stage_f, NS = g.NS, pre = g.pre;
+    const bool has_res = g.has_res;
     const int t_in = op.t_in, t_out = op.t_out, stride = op.stride;
-    const int rows = qi * t_out, nrb = (rows + 15) >> 4, RM = nrb * 16;
-    const int rstride = t_in + 4, lrows = qi * rstride, a_iters = (lrows + 15) >> 4;
-    const int nt = op.ntaps;
-    const bool has_res = op.Wres != nullptr;
-    const int ntt = nt + (has_res ? 1 : 0);
-    const int nch = op.cin_pad / kKC;
-    const int col0 = cb * 16;
-
-    // staging ring: a stage = the item's input rows (whole 16-row DMA passes) + its weight rows of ONE 64-channel chunk; as many
-    // stages as the LDS holds (2 at level 0 .. 8 for a 1x1 conv at the deep levels): the weights stream from HBM / the memory-side
-    // cache at ~2.5 us a round trip, so a deep-level layer (8 .. 16 chunks of < 1 us of MFMAs each) lives on the chunks in flight
-    const int per_chunk = a_iters + ntt;               // DMA instructions per chunk and wave
-    const int stage_f = per_chunk * 16 * kKC;
-    int NS = min(kMaxStages, kStage / stage_f);
-    NS = min(NS, nch + 1);
-    while (NS > 2 && (NS - 2) * per_chunk > 63) --NS;  // s_waitcnt vmcnt counts to 63
-    const int pre = min(NS - 1, nch);                  // chunks in flight ahead of the one being multiplied
+    // the tap offsets in scalar registers NOW: a read of the layer record inside the K loop would be a vector memory load, and waiting for
+    // it (vmcnt counts in order) waits for every weight chunk in flight -- measured: 2 us per chunk, no overlap at all
+    int shifts[kMaxTaps];
+#pragma unroll
+    for (int tp = 0; tp < kMaxTaps; ++tp) shifts[tp] = __builtin_amdgcn_readfirstlane(op.off[tp]);
     // ---- operand addresses of chunk 0 (16-byte units; unit u of a DMA pass lands at LDS position u: the global side is swizzled) ------
+    const float inv_rstride = 1.0f / (float)rstride;
     const float* a_src[kAIters];
     unsigned a_real = 0u;                              // bit it: this lane's unit of pass it is a real input row (else: halo / padding -> zeros)
 #pragma unroll
     for (int it = 0; it < kAIters; ++it) {
-        const int u = it * 256 + tid, row = u >> 4, slot = (u & 15) ^ (row & 15);
-        const int k = row / rstride, t = row - k * rstride - 2;
-        const bool real = row < lrows && t >= 0 && t < t_in;
-        a_src[it] = real ? op.A + ((size_t)(clip0 + k) * t_in + t) * op.lda + slot * 4 : p.zero_page + slot * 4;
-        a_real |= real ? (1u << it) : 0u;
-    }
-    const float* w_src[kMaxTaps + 1];
-    {
-        const int col = tid >> 4, slot = (tid & 15) ^ col;      // row of pass `tap` = tap * 16 + col: (row & 15) == col
-#pragma unroll
-        for (int tp = 0; tp < kMaxTaps + 1; ++tp) {
-            w_src[tp] = (tp < nt) ? op.W + (size_t)(col0 + col) * op.ldw + tp * op.cin_pad + slot * 4
-                                  : (has_res ? op.Wres + (size_t)(col0 + col) * op.cin_pad + slot * 4 : p.zero_page);
+        a_src[it] = p.zero_page;
+        if (it < a_iters) {                            // (32-bit element offsets: an activation matrix has < 2^31 floats)
+            const int u = it * 256 + tid, row = u >> 4, slot = (u & 15) ^ (row & 15);
+            const int k = idiv_small(row, inv_rstride), t = row - k * rstride - 2;
+            const bool real = row < lrows && t >= 0 && t < t_in;
+            const unsigned off = (unsigned)(((clip0 + k) * t_in + t) * op.lda + slot * 4);
+            a_src[it] = real ? op.A + off : p.zero_page + slot * 4;
+            a_real |= real ? (1u << it) : 0u;
         }
     }
-    auto dma = [&](int stage, int kc) __attribute__((always_inline)) {
+    const float* w_src[kMaxTaps + 1];
+    weight_src(p, op, g, tid, w_src);
+    auto dma_a = [&](int stage, int kc) __attribute__((always_inline)) {
         float* const Ab = smem + stage * stage_f;
-        float* const Wb = Ab + a_iters * 16 * kKC;
 #pragma unroll
         for (int it = 0; it < kAIters; ++it)
             if (it < a_iters)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[it] + (((a_real >> it) & 1u) ? kc * kKC : 0)),
                                                  (__attribute__((address_space(3))) void*)(Ab + (it * 256 + wave * 64) * 4), 16, 0, 16);
-#pragma unroll
-        for (int tp = 0; tp < kMaxTaps + 1; ++tp)
-            if (tp < ntt)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[tp] + kc * kKC),
-                                                 (__attribute__((address_space(3))) void*)(Wb + (tp * 256 + wave * 64) * 4), 16, 0, 0);
     };
+    auto dma = [&](int stage, int kc) __attribute__((always_inline)) { dma_a(stage, kc); dma_w(g, w_src, smem, stage, kc, wave); };
 
     // ---- fragment rows: conv position o = 16 r + li of the item -> staged row of its centre tap ------------------------------------
     int base[kMaxRB];
+    {
+        const float inv_t = 1.0f / (float)t_out;
 #pragma unroll
-    for (int r = 0; r < kMaxRB; ++r) {
-        const int o = min(r * 16 + li, rows - 1);      // positions past the item's last repeat it (never stored, never counted)
-        const int k = o / t_out, tq = o - k * t_out;
-        base[r] = k * rstride + 2 + tq * stride;
+        for (int r = 0; r < kMaxRB; ++r) {
+            base[r] = 2;
+            if (r < nrb) {
+                const int o = min(r * 16 + li, rows - 1);      // positions past the item's last repeat it (never stored, never counted)
+                const int k = idiv_small(o, inv_t), tq = o - k * t_out;
+                base[r] = k * rstride + 2 + tq * stride;
+            }
+        }
+        // blocks beyond nrb that an instantiation with more row blocks still multiplies read block 0's rows again (never stored)
+#pragma unroll
+        for (int r = 1; r < kMaxRB; ++r)
+            if (r >= nrb) base[r] = base[0];
     }
     f32x4 acc[kMaxRB], accr[kMaxRB];
 #pragma unroll
@@ -224,39 +273,63 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
     __syncthreads();                                   // the previous item's partial tiles (same LDS) have been consumed
     for (int c = 0; c < pre; ++c) dma(c, c);
     const int kslot = 4 * wave + lg;                   // this lane's 16-byte slot of a 64-channel row: wave w contracts channels 16 w ..
-    int st = 0;                                        // stage of chunk kc
-    for (int kc = 0; kc < nch; ++kc) {
-        wait_vmcnt(min(pre - 1, nch - 1 - kc) * per_chunk);      // chunk kc has landed; the younger ones may still be on their way
-        __syncthreads();                               // ... for everybody; everybody is done with chunk kc - 1
-        if (kc + pre < nch) { const int sn = st + pre; dma(sn >= NS ? sn - NS : sn, kc + pre); }      // pre == NS - 1: the stage of chunk kc - 1
-        const float* Ab = smem + st * stage_f;
-        const float* Wb = Ab + a_iters * 16 * kKC;
-        st = (st + 1 == NS) ? 0 : st + 1;
+    // The K loop, instantiated per (row blocks, taps, residual tap): with static trip counts the compiler can count the LDS reads in flight
+    // (lgkmcnt) -- the fragments of tap t + 1 are requested before the MFMAs of tap t.  With run-time counts it emitted read - wait - 4 MFMAs
+    // per block: ~1.1 us per chunk on top of the MFMAs (profiles/r6_r_*).  Row-block counts are rounded up to an instantiated one (the extra
+    // blocks repeat the item's last row and are never stored).
+    auto kl = [&](auto nrb_t, auto nt_t, auto res_t) __attribute__((always_inline)) {
+        constexpr int NRB = decltype(nrb_t)::value, NT = decltype(nt_t)::value;
+        constexpr bool RES = decltype(res_t)::value;
+        constexpr int NTT = NT + (RES ? 1 : 0);
+        int st = 0;                                    // stage of chunk kc
+        for (int kc = 0; kc < nch; ++kc) {
+            wait_vmcnt(min(pre - 1, nch - 1 - kc) * per_chunk);      // chunk kc has landed; the younger ones may still be on their way
+            // ... for everybody, and everybody is done with chunk kc - 1 (its fragments were consumed by MFMAs).  A bare s_barrier:
+            // __syncthreads() is a fence and waits for vmcnt(0) -- every chunk in flight -- first
+            asm volatile("s_barrier" ::: "memory");
+            if (kc + pre < nch) { const int sn = st + pre; dma(sn >= NS ? sn - NS : sn, kc + pre); }      // pre == NS - 1: the stage of chunk kc - 1
+            const float* Ab = smem + st * stage_f;
+            const float* Wb = Ab + a_iters * 16 * kKC;
+            st = (st + 1 == NS) ? 0 : st + 1;
+            f32x4 fw[NTT], fa[2][NRB];
 #pragma unroll
-        for (int tp = 0; tp < kMaxTaps; ++tp) {
-            if (tp < nt) {
-                const f32x4 wf = *reinterpret_cast<const f32x4*>(Wb + lds_off64(tp * 16 + li, kslot));
-                const int shift = op.off[tp];
+            for (int tp = 0; tp < NTT; ++tp) fw[tp] = *reinterpret_cast<const f32x4*>(Wb + lds_off64(tp * 16 + li, kslot));
 #pragma unroll
-                for (int r = 0; r < kMaxRB; ++r)
-                    if (r < nrb) {
-                        const f32x4 af = *reinterpret_cast<const f32x4*>(Ab + lds_off64(base[r] + shift, kslot));
+            for (int r = 0; r < NRB; ++r) fa[0][r] = *reinterpret_cast<const f32x4*>(Ab + lds_off64(base[r] + (NT > 0 ? shifts[0] : 0), kslot));
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jj], af[jj], acc[r], 0, 0, 0);
+            for (int tp = 0; tp < NTT; ++tp) {
+                if (tp + 1 < NTT) {
+                    const int sh = (tp + 1 < NT) ? shifts[tp + 1] : 0;      // the residual 1x1 conv reads the centre row
+#pragma unroll
+                    for (int r = 0; r < NRB; ++r) fa[(tp + 1) & 1][r] = *reinterpret_cast<const f32x4*>(Ab + lds_off64(base[r] + sh, kslot));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < NRB; ++r) {
+                        if (RES && tp == NT) accr[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[tp][jj], fa[tp & 1][r][jj], accr[r], 0, 0, 0);
+                        else acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[tp][jj], fa[tp & 1][r][jj], acc[r], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (has_res) {
-            const f32x4 wf = *reinterpret_cast<const f32x4*>(Wb + lds_off64(nt * 16 + li, kslot));
-#pragma unroll
-            for (int r = 0; r < kMaxRB; ++r)
-                if (r < nrb) {
-                    const f32x4 af = *reinterpret_cast<const f32x4*>(Ab + lds_off64(base[r], kslot));
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) accr[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jj], af[jj], accr[r], 0, 0, 0);
-                }
-        }
-    }
+    };
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I5 = std::integral_constant<int, 5>; using I9 = std::integral_constant<int, 9>; using I10 = std::integral_constant<int, 10>;
+    auto by_taps = [&](auto nrb_t) __attribute__((always_inline)) {
+        if (nt == 5 && has_res) kl(nrb_t, I5{}, std::true_type{});
+        else if (nt == 5) kl(nrb_t, I5{}, std::false_type{});
+        else if (nt == 3) kl(nrb_t, I3{}, std::false_type{});
+        else if (nt == 2) kl(nrb_t, I2{}, std::false_type{});
+        else kl(nrb_t, I1{}, std::false_type{});
+    };
+    if (nrb <= 1) by_taps(I1{});
+    else if (nrb == 2) by_taps(I2{});
+    else if (nrb == 3) by_taps(I3{});
+    else if (nrb <= 5) by_taps(I5{});
+    else if (nrb <= 9) by_taps(I9{});
+    else by_taps(I10{});
     __syncthreads();                                   // every wave is done with the staging buffers
     stamp(2);
 
@@ -270,21 +343,46 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
             if (has_res) *reinterpret_cast<f32x4*>(redr + ((wave * RM + r * 16 + li) * 16 + lg * 4)) = accr[r];
         }
     __syncthreads();
-    float* const rowsum = smem + kStage;               // [160][4]
-    float* const stat = rowsum + kMaxRows * 4;         // [16 pairs][2]: mean, rstd (or M2 on the way)
+    float* const rowst = smem + kStage;                // [160 rows][4 local groups][2]: (mean, M2) of the row's columns of the group
+    float* const stat = rowst + kMaxRows * 8;          // [16 (clip, local group) pairs][2]: mean, M2
     constexpr int NU = 3;                              // 16-byte units per thread: rows x 4 <= 640
-    f32x4 v[NU];
+    const int c4 = (tid & 3) * 4;
+    const bool gn = op.gn != 0;
+    const float* const tb = (gn && op.tb_off >= 0) ? p.tb_row + op.tb_off + col0 + c4 : nullptr;
+    const float inv_tout = 1.0f / (float)t_out;
     int urow[NU], uclip[NU];
     bool uok[NU];
-    const int c4 = (tid & 3) * 4;
+    // every operand of the epilogue is requested NOW (partner-written ones past the L1): they land underneath the sums and the statistics
+    f32x4 r4[NU], a4[NU];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 g4 = zero4, be4 = zero4, t4 = zero4;
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(op.bias + col0 + c4);
+    f32x4 rb4 = zero4;
+    if (has_res) rb4 = *reinterpret_cast<const f32x4*>(op.bres + col0 + c4);
+    if (gn) {
+        g4 = *reinterpret_cast<const f32x4*>(op.gamma + col0 + c4);
+        be4 = *reinterpret_cast<const f32x4*>(op.beta + col0 + c4);
+        if (tb) t4 = *reinterpret_cast<const f32x4*>(tb);
+    }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-        const int e = tid + 256 * i, o = e >> 2;
+        const int o = (tid + 256 * i) >> 2;
         uok[i] = o < rows;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        urow[i] = 0; uclip[i] = 0;
+        const int k = uok[i] ? idiv_small(o, inv_tout) : 0, tq = uok[i] ? o - k * t_out : 0;
+        uclip[i] = k;
+        urow[i] = (clip0 + k) * op.t_dst + tq * op.omul + op.oadd;
+        r4[i] = a4[i] = zero4;
+        if (uok[i] && gn) {
+            if (op.res) r4[i] = ld16_l2(op.res + (size_t)urow[i] * op.ldres + col0 + c4);
+            if (op.add2) a4[i] = ld16_l2(op.add2 + (size_t)urow[i] * op.ldadd2 + col0 + c4);
+        }
+    }
+    f32x4 v[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int o = (tid + 256 * i) >> 2;
+        v[i] = zero4;
         if (uok[i]) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(op.bias + col0 + c4);
             f32x4 s = *reinterpret_cast<const f32x4*>(red + ((0 * RM + o) * 16 + c4));
 #pragma unroll
             for (int w = 1; w < 4; ++w) {
@@ -294,11 +392,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x) v[i][x] = s[x] + b4[x];
-            const int k = o / t_out, tq = o - k * t_out;
-            uclip[i] = k;
-            urow[i] = (clip0 + k) * op.t_dst + tq * op.omul + op.oadd;
             if (has_res) {      // the 1x1 residual conv of the block's input, raw: the block's second layer adds it
-                const f32x4 rb = *reinterpret_cast<const f32x4*>(op.bres + col0 + c4);
                 f32x4 sr = *reinterpret_cast<const f32x4*>(redr + ((0 * RM + o) * 16 + c4));
 #pragma unroll
                 for (int w = 1; w < 4; ++w) {
@@ -307,14 +401,14 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
                     for (int x = 0; x < 4; ++x) sr[x] += t[x];
                 }
 #pragma unroll
-                for (int x = 0; x < 4; ++x) sr[x] += rb[x];
-                *reinterpret_cast<f32x4*>(op.res_out + (size_t)((clip0 + k) * t_out + tq) * op.ld_res_out + col0 + c4) = sr;
+                for (int x = 0; x < 4; ++x) sr[x] += rb4[x];
+                *reinterpret_cast<f32x4*>(op.res_out + (size_t)((clip0 + uclip[i]) * t_out + (o - uclip[i] * t_out)) * op.ld_res_out + col0 + c4) = sr;
             }
         }
     }
 
     stamp(3);
-    if (op.gn == 0) {
+    if (!gn) {
 #pragma unroll
         for (int i = 0; i < NU; ++i)
             if (uok[i]) *reinterpret_cast<f32x4*>(op.dst + (size_t)urow[i] * op.lddst + col0 + c4) = v[i];
@@ -322,61 +416,64 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
         return;
     }
 
-    // ---- GroupNorm over (group channels x T) per clip: two passes (mean, centred squares), fixed summation order ---------------------
+    // ---- GroupNorm over (group channels x T) per clip.  ONE pass, no cancellation: every unit's (mean, M2) of its 4 values, merged pairwise
+    // (Chan) over the row's units of the group, the clip's rows, the 16 lanes of the pair -- each merge symmetric in its operands, so every lane
+    // that holds a result holds the same bits, run after run
     const int gw = op.gn, gl = min(gw, 16), ngl = 16 / gl;       // local groups of this 16-column block: 4 / 2 / 1
     const int ugrp = (gl == 4) ? (tid & 3) : (gl == 8 ? ((tid & 3) >> 1) : 0);
     const int npairs = qi * ngl;                                 // <= 16: (clip, local group)
-    auto quad_sum = [&](float s) {                               // sum over the units of a row that share a local group
-        if (gl >= 8) s += __shfl_xor(s, 1);
-        if (gl >= 16) s += __shfl_xor(s, 2);
-        return s;
+    auto merge_eq = [](float& m, float& q, float mb, float qb, float n_each) __attribute__((always_inline)) {
+        const float d = mb - m;
+        m = 0.5f * (m + mb);
+        q = (q + qb) + 0.5f * n_each * d * d;
     };
-    auto pair_total = [&]() {                                    // rowsum[row][local group] -> sum over the clip's rows, every lane of the pair's 16
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        float m = 0.25f * ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])), q = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { const float d = v[i][x] - m; q += d * d; }
+        if (gl >= 8) { const float mb = __shfl_xor(m, 1), qb = __shfl_xor(q, 1); merge_eq(m, q, mb, qb, 4.f); }
+        if (gl >= 16) { const float mb = __shfl_xor(m, 2), qb = __shfl_xor(q, 2); merge_eq(m, q, mb, qb, 8.f); }
+        if (uok[i]) *reinterpret_cast<f32x2*>(rowst + (((tid + 256 * i) >> 2) * 4 + ugrp) * 2) = f32x2{m, q};
+    }
+    __syncthreads();
+    {
         const int pi = tid >> 4, l16 = tid & 15;
-        float s = 0.f;
+        const float fgl = (float)gl;
+        float r = 0.f, m = 0.f, q = 0.f;                         // rows merged so far, their mean, their M2
         if (pi < npairs) {
-            const int k = pi / ngl, g = pi - k * ngl;
-            for (int t = l16; t < t_out; t += 16) s += rowsum[(k * t_out + t) * 4 + g];
+            const int k = idiv_small(pi, 1.0f / (float)ngl), g = pi - k * ngl;
+            for (int t = l16; t < t_out; t += 16) {
+                const f32x2 row = *reinterpret_cast<const f32x2*>(rowst + ((k * t_out + t) * 4 + g) * 2);
+                const float d = row[0] - m, rn = r + 1.0f, inv = 1.0f / rn;
+                m = (r * m + row[0]) * inv;
+                q = (q + row[1]) + fgl * d * d * r * inv;
+                r = rn;
+            }
         }
-        return sum16(s);
-    };
-    const float inv_n = 1.0f / (float)(t_out * gl);
 #pragma unroll
-    for (int i = 0; i < NU; ++i) {
-        const float s = quad_sum((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
-        if (uok[i]) rowsum[((tid + 256 * i) >> 2) * 4 + ugrp] = s;
-    }
-    __syncthreads();
-    {
-        const float tot = pair_total();
-        if ((tid >> 4) < npairs && (tid & 15) == 0) stat[(tid >> 4) * 2] = tot * inv_n;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NU; ++i) {
-        const float m = stat[(uclip[i] * ngl + ugrp) * 2];
-        float s = 0.f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { const float d = v[i][x] - m; s += d * d; }
-        s = quad_sum(s);
-        if (uok[i]) rowsum[((tid + 256 * i) >> 2) * 4 + ugrp] = s;
-    }
-    __syncthreads();
-    {
-        const float tot = pair_total();
-        if ((tid >> 4) < npairs && (tid & 15) == 0) stat[(tid >> 4) * 2 + 1] = tot;      // M2
+        for (int sh = 8; sh >= 1; sh >>= 1) {
+            const float rb = __shfl_xor(r, sh), mb = __shfl_xor(m, sh), qb = __shfl_xor(q, sh);
+            const float n = r + rb, inv = n > 0.f ? 1.0f / n : 0.f, d = mb - m;
+            m = (r * m + rb * mb) * inv;
+            q = (q + qb) + fgl * d * d * (r * rb) * inv;
+            r = n;
+        }
+        if (pi < npairs && l16 == 0) *reinterpret_cast<f32x2*>(stat + pi * 2) = f32x2{m, q};
     }
     __syncthreads();
     if (gw > 16) {
         // the group spans nparts = gw / 16 neighbouring column blocks (items id - part .. of the same clip run, resident at the same time
-        // on other workgroups of the XCD): exchange (mean, M2) per clip, merge in a fixed tree -- every partner gets the same bits
+        // on other workgroups of the XCD): exchange (mean, M2) per clip, merge in a fixed tree -- every partner gets the same bits.
+        // Granules {value, tag} by PLAIN 8-byte stores (they stay in the XCD's L2, where the partners' device-scope loads find them)
         const int nparts = gw >> 4, part = cb & (nparts - 1);
         const unsigned tag = p.tag_base + (unsigned)oi;
         if (tid < qi) {
             unsigned long long* const mine = p.slots + (((size_t)xcd * kMaxItems + op.slot_base + id) * kMaxQ + tid) * 2;
             const float m = stat[tid * 2], q2 = stat[tid * 2 + 1];
-            __hip_atomic_store(mine, ((unsigned long long)tag << 32) | __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(mine + 1, ((unsigned long long)tag << 32) | __float_as_uint(q2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mine[0] = ((unsigned long long)tag << 32) | __float_as_uint(m);
+            mine[1] = ((unsigned long long)tag << 32) | __float_as_uint(q2);
+            asm volatile("" ::: "memory");
             float mk[4], qk[4];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
@@ -389,16 +486,11 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
                     mk[pp] = __uint_as_float((unsigned)a); qk[pp] = __uint_as_float((unsigned)b);
                 }
             }
-            auto merge = [](float ma, float qa, float mb, float qb, float n, float& mo, float& qo) {
-                const float d = mb - ma;
-                mo = 0.5f * (ma + mb);
-                qo = (qa + qb) + 0.5f * n * d * d;
-            };
             const float n1 = (float)(t_out * 16);
-            merge(mk[0], qk[0], mk[1], qk[1], n1, mk[0], qk[0]);
+            merge_eq(mk[0], qk[0], mk[1], qk[1], n1);
             if (nparts > 2) {
-                merge(mk[2], qk[2], mk[3], qk[3], n1, mk[2], qk[2]);
-                merge(mk[0], qk[0], mk[2], qk[2], 2.0f * n1, mk[0], qk[0]);
+                merge_eq(mk[2], qk[2], mk[3], qk[3], n1);
+                merge_eq(mk[0], qk[0], mk[2], qk[2], 2.0f * n1);
             }
             stat[tid * 2] = mk[0];
             stat[tid * 2 + 1] = qk[0];
@@ -406,32 +498,14 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
         __syncthreads();
     }
     const float inv_ng = 1.0f / (float)(t_out * gw);
-    const float* const tb = op.tb_off >= 0 ? p.tb_row + op.tb_off + col0 + c4 : nullptr;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         if (!uok[i]) continue;
         const int pr = (uclip[i] * ngl + ugrp) * 2;
         const float m = stat[pr], rstd = 1.0f / sqrtf(stat[pr + 1] * inv_ng + 1e-5f);
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(op.gamma + col0 + c4);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(op.beta + col0 + c4);
         f32x4 o;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) o[x] = mishf((v[i][x] - m) * rstd * g4[x] + b4[x]);
-        if (tb) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(tb);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) o[x] += t4[x];
-        }
-        if (op.res) {
-            const f32x4 r4 = ld16_l2(op.res + (size_t)urow[i] * op.ldres + col0 + c4);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) o[x] += r4[x];
-        }
-        if (op.add2) {
-            const f32x4 r4 = ld16_l2(op.add2 + (size_t)urow[i] * op.ldadd2 + col0 + c4);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) o[x] += r4[x];
-        }
+        for (int x = 0; x < 4; ++x) o[x] = ((mishf((v[i][x] - m) * rstd * g4[x] + be4[x]) + t4[x]) + r4[i][x]) + a4[i][x];
         *reinterpret_cast<f32x4*>(op.dst + (size_t)urow[i] * op.lddst + col0 + c4) = o;
         if (op.dst2) *reinterpret_cast<f32x4*>(op.dst2 + (size_t)urow[i] * op.lddst2 + col0 + c4) = o;
     }
@@ -476,10 +550,36 @@ __global__ __launch_bounds__(256) void traj_resident_kernel(RParams p) {
     if (nx <= 0) return;
     if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // an earlier step's wait expired: the host re-runs the loop
     const unsigned xcc1 = 1u + (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+    // The layer records come from memory ONCE per launch, all of them in one round trip, into LDS: read one by one where they are used,
+    // every layer started with ~1.4 us of scalar-load latency (a launch begins with cold caches; profiles/r6_u_*)
+    unsigned* const lds_ops = reinterpret_cast<unsigned*>(smem + kStage + 1536);
+    {
+        const int words = p.n_ops * (int)(sizeof(ROp) / 4);
+        const unsigned* src = reinterpret_cast<const unsigned*>(p.ops);
+        for (int i = tid; i < words; i += 256) lds_ops[i] = src[i];
+        __syncthreads();
+    }
+    constexpr int W = (int)(sizeof(ROp) / 4);
+    static_assert(sizeof(ROp) % 16 == 0, "layer records are read 16 bytes at a time");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_op = [&](int oi) __attribute__((always_inline)) {      // a layer's record in scalar registers
+        // all 16-byte reads first, then the broadcasts: word by word every read's LDS latency was exposed (~1.4 us per layer)
+        constexpr int Q = W / 4;
+        u32x4 q[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) q[i] = *reinterpret_cast<const u32x4*>(lds_ops + oi * W + i * 4);
+        ROp o;
+        unsigned* dst = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+        for (int i = 0; i < Q; ++i)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) dst[i * 4 + x] = __builtin_amdgcn_readfirstlane(q[i][x]);
+        return o;
+    };
     int sync_idx = 0;
 #pragma unroll 1
     for (int oi = 0; oi < p.n_ops; ++oi) {
-        const ROp& op = p.ops[oi];
+        const ROp op = load_op(oi);
         unsigned long long* const tl = p.timeline ? p.timeline + ((size_t)blockIdx.x * kMaxOps + oi) * 8 : nullptr;
         if (tl != nullptr && threadIdx.x == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
         if (op.kind == 1) {
