@@ -343,7 +343,7 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
 
 /* Which form the last rohm_trajnet_sample_loop of the calling host thread ran in: 0 one launch per layer (the default), 1 the
  * clip-resident step (opt-in ROHM_TRAJ_RESIDENT=1: one launch per denoising step, an XCD's workgroups stay with its clips and meet
- * through its L2 between the layers -- csrc/trajnet_resident.hip; measured slower on MI355X, kept for the record; when it runs
+ * through its L2 between the layers -- csrc/trajnet_resident.hip; measured on a par with form 0 for TrajNet and slower for TrajControl, kept opt-in; when it runs
  * rohm_trajnet_sample_loop waits for the stream once at its end to read the exchange's error word, and a wait that expired hands the
  * call back to form 0 with x restored), 2 the recorded step (opt-in ROHM_TRAJNET_GRAPH=1).  No counterpart in the reference. */
 int rohm_trajnet_loop_mode(void);

@@ -756,11 +756,11 @@ size_t resident_floats(int B, int T) {
 }
 
 bool resident_ok(const rohm_trajnet* h, int B, int T, int n_steps, hipStream_t s) {
-    // Opt-in (ROHM_TRAJ_RESIDENT=1).  Measured on MI355X (profiles/r6_n_*): correct (3e-6 from the launch-per-layer loop, reference
-    // goldens green) but SLOWER -- 65 vs 41 ms per 100 steps for one clip, 81 vs 56 ms for 32, 107 vs 73 for 64: every XCD streams all
-    // 90 MB of weights per step for its own clips (8 x the traffic of the launch-per-layer loop, whose split-K slices read every
-    // weight once chip-wide), and one XCD pulls them at ~0.45 TB/s (eight together 2.3 TB/s): the deep levels -- 85 % of the weights,
-    // 9-18 rows per clip -- are bound by that stream, not by dispatch latency.  See the file header and NOTES section 12.4.
+    // Opt-in (ROHM_TRAJ_RESIDENT=1).  Measured on MI355X (profiles/r6_y_*): correct (3e-6 from the launch-per-layer loop after 100 steps, the
+    // reference's goldens green) and, after the K loop was made to overlap its weight stream, on a par with that loop for TrajNet --
+    // 43.7 vs 41.3 ms per 100 steps at B = 1, 44.1 vs 46.1 at B = 8, 54.3 vs 55.9 at B = 32, 72.0 vs 73.3 at B = 64, with 100 launches per
+    // loop instead of 5 946 -- and 20-25 % slower for TrajControl (its ControlNet branch shares the U-Net's slots here and hides on a
+    // second stream there).  No gain worth a change of default in the last round; see NOTES section 12.4 for where the step's time goes.
     const char* e = getenv("ROHM_TRAJ_RESIDENT");
     if (!(e && e[0] == '1')) return false;
     if (n_steps < 1 || T % 16 != 0 || T > 160 || (T >> 4) < 1 || h->mid % 256 != 0 || h->final_conv.cin > 64 || h->final_conv.cin % 4 != 0) return false;
