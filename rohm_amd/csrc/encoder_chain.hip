@@ -82,8 +82,17 @@ __device__ __forceinline__ void prefetch_w(const float* W, int ldw, int n0, floa
 __device__ __forceinline__ void group_sync(unsigned long long* flags, int tn, int G, unsigned tag, unsigned xcc1, unsigned* err, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are acknowledged by L2
     __syncthreads();
-    if (tid == 0)
+    // The flag by a PLAIN 8-byte store: it stays in the XCD's L2, where the partners' device-scope polls are served.  A device-scope (sc1)
+    // store writes through to the memory side and drops the line from L2, so every poll pays the trip out (measured in
+    // csrc/trajnet_resident.hip: 2.0 -> 1.2 us per 32-partner meeting; here -DROHM_CHAIN_FLAG_SC1 builds the old form for A/B runs).
+    if (tid == 0) {
+#ifdef ROHM_CHAIN_FLAG_SC1
         __hip_atomic_store(flags + tn, ((unsigned long long)xcc1 << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        flags[tn] = ((unsigned long long)xcc1 << 32) | tag;
+        asm volatile("" ::: "memory");
+#endif
+    }
 #ifndef ROHM_CHAIN_NO_MEET      // TIMING experiment only (results may be stale): what do the meetings cost?
     if (tid < G && tid != tn) {
         for (int it = 0;; ++it) {
