@@ -7,8 +7,8 @@
 // is NOT one grid-synchronised kernel.  Instead the dependency structure is used: clips never talk to each other, only the layers of
 // ONE clip do.  An XCD owns a contiguous run of clips for the whole step; its 32 workgroups (block b runs on XCD b % 8) compute every
 // layer of those clips and meet between layers through the flags of encoder_chain.hip's group_sync -- one L2, no cache maintenance:
-// ~1 us per meeting.  Weights are read by every XCD (8 x 90 MB per step at the outside, served by the memory-side cache); activations
-// never leave the owner's L2.
+// ~1.2 us per meeting.  Weights are read by every XCD (8 x 90 MB per step at the outside; one XCD streams at 1.3 TB/s, eight the same
+// data at 6.9 TB/s: scripts/probes/xcd_stream_probe.hip); activations never leave the owner's L2.
 //
 // Work item of a layer = (a run of q clips of the XCD, one block of 16 output channels): the GEMM  rows = q x T_level conv positions,
 // 16 columns, K = taps x C_in.  The INPUT rows of the item are staged once per 64-channel K chunk with a two-row zero halo per clip
@@ -24,6 +24,11 @@
 //
 // Guards: exchange.hip's layout probe (whole device, block b on XCD b % 8), bounded waits that report into an error word; the host
 // checks it at the end of the loop, restores x_T and hands the call to the launch-per-layer loop if a wait expired.
+//
+// Status: opt-in (ROHM_TRAJ_RESIDENT=1).  Measured on a par with the launch-per-layer loop for TrajNet (43.7 / 54.3 ms per 100 steps at
+// B = 1 / 32 against 41.3 / 55.9; 100 launches instead of 5 946) and 20-25 % slower for TrajControl: what replaces 59 kernel boundaries
+// at ~7 us is 30 layers at ~7 us of address set-up, K-split reduction, GroupNorm epilogue and meeting (NOTES.md section 12.4; the kernel
+// prints its own per-layer timeline with ROHM_TRAJ_RESIDENT_TIMELINE=1).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,9 +48,8 @@ constexpr int kAIters = kMaxLdsRows / 16;
 constexpr int kKC = 64;                        // input channels per K chunk
 constexpr int kMaxTaps = 5;
 constexpr int kWRows = (kMaxTaps + 1) * 16;    // weight rows per chunk: taps x 16 columns, + 16 of the 1x1 residual conv
-constexpr int kABuf = kMaxLdsRows * kKC;       // floats
-constexpr int kWBuf = kWRows * kKC;
-constexpr int kStage = 2 * (kABuf + kWBuf);    // two staging buffers; after the K loop the same floats hold the waves' partial tiles
+constexpr int kStage = 2 * (kMaxLdsRows + kWRows) * kKC;      // floats of the staging ring (two stages of the largest item; more, smaller ones
+                                                            // for the deep levels); after the K loop the same floats hold the waves' partial tiles
 constexpr int kRed = 4 * kMaxRows * 16;        // [wave][row][16]
 static_assert(2 * kRed <= kStage, "the partial tiles of conv + residual must fit the staging buffers");
 constexpr int kMaxSync = 64, kMaxItems = 256, kMaxOps = 64, kMaxQ = 16, kMaxStages = 8;
