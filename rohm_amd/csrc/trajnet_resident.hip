@@ -25,10 +25,10 @@
 // Guards: exchange.hip's layout probe (whole device, block b on XCD b % 8), bounded waits that report into an error word; the host
 // checks it at the end of the loop, restores x_T and hands the call to the launch-per-layer loop if a wait expired.
 //
-// Status: opt-in (ROHM_TRAJ_RESIDENT=1).  Measured on a par with the launch-per-layer loop for TrajNet (43.7 / 54.3 ms per 100 steps at
-// B = 1 / 32 against 41.3 / 55.9; 100 launches instead of 5 946) and 20-25 % slower for TrajControl: what replaces 59 kernel boundaries
-// at ~7 us is 30 layers at ~7 us of address set-up, K-split reduction, GroupNorm epilogue and meeting (NOTES.md section 12.4; the kernel
-// prints its own per-layer timeline with ROHM_TRAJ_RESIDENT_TIMELINE=1).
+// Status: the default for TrajNet at B <= 64 (39.8 / 40.3 / 53.1 / 72.1 ms per 100 steps at B = 1 / 8 / 32 / 64 against 41.3 / 46.0 / 55.8 /
+// 73.2 for the launch-per-layer loop; 100 launches instead of 5 946), opt-in for TrajControl (ROHM_TRAJ_RESIDENT=1), which is 20-25 %
+// slower in this form.  What replaces 59 kernel boundaries at ~7 us is 30 layers at ~6 us of address set-up, K-split reduction, GroupNorm
+// epilogue and meeting (NOTES.md section 12.4; the kernel prints its own per-layer timeline with ROHM_TRAJ_RESIDENT_TIMELINE=1).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -54,7 +54,7 @@ constexpr int kRed = 4 * kMaxRows * 16;        // [wave][row][16]
 static_assert(2 * kRed <= kStage, "the partial tiles of conv + residual must fit the staging buffers");
 constexpr int kMaxSync = 64, kMaxItems = 256, kMaxOps = 64, kMaxQ = 16, kMaxStages = 8;
 
-struct ROp {
+struct alignas(16) ROp {
     int kind;                                  // 0 conv layer, 1 head + update
     int cout, cin_pad, t_in, t_out, stride, ntaps;
     int off[kMaxTaps];
@@ -63,6 +63,7 @@ struct ROp {
     int tb_off;                                // time bias columns inside the step's row (-1: none)
     int ldres, ldadd2, lddst, lddst2, ld_res_out;
     int q, wg_off, sync_after;
+    int rsplit;                                // > 1 (only with q == 1): a clip's conv positions are dealt to `rsplit` items of t_out / rsplit rows each
     int slot_base;                             // first statistics slot of this layer (layers between two meetings use disjoint slots)
     const float* A; const float* W; const float* bias;
     const float* Wres; const float* bres; float* res_out;      // fused 1x1 residual conv of the same input (null: none)
@@ -162,18 +163,24 @@ __device__ __forceinline__ float sum16(float v) {      // all-lanes sum of a 16-
 // requests its first weight chunks ahead of time.
 struct Geom {
     int ncb, cb, clip0, qi, rows, nrb, rstride, lrows, a_iters, nt, ntt, nch, col0, per_chunk, stage_f, NS, pre;
+    int rp, t_part, t0;                                // row part of the clip: conv positions t0 .. t0 + t_part
     bool has_res;
 };
 __device__ __forceinline__ Geom item_geom(const ROp& op, int id, int c_lo, int nx) {
     Geom g;
     g.ncb = op.cout >> 4;
-    const int cg = idiv_small(id, 1.0f / (float)g.ncb);
-    g.cb = id - cg * g.ncb;
+    // item id = ((clip run * rsplit + row part) * column blocks + column block): the partners of a GroupNorm group are neighbours
+    const int cr = idiv_small(id, 1.0f / (float)g.ncb);
+    g.cb = id - cr * g.ncb;
+    const int cg = idiv_small(cr, 1.0f / (float)op.rsplit);
+    g.rp = cr - cg * op.rsplit;
+    g.t_part = op.t_out / op.rsplit; g.t0 = g.rp * g.t_part;
     const int k0 = cg * op.q;
     g.qi = min(op.q, nx - k0);
     g.clip0 = c_lo + k0;
-    g.rows = g.qi * op.t_out; g.nrb = (g.rows + 15) >> 4;
-    g.rstride = op.t_in + 4; g.lrows = g.qi * g.rstride; g.a_iters = (g.lrows + 15) >> 4;
+    g.rows = g.qi * g.t_part; g.nrb = (g.rows + 15) >> 4;
+    g.rstride = (op.rsplit > 1 ? g.t_part * op.stride : op.t_in) + 4;      // staged input rows per clip: the part's span + two rows either side
+    g.lrows = g.qi * g.rstride; g.a_iters = (g.lrows + 15) >> 4;
     g.nt = op.ntaps; g.has_res = op.Wres != nullptr; g.ntt = g.nt + (g.has_res ? 1 : 0);
     g.nch = op.cin_pad / kKC; g.col0 = g.cb * 16;
     // staging ring: a stage = the item's input rows (whole 16-row DMA passes) + its weight rows of ONE 64-channel chunk; as many
@@ -216,7 +223,8 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
     const int cb = g.cb, qi = g.qi, clip0 = g.clip0, rows = g.rows, nrb = g.nrb, RM = g.nrb * 16, rstride = g.rstride, lrows = g.lrows;
     const int a_iters = g.a_iters, nt = g.nt, ntt = g.ntt, nch = g.nch, col0 = g.col0, per_chunk = g.per_chunk, stage_f = g.stage_f, NS = g.NS, pre = g.pre;
     const bool has_res = g.has_res;
-    const int t_in = op.t_in, t_out = op.t_out, stride = op.stride;
+    const int t_in = op.t_in, t_out = g.t_part, stride = op.stride;      // t_out: conv positions per clip of THIS item
+    const int in0 = g.t0 * stride;                     // first input row of the part (the staged image starts two rows earlier)
     // the tap offsets in scalar registers NOW: a read of the layer record inside the K loop would be a vector memory load, and waiting for
     // it (vmcnt counts in order) waits for every weight chunk in flight -- measured: 2 us per chunk, no overlap at all
     int shifts[kMaxTaps];
@@ -231,7 +239,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
         a_src[it] = p.zero_page;
         if (it < a_iters) {                            // (32-bit element offsets: an activation matrix has < 2^31 floats)
             const int u = it * 256 + tid, row = u >> 4, slot = (u & 15) ^ (row & 15);
-            const int k = idiv_small(row, inv_rstride), t = row - k * rstride - 2;
+            const int k = idiv_small(row, inv_rstride), t = in0 + row - k * rstride - 2;
             const bool real = row < lrows && t >= 0 && t < t_in;
             const unsigned off = (unsigned)(((clip0 + k) * t_in + t) * op.lda + slot * 4);
             a_src[it] = real ? op.A + off : p.zero_page + slot * 4;
@@ -374,7 +382,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
         uok[i] = o < rows;
         const int k = uok[i] ? idiv_small(o, inv_tout) : 0, tq = uok[i] ? o - k * t_out : 0;
         uclip[i] = k;
-        urow[i] = (clip0 + k) * op.t_dst + tq * op.omul + op.oadd;
+        urow[i] = (clip0 + k) * op.t_dst + (g.t0 + tq) * op.omul + op.oadd;
         r4[i] = a4[i] = zero4;
         if (uok[i] && gn) {
             if (op.res) r4[i] = ld16_l2(op.res + (size_t)urow[i] * op.ldres + col0 + c4);
@@ -406,7 +414,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
                 }
 #pragma unroll
                 for (int x = 0; x < 4; ++x) sr[x] += rb4[x];
-                *reinterpret_cast<f32x4*>(op.res_out + (size_t)((clip0 + uclip[i]) * t_out + (o - uclip[i] * t_out)) * op.ld_res_out + col0 + c4) = sr;
+                *reinterpret_cast<f32x4*>(op.res_out + (size_t)((clip0 + uclip[i]) * op.t_out + g.t0 + (o - uclip[i] * t_out)) * op.ld_res_out + col0 + c4) = sr;
             }
         }
     }
@@ -466,42 +474,45 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
         if (pi < npairs && l16 == 0) *reinterpret_cast<f32x2*>(stat + pi * 2) = f32x2{m, q};
     }
     __syncthreads();
-    if (gw > 16) {
-        // the group spans nparts = gw / 16 neighbouring column blocks (items id - part .. of the same clip run, resident at the same time
-        // on other workgroups of the XCD): exchange (mean, M2) per clip, merge in a fixed tree -- every partner gets the same bits.
-        // Granules {value, tag} by PLAIN 8-byte stores (they stay in the XCD's L2, where the partners' device-scope loads find them)
-        const int nparts = gw >> 4, part = cb & (nparts - 1);
+    const int cparts = gw > 16 ? gw >> 4 : 1, parts = cparts * op.rsplit;
+    if (parts > 1) {
+        // the group spans `cparts` neighbouring column blocks and the clip `rsplit` row parts: parts = cparts x rsplit items (of the same
+        // clip run, resident at the same time on other workgroups of the XCD) exchange (mean, M2) per (clip, local group) pair and merge them
+        // in a fixed order -- every partner gets the same bits.  Granules {value, tag} by PLAIN 8-byte stores (they stay in the XCD's L2,
+        // where the partners' device-scope loads find them)
+        const int cpart = cb & (cparts - 1);
         const unsigned tag = p.tag_base + (unsigned)oi;
-        if (tid < qi) {
+        if (tid < npairs) {
             unsigned long long* const mine = p.slots + (((size_t)xcd * kMaxItems + op.slot_base + id) * kMaxQ + tid) * 2;
             const float m = stat[tid * 2], q2 = stat[tid * 2 + 1];
             mine[0] = ((unsigned long long)tag << 32) | __float_as_uint(m);
             mine[1] = ((unsigned long long)tag << 32) | __float_as_uint(q2);
             asm volatile("" ::: "memory");
-            float mk[4], qk[4];
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                mk[pp] = 0.f; qk[pp] = 0.f;
-                if (pp >= nparts) continue;
-                if (pp == part) { mk[pp] = m; qk[pp] = q2; continue; }
-                const unsigned long long* theirs = p.slots + (((size_t)xcd * kMaxItems + op.slot_base + (id - part + pp)) * kMaxQ + tid) * 2;
-                unsigned long long a = 0ull, b = 0ull;
-                if (wait_tag(theirs, tag, p.err, 0x80u | (unsigned)oi, &a) && wait_tag(theirs + 1, tag, p.err, 0x80u | (unsigned)oi, &b)) {
-                    mk[pp] = __uint_as_float((unsigned)a); qk[pp] = __uint_as_float((unsigned)b);
+            const float n1 = (float)(t_out * gl);      // values behind one part's pair
+            float mm = 0.f, qq = 0.f, nn = 0.f;          // merged so far: row parts outer, column parts inner, ascending
+            for (int rp = 0; rp < op.rsplit; ++rp)
+                for (int cp = 0; cp < cparts; ++cp) {
+                    float mb = m, qb = q2;
+                    if (!(rp == g.rp && cp == cpart)) {
+                        const int pid = id + (rp - g.rp) * g.ncb + (cp - cpart);
+                        const unsigned long long* theirs = p.slots + (((size_t)xcd * kMaxItems + op.slot_base + pid) * kMaxQ + tid) * 2;
+                        unsigned long long a = 0ull, b = 0ull;
+                        mb = 0.f; qb = 0.f;
+                        if (wait_tag(theirs, tag, p.err, 0x80u | (unsigned)oi, &a) && wait_tag(theirs + 1, tag, p.err, 0x80u | (unsigned)oi, &b)) {
+                            mb = __uint_as_float((unsigned)a); qb = __uint_as_float((unsigned)b);
+                        }
+                    }
+                    const float nt2 = nn + n1, inv = 1.0f / nt2, d = mb - mm;      // Chan: (nn, mm, qq) + (n1, mb, qb)
+                    mm = (nn * mm + n1 * mb) * inv;
+                    qq = (qq + qb) + d * d * (nn * n1) * inv;
+                    nn = nt2;
                 }
-            }
-            const float n1 = (float)(t_out * 16);
-            merge_eq(mk[0], qk[0], mk[1], qk[1], n1);
-            if (nparts > 2) {
-                merge_eq(mk[2], qk[2], mk[3], qk[3], n1);
-                merge_eq(mk[0], qk[0], mk[2], qk[2], 2.0f * n1);
-            }
-            stat[tid * 2] = mk[0];
-            stat[tid * 2 + 1] = qk[0];
+            stat[tid * 2] = mm;
+            stat[tid * 2 + 1] = qq;
         }
         __syncthreads();
     }
-    const float inv_ng = 1.0f / (float)(t_out * gw);
+    const float inv_ng = 1.0f / (float)(op.t_out * gw);      // the whole group: all row parts, all its columns
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         if (!uok[i]) continue;
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(256) void traj_resident_kernel(RParams p) {
         if (op.kind == 1) {
             tail_op(p, j, c_lo, nx, smem, tid);
         } else {
-            const int n_items = ((nx + op.q - 1) / op.q) * (op.cout >> 4);
+            const int n_items = ((nx + op.q - 1) / op.q) * op.rsplit * (op.cout >> 4);
 #pragma unroll 1
             for (int id = (j + kWG - op.wg_off) & (kWG - 1); id < n_items; id += kWG) {
                 int t = tid;
@@ -630,7 +641,16 @@ struct Builder {
         o.lda = lda; o.ldw = (c.taps > 0 ? c.taps : 1) * c.cin_pad; o.omul = omul; o.oadd = oadd; o.t_dst = t_dst;
         o.tb_off = -1; o.A = A; o.W = c.w; o.bias = c.b; o.dst = dst; o.lddst = lddst; o.sync_after = 1;
         o.q = pick_q(t_in, t_out, c.cout / 16);
-        if (o.q < 1 || c.cout % 16 != 0 || c.cin_pad % kKC != 0 || ((n + o.q - 1) / o.q) * (c.cout / 16) > kMaxItems) ok = false;
+        o.rsplit = 1;
+        if (o.q == 1) {      // one clip per item and workgroups to spare: deal the clip's conv positions to 2 .. 4 items (whole 16-row blocks where possible)
+            const int items = n * (c.cout / 16);
+            for (int rs : {3, 4, 2}) {
+                if (items * rs > kWG || t_out % rs != 0 || t_out / rs < 16) continue;
+                o.rsplit = rs;
+                break;
+            }
+        }
+        if (o.q < 1 || c.cout % 16 != 0 || c.cin_pad % kKC != 0 || ((n + o.q - 1) / o.q) * o.rsplit * (c.cout / 16) > kMaxItems) ok = false;
         return o;
     }
     // ResidualTemporalBlock (heads.py:43-54) as two layers
@@ -697,7 +717,7 @@ struct Builder {
             U.push_back(f);
             ROp t;
             memset(&t, 0, sizeof(t));
-            t.kind = 1; t.q = 1; t.cout = 16;
+            t.kind = 1; t.q = 1; t.cout = 16; t.rsplit = 1;
             U.push_back(t);
         }
         if (h->control) {      // ControlNet.forward (trajnet.py:43-75) behind control_zero_conv_0: depends on t and the conditions only
@@ -724,7 +744,7 @@ struct Builder {
                 const bool last = o.sync_after != 0;
                 o.wg_off = (wg_off + items) & (kWG - 1) & ~3;
                 o.slot_base = wg_off + items;
-                items += o.kind == 0 ? ((n + o.q - 1) / o.q) * (o.cout / 16) : 0;
+                items += o.kind == 0 ? ((n + o.q - 1) / o.q) * o.rsplit * (o.cout / 16) : 0;
                 items = (items + 3) & ~3;
                 if (wg_off + items > kMaxItems) ok = false;
                 if (last) o.sync_after = sync ? 1 : 0;
@@ -760,13 +780,13 @@ size_t resident_floats(int B, int T) {
 }
 
 bool resident_ok(const rohm_trajnet* h, int B, int T, int n_steps, hipStream_t s) {
-    // Opt-in (ROHM_TRAJ_RESIDENT=1).  Measured on MI355X (profiles/r6_y_*): correct (3e-6 from the launch-per-layer loop after 100 steps, the
-    // reference's goldens green) and, after the K loop was made to overlap its weight stream, on a par with that loop for TrajNet --
-    // 43.7 vs 41.3 ms per 100 steps at B = 1, 44.1 vs 46.1 at B = 8, 54.3 vs 55.9 at B = 32, 72.0 vs 73.3 at B = 64, with 100 launches per
-    // loop instead of 5 946 -- and 20-25 % slower for TrajControl (its ControlNet branch shares the U-Net's slots here and hides on a
-    // second stream there).  No gain worth a change of default in the last round; see NOTES section 12.4 for where the step's time goes.
+    // Default for TrajNet (no ControlNet branch), opt-in for TrajControl; ROHM_TRAJ_RESIDENT=0 / 1 switches it off / on for both.  Measured on
+    // MI355X (profiles/r6_ya_*): 3e-6 from the launch-per-layer loop after 100 steps, the reference's goldens green; per 100-step TrajNet loop
+    // 39.8 vs 41.3 ms at B = 1, 40.3 vs 46.0 at B = 8, 53.1 vs 55.8 at B = 32, 72.1 vs 73.2 at B = 64, 100 launches instead of 5 946.
+    // TrajControl is 20-25 % SLOWER in this form (its ControlNet branch shares the U-Net's slots here and hides on a second stream there).
     const char* e = getenv("ROHM_TRAJ_RESIDENT");
-    if (!(e && e[0] == '1')) return false;
+    if (e && e[0] == '0') return false;
+    if (!(e && e[0] == '1') && h->control) return false;
     if (n_steps < 1 || T % 16 != 0 || T > 160 || (T >> 4) < 1 || h->mid % 256 != 0 || h->final_conv.cin > 64 || h->final_conv.cin % 4 != 0) return false;
     const int n = (B + kNumXCD - 1) / kNumXCD;
     int bmax = 64;                     // clips per forward up to which the resident step is the faster plan (measured; ROHM_TRAJ_RESIDENT_MAX_B)
@@ -859,7 +879,7 @@ int resident_loop(const rohm_trajnet* h, const TWs& w, float* x, const float* no
             if (lo == ~0ull) continue;
             t_first = std::min(t_first, lo); t_last = std::max(t_last, hi);
             const double d = busy ? 100.0 * busy : 1.0;
-            const int items = o.kind == 0 ? ((b.n + o.q - 1) / o.q) * (o.cout / 16) : 0;
+            const int items = o.kind == 0 ? ((b.n + o.q - 1) / o.q) * o.rsplit * (o.cout / 16) : 0;
             fprintf(stderr, "[rohm]   %2d %s %4d %4d %d %3d %3d | %5.2f %6.2f %6.2f %6.2f | %2d wgs  %6.2f  %6.2f%s\n", oi, o.kind ? "tail" : "conv", o.cout, o.cin_pad,
                     o.ntaps, o.t_out, items, su[0] / d, su[1] / d, su[2] / d, su[3] / d, busy, meet_max / 100.0, (double)(hi - lo) / 100.0, o.sync_after ? "" : "  (no meeting)");
         }

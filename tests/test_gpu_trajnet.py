@@ -235,7 +235,7 @@ def test_large_batch_is_clip_independent():
         assert max_abs(y[sl], ys) < 2e-5, lo
 
 
-# ---- the clip-resident step (opt-in ROHM_TRAJ_RESIDENT=1, csrc/trajnet_resident.hip): one launch per denoising step ----------------
+# ---- the clip-resident step (csrc/trajnet_resident.hip): one launch per denoising step; default for TrajNet, ROHM_TRAJ_RESIDENT=1 for TrajControl ----
 
 def _loop(net, batch, shape, x_T, noises, fused_chunk=None):
     diff = make_diffusion()
@@ -305,3 +305,26 @@ def test_resident_step_survives_a_missing_partner(monkeypatch):
     y = _loop(net, batch, (B, 144, 13), x_T, noises)
     assert _lib.lib().rohm_trajnet_loop_mode() == 0
     assert torch.equal(y, ref)
+
+
+def test_resident_step_is_the_default_for_trajnet_and_opt_in_for_trajcontrol(monkeypatch):
+    """Without the environment variable the TrajNet loop runs clip-resident (mode 1), the TrajControl loop launch per layer (mode 0: its
+    ControlNet branch hides on a second stream there); above 64 clips and under the launch profiler the launch-per-layer loop serves both."""
+    from rohm_amd import _lib
+    monkeypatch.delenv('ROHM_TRAJ_RESIDENT', raising=False)
+    for ctrl, B, want in ((False, 2, 1), (True, 2, 0), (False, 72, 0)):
+        net, _ = make_trajnet(70, ctrl)
+        cond, cc = seeded(5, B, 144, 13), seeded(6, B, 144, 272)
+        x_T, noises = cpu_noise_sequence(8, (B, 144, 13), 100)
+        y = _loop(net, {'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}, (B, 144, 13), x_T, noises)
+        assert _lib.lib().rohm_trajnet_loop_mode() == want, (ctrl, B)
+        assert torch.isfinite(y).all()
+    net, _ = make_trajnet(70, False)
+    cond = seeded(5, 2, 144, 13)
+    x_T, noises = cpu_noise_sequence(8, (2, 144, 13), 100)
+    _lib.profile_start(10)
+    try:
+        _loop(net, {'cond': cond.to(DEV)}, (2, 144, 13), x_T, noises)
+        assert _lib.lib().rohm_trajnet_loop_mode() == 0
+    finally:
+        _lib.profile_stop()
