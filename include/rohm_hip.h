@@ -20,6 +20,8 @@
  *     synchronise: *_create, rohm_exchange_probe, rohm_posenet_set_exchange(h, 1), the status read
  *     rohm_posenet_exchange_status; the stand-alone rohm_gemm_res_layernorm_f32 / rohm_output_process_f32
  *     probe an un-probed device on their FIRST call unless the stream records a graph (see there).
+ *     One loop call does wait: rohm_trajnet_sample_loop in its clip-resident form (TrajNet's default, see rohm_trajnet_loop_mode)
+ *     synchronises `stream` once at its end to read the in-kernel meetings' error word (ROHM_TRAJ_RESIDENT=0 keeps it wait-free).
  *   - handles are immutable after create (documented exceptions, all control calls that must not race with
  *     launches of the same handle: rohm_posenet_set_exchange, rohm_posenet_inject_exchange_fault,
  *     rohm_posenet_set_stack_timeline); calls are re-entrant across streams given distinct workspaces.
@@ -341,11 +343,12 @@ int rohm_trajnet_sample_loop(const rohm_trajnet_t* h, float* x, const float* con
                              float* x_in_last, int n_steps, int B, int T, void* ws, size_t ws_bytes,
                              rohm_stream_t stream);
 
-/* Which form the last rohm_trajnet_sample_loop of the calling host thread ran in: 0 one launch per layer (the default), 1 the
- * clip-resident step (opt-in ROHM_TRAJ_RESIDENT=1: one launch per denoising step, an XCD's workgroups stay with its clips and meet
- * through its L2 between the layers -- csrc/trajnet_resident.hip; measured on a par with form 0 for TrajNet and slower for TrajControl, kept opt-in; when it runs
- * rohm_trajnet_sample_loop waits for the stream once at its end to read the exchange's error word, and a wait that expired hands the
- * call back to form 0 with x restored), 2 the recorded step (opt-in ROHM_TRAJNET_GRAPH=1).  No counterpart in the reference. */
+/* Which form the last rohm_trajnet_sample_loop of the calling host thread ran in: 0 one launch per layer, 1 the clip-resident step (one
+ * launch per denoising step, an XCD's workgroups stay with its clips and meet through its L2 between the layers -- csrc/trajnet_resident.hip:
+ * the default for TrajNet at B <= 64 on a device that passed the exchange probe, opt-in ROHM_TRAJ_RESIDENT=1 for TrajControl, off with
+ * ROHM_TRAJ_RESIDENT=0; when it runs, rohm_trajnet_sample_loop waits for the stream once at its end to read the exchange's error word, and
+ * a wait that expired hands the call back to form 0 with x restored), 2 the recorded step (opt-in ROHM_TRAJNET_GRAPH=1).  No counterpart in
+ * the reference. */
 int rohm_trajnet_loop_mode(void);
 
 /* ------------------------------------------------------------------------- SMPL-X + guidance

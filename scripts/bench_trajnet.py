@@ -99,21 +99,30 @@ def main():
             batch = {'cond': torch.randn(B, 144, 13, device=dev), 'control_cond': torch.randn(B, 144, 272, device=dev)}
             run = lambda: diff.eval_losses(model=net, batch=batch, shape=[B, 144, 13], progress=False, clip_denoised=False,
                                            timestep_respacing='', cond_fn_with_grad=False, compute_loss=False)
-            run()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
+            def timed():
                 run()
-            t_enq = (time.perf_counter() - t0) / 3          # host time to enqueue (the call returns before the GPU is done)
-            torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) / 3
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    run()
+                t_enq = (time.perf_counter() - t0) / 3      # host time to enqueue (the call returns before the GPU is done)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / 3, t_enq
+            keep = os.environ.get('ROHM_TRAJ_RESIDENT')
+            wall_default, _ = timed()                       # the library's default form (TrajNet: one launch per step at B <= 64)
+            os.environ['ROHM_TRAJ_RESIDENT'] = '0'          # the launch-per-layer loop: what the launch profiler below breaks down
+            wall, t_enq = timed()
             _lib.profile_start(1)
             run()
             torch.cuda.synchronize()
             prof = _lib.profile_stop()
             ksum = sum(v['total_ms'] for v in prof.values())
             n = sum(v['launches'] for v in prof.values())
-            res[f'{"control" if ctrl else "vanilla"}_B{B}'] = {'wall_ms': round(wall * 1e3, 2), 'host_enqueue_ms': round(t_enq * 1e3, 2), 'kernel_event_ms': round(ksum, 2),
+            if keep is None:
+                os.environ.pop('ROHM_TRAJ_RESIDENT', None)
+            else:
+                os.environ['ROHM_TRAJ_RESIDENT'] = keep
+            res[f'{"control" if ctrl else "vanilla"}_B{B}'] = {'wall_ms_default_form': round(wall_default * 1e3, 2), 'wall_ms': round(wall * 1e3, 2), 'host_enqueue_ms': round(t_enq * 1e3, 2), 'kernel_event_ms': round(ksum, 2),
                                                                 'launches': n, 'clips_per_s': round(B / wall, 1),
                                                                 'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['total_ms'] / v['launches'] * 1e3, 2),
                                                                                 'share': round(v['total_ms'] / ksum, 3)}
