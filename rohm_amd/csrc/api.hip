@@ -47,6 +47,7 @@ void set_step(int step) { g_active = g_enabled && (step % g_stride == 0); }
 bool enabled() { return g_enabled; }
 static bool g_detail = false;
 bool detail() { return g_detail && g_active; }
+bool detail_requested() { return g_detail && g_enabled; }
 const char* intern(const char* s) {        // stable storage for labels composed at launch time (detail mode only)
     static std::vector<std::string*> pool;
     static std::mutex mu;                  // launches may come from several host threads (one stream each)

@@ -53,6 +53,7 @@ struct Scope {
 void set_step(int step);       // sample loops call this; activates every `stride`-th step
 bool enabled();                // between rohm_profile_start and rohm_profile_stop
 bool detail();                 // rohm_profile_detail(1): GEMM / GroupNorm launches are labelled with their shape
+bool detail_requested();       // ... asked for, in a profiling session (whether or not the current step is a sampled one)
 const char* intern(const char* s);
 }  // namespace prof
 

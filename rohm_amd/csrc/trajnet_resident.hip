@@ -792,7 +792,9 @@ bool resident_ok(const rohm_trajnet* h, int B, int T, int n_steps, hipStream_t s
     int bmax = 64;                     // clips per forward up to which the resident step is the faster plan (measured; ROHM_TRAJ_RESIDENT_MAX_B)
     if (const char* m = getenv("ROHM_TRAJ_RESIDENT_MAX_B")) bmax = atoi(m);
     if (B > bmax || n > res::kMaxQ) return false;
-    if (prof::enabled() || stream_is_capturing(s)) return false;      // the launch profiler's labels and graph capture belong to the launch-per-layer loop
+    // graph capture and the launch profiler's per-shape labels (rohm_profile_detail) belong to the launch-per-layer loop; the plain profiler
+    // brackets the step's one launch (label conv_gemm/resident_step)
+    if (prof::detail_requested() || stream_is_capturing(s)) return false;
     const char* why = nullptr;
     return exchange_layout_state(h->device, &why) == 1;
 }
@@ -811,6 +813,14 @@ int resident_loop(const rohm_trajnet* h, const TWs& w, float* x, const float* no
     Builder b{h, w, B, T, (B + kNumXCD - 1) / kNumXCD};
     b.build();
     if (!b.ok) return ROHM_ERR_UNSUPPORTED;
+    // algorithmic work of a step for the launch profiler: the convolutions' multiply-adds; weights once + every activation written and read once
+    double step_flops = 0.0, step_bytes = 0.0;
+    for (const ROp& o : b.ops) {
+        if (o.kind != 0) continue;
+        const double rows = (double)B * o.t_out, k = (double)o.ntaps * o.cin_pad + (o.Wres ? o.cin_pad : 0);
+        step_flops += 2.0 * rows * o.cout * k;
+        step_bytes += 4.0 * (o.cout * k + (double)B * o.t_in * o.cin_pad + rows * o.cout);
+    }
     // the meeting flags and statistics slots start from zero (a tag is never 0), the error word too; x_T is kept for a re-run
     ROHM_HIP_CHECK(hipMemsetAsync(flags, 0, (res_flags_floats() + res_slots_floats() + 64) * sizeof(float), s));
     ROHM_HIP_CHECK(hipMemcpyAsync(d_ops, b.ops.data(), b.ops.size() * sizeof(ROp), hipMemcpyHostToDevice, s));
@@ -846,7 +856,11 @@ int resident_loop(const rohm_trajnet* h, const TWs& w, float* x, const float* no
         p.c1 = coef[3 * i]; p.c2 = coef[3 * i + 1]; p.sigma = coef[3 * i + 2];
         p.noise = noise ? noise + (size_t)i * n : nullptr;
         p.x0_out = (x0_last && i == n_steps - 1) ? x0_last : nullptr;
-        hipLaunchKernelGGL(traj_resident_kernel, dim3(kNumXCD * kWG), dim3(256), lds, s, p);
+        prof::set_step(i);
+        {
+            prof::Scope ps("conv_gemm/resident_step", step_flops, step_bytes, s);      // the step IS its convolutions: counted with the conv GEMMs
+            hipLaunchKernelGGL(traj_resident_kernel, dim3(kNumXCD * kWG), dim3(256), lds, s, p);
+        }
         ROHM_LAUNCH_CHECK();
     }
     // did every meeting complete?  (one host wait per loop call: 100 steps of work are behind it)

@@ -309,7 +309,8 @@ def test_resident_step_survives_a_missing_partner(monkeypatch):
 
 def test_resident_step_is_the_default_for_trajnet_and_opt_in_for_trajcontrol(monkeypatch):
     """Without the environment variable the TrajNet loop runs clip-resident (mode 1), the TrajControl loop launch per layer (mode 0: its
-    ControlNet branch hides on a second stream there); above 64 clips and under the launch profiler the launch-per-layer loop serves both."""
+    ControlNet branch hides on a second stream there); above 64 clips and under the launch profiler's per-shape detail mode the launch-per-layer
+    loop serves both."""
     from rohm_amd import _lib
     monkeypatch.delenv('ROHM_TRAJ_RESIDENT', raising=False)
     for ctrl, B, want in ((False, 2, 1), (True, 2, 0), (False, 72, 0)):
@@ -319,12 +320,22 @@ def test_resident_step_is_the_default_for_trajnet_and_opt_in_for_trajcontrol(mon
         y = _loop(net, {'cond': cond.to(DEV), 'control_cond': cc.to(DEV)}, (B, 144, 13), x_T, noises)
         assert _lib.lib().rohm_trajnet_loop_mode() == want, (ctrl, B)
         assert torch.isfinite(y).all()
+    # the launch profiler brackets the step's one launch; only its per-shape detail mode needs the launch-per-layer loop
     net, _ = make_trajnet(70, False)
     cond = seeded(5, 2, 144, 13)
     x_T, noises = cpu_noise_sequence(8, (2, 144, 13), 100)
     _lib.profile_start(10)
     try:
         _loop(net, {'cond': cond.to(DEV)}, (2, 144, 13), x_T, noises)
+        assert _lib.lib().rohm_trajnet_loop_mode() == 1
+    finally:
+        prof = _lib.profile_stop()
+    assert prof['conv_gemm/resident_step']['launches'] == 10 and prof['conv_gemm/resident_step']['flops'] > 0
+    _lib.check(_lib.lib().rohm_profile_detail(1), 'rohm_profile_detail')
+    _lib.profile_start(10)
+    try:
+        _loop(net, {'cond': cond.to(DEV)}, (2, 144, 13), x_T, noises)
         assert _lib.lib().rohm_trajnet_loop_mode() == 0
     finally:
         _lib.profile_stop()
+        _lib.check(_lib.lib().rohm_profile_detail(0), 'rohm_profile_detail')
