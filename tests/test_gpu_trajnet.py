@@ -339,3 +339,31 @@ def test_resident_step_is_the_default_for_trajnet_and_opt_in_for_trajcontrol(mon
     finally:
         _lib.profile_stop()
         _lib.check(_lib.lib().rohm_profile_detail(0), 'rohm_profile_detail')
+
+
+@pytest.mark.parametrize('T', [16, 64, 128, 160])
+def test_resident_step_at_other_clip_lengths(monkeypatch, T):
+    """T is not tied to the drivers' 144 frames: the shortest the U-Net takes (16: one row at the deepest level), a power of two, and
+    the longest the resident step stages (160) -- each against the launch-per-layer loop; longer clips fall back to that loop."""
+    from rohm_amd import _lib
+    net, _ = make_trajnet(33, False)
+    B = 3
+    cond = seeded(5, B, T, 13)
+    x_T, noises = cpu_noise_sequence(8, (B, T, 13), 100)
+    batch = {'cond': cond.to(DEV)}
+    monkeypatch.setenv('ROHM_TRAJ_RESIDENT', '0')
+    ref = _loop(net, batch, (B, T, 13), x_T, noises).clone()
+    monkeypatch.delenv('ROHM_TRAJ_RESIDENT')
+    y = _loop(net, batch, (B, T, 13), x_T, noises)
+    assert _lib.lib().rohm_trajnet_loop_mode() == 1
+    assert torch.isfinite(y).all() and max_abs(y, ref) < 2e-5
+
+
+def test_resident_step_leaves_long_clips_to_the_launch_per_layer_loop(monkeypatch):
+    from rohm_amd import _lib
+    monkeypatch.delenv('ROHM_TRAJ_RESIDENT', raising=False)
+    net, _ = make_trajnet(33, False)
+    B, T = 2, 176
+    x_T, noises = cpu_noise_sequence(8, (B, T, 13), 100)
+    y = _loop(net, {'cond': seeded(5, B, T, 13).to(DEV)}, (B, T, 13), x_T, noises)
+    assert _lib.lib().rohm_trajnet_loop_mode() == 0 and torch.isfinite(y).all()
