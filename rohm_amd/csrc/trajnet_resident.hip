@@ -299,15 +299,17 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
             // ... for everybody, and everybody is done with chunk kc - 1 (its fragments were consumed by MFMAs).  A bare s_barrier:
             // __syncthreads() is a fence and waits for vmcnt(0) -- every chunk in flight -- first
             asm volatile("s_barrier" ::: "memory");
-            if (kc + pre < nch) { const int sn = st + pre; dma(sn >= NS ? sn - NS : sn, kc + pre); }      // pre == NS - 1: the stage of chunk kc - 1
             const float* Ab = smem + st * stage_f;
             const float* Wb = Ab + a_iters * 16 * kKC;
-            st = (st + 1 == NS) ? 0 : st + 1;
             f32x4 fw[NTT], fa[2][NRB];
 #pragma unroll
             for (int tp = 0; tp < NTT; ++tp) fw[tp] = *reinterpret_cast<const f32x4*>(Wb + lds_off64(tp * 16 + li, kslot));
 #pragma unroll
             for (int r = 0; r < NRB; ++r) fa[0][r] = *reinterpret_cast<const f32x4*>(Ab + lds_off64(base[r] + (NT > 0 ? shifts[0] : 0), kslot));
+            __builtin_amdgcn_sched_barrier(0);
+            // the request for chunk kc + pre goes out BEHIND the first fragment reads: their LDS latency passes underneath its issue
+            if (kc + pre < nch) { const int sn = st + pre; dma(sn >= NS ? sn - NS : sn, kc + pre); }      // pre == NS - 1: the stage of chunk kc - 1
+            st = (st + 1 == NS) ? 0 : st + 1;
 #pragma unroll
             for (int tp = 0; tp < NTT; ++tp) {
                 if (tp + 1 < NTT) {
