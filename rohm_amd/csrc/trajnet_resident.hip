@@ -96,8 +96,11 @@ struct RParams {
     int fault;                                 // test hook (ROHM_TRAJ_RESIDENT_FAULT=1): workgroup 0 of XCD 0 stays away from the fourth meeting
 };
 
-// x / d for 0 <= x < 4096, d <= 256, inv = 1.0f / d: exact (x + 0.5 is never within float rounding of a multiple of d)
+// x / d for 0 <= x < 65536, quotient <= 64, inv ~ 1 / d: exact (x + 0.5 stays >= 0.5 / d away from every multiple of d, the float error is < 1e-5)
 __device__ __forceinline__ int idiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+// 1 / d for idiv_small (the hardware reciprocal, 1 ulp: far inside idiv_small's margin; a true division is a ten-instruction sequence, and an
+// INTEGER division of two run-time values ~40 dependent ones -- four of them were 0.6 us of every item's set-up)
+__device__ __forceinline__ float rcp_small(int d) { return __builtin_amdgcn_rcpf((float)d); }
 
 __device__ __forceinline__ int lds_off64(int row, int slot) { return row * kKC + ((slot ^ (row & 15)) << 2); }
 
@@ -170,11 +173,11 @@ __device__ __forceinline__ Geom item_geom(const ROp& op, int id, int c_lo, int n
     Geom g;
     g.ncb = op.cout >> 4;
     // item id = ((clip run * rsplit + row part) * column blocks + column block): the partners of a GroupNorm group are neighbours
-    const int cr = idiv_small(id, 1.0f / (float)g.ncb);
+    const int cr = idiv_small(id, rcp_small(g.ncb));
     g.cb = id - cr * g.ncb;
-    const int cg = idiv_small(cr, 1.0f / (float)op.rsplit);
+    const int cg = idiv_small(cr, rcp_small(op.rsplit));
     g.rp = cr - cg * op.rsplit;
-    g.t_part = op.t_out / op.rsplit; g.t0 = g.rp * g.t_part;
+    g.t_part = idiv_small(op.t_out, rcp_small(op.rsplit)); g.t0 = g.rp * g.t_part;
     const int k0 = cg * op.q;
     g.qi = min(op.q, nx - k0);
     g.clip0 = c_lo + k0;
@@ -182,13 +185,14 @@ __device__ __forceinline__ Geom item_geom(const ROp& op, int id, int c_lo, int n
     g.rstride = (op.rsplit > 1 ? g.t_part * op.stride : op.t_in) + 4;      // staged input rows per clip: the part's span + two rows either side
     g.lrows = g.qi * g.rstride; g.a_iters = (g.lrows + 15) >> 4;
     g.nt = op.ntaps; g.has_res = op.Wres != nullptr; g.ntt = g.nt + (g.has_res ? 1 : 0);
-    g.nch = op.cin_pad / kKC; g.col0 = g.cb * 16;
+    g.nch = op.cin_pad >> 6; g.col0 = g.cb * 16;
+    static_assert(kKC == 64, "chunk count by shift");
     // staging ring: a stage = the item's input rows (whole 16-row DMA passes) + its weight rows of ONE 64-channel chunk; as many
     // stages as the LDS holds (2 at level 0 .. 8 for a 1x1 conv at the deep levels): a deep-level layer (8 .. 16 chunks of < 1 us of
     // MFMAs each) lives on the chunks in flight
     g.per_chunk = g.a_iters + g.ntt;                   // DMA instructions per chunk and wave
     g.stage_f = g.per_chunk * 16 * kKC;
-    int NS = min(kMaxStages, kStage / g.stage_f);
+    int NS = min(kMaxStages, idiv_small(kStage, rcp_small(g.stage_f)));
     NS = min(NS, g.nch + 1);
     while (NS > 2 && (NS - 2) * g.per_chunk > 63) --NS;      // s_waitcnt vmcnt counts to 63
     g.NS = NS;
@@ -231,7 +235,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
 #pragma unroll
     for (int tp = 0; tp < kMaxTaps; ++tp) shifts[tp] = __builtin_amdgcn_readfirstlane(op.off[tp]);
     // ---- operand addresses of chunk 0 (16-byte units; unit u of a DMA pass lands at LDS position u: the global side is swizzled) ------
-    const float inv_rstride = 1.0f / (float)rstride;
+    const float inv_rstride = rcp_small(rstride);
     const float* a_src[kAIters];
     unsigned a_real = 0u;                              // bit it: this lane's unit of pass it is a real input row (else: halo / padding -> zeros)
 #pragma unroll
@@ -261,7 +265,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
     // ---- fragment rows: conv position o = 16 r + li of the item -> staged row of its centre tap ------------------------------------
     int base[kMaxRB];
     {
-        const float inv_t = 1.0f / (float)t_out;
+        const float inv_t = rcp_small(t_out);
 #pragma unroll
         for (int r = 0; r < kMaxRB; ++r) {
             base[r] = 2;
@@ -363,7 +367,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
     const int c4 = (tid & 3) * 4;
     const bool gn = op.gn != 0;
     const float* const tb = (gn && op.tb_off >= 0) ? p.tb_row + op.tb_off + col0 + c4 : nullptr;
-    const float inv_tout = 1.0f / (float)t_out;
+    const float inv_tout = rcp_small(t_out);
     int urow[NU], uclip[NU];
     bool uok[NU];
     // every operand of the epilogue is requested NOW (partner-written ones past the L1): they land underneath the sums and the statistics
@@ -456,7 +460,7 @@ __device__ __forceinline__ void conv_item(const RParams& p, const ROp& op, const
         const float fgl = (float)gl;
         float r = 0.f, m = 0.f, q = 0.f;                         // rows merged so far, their mean, their M2
         if (pi < npairs) {
-            const int k = idiv_small(pi, 1.0f / (float)ngl), g = pi - k * ngl;
+            const int k = idiv_small(pi, rcp_small(ngl)), g = pi - k * ngl;
             for (int t = l16; t < t_out; t += 16) {
                 const f32x2 row = *reinterpret_cast<const f32x2*>(rowst + ((k * t_out + t) * 4 + g) * 2);
                 const float d = row[0] - m, rn = r + 1.0f, inv = 1.0f / rn;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(256) void traj_resident_kernel(RParams p) {
         if (op.kind == 1) {
             tail_op(p, j, c_lo, nx, smem, tid);
         } else {
-            const int n_items = ((nx + op.q - 1) / op.q) * op.rsplit * (op.cout >> 4);
+            const int n_items = idiv_small(nx + op.q - 1, rcp_small(op.q)) * op.rsplit * (op.cout >> 4);
 #pragma unroll 1
             for (int id = (j + kWG - op.wg_off) & (kWG - 1); id < n_items; id += kWG) {
                 int t = tid;
