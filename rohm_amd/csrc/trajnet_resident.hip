@@ -25,8 +25,8 @@
 // Guards: exchange.hip's layout probe (whole device, block b on XCD b % 8), bounded waits that report into an error word; the host
 // checks it at the end of the loop, restores x_T and hands the call to the launch-per-layer loop if a wait expired.
 //
-// Status: the default for TrajNet at B <= 64 (39.8 / 40.3 / 53.1 / 72.1 ms per 100 steps at B = 1 / 8 / 32 / 64 against 41.3 / 46.0 / 55.8 /
-// 73.2 for the launch-per-layer loop; 100 launches instead of 5 946), opt-in for TrajControl (ROHM_TRAJ_RESIDENT=1), which is 20-25 %
+// Status: the default for TrajNet at B <= 64 (38.4 / 38.8 / 52.3 / 69.9 ms per 100 steps at B = 1 / 8 / 32 / 64 against 41.3 / 46.1 / 55.8 /
+// 73.4 for the launch-per-layer loop; 100 launches instead of 5 946), opt-in for TrajControl (ROHM_TRAJ_RESIDENT=1), which is 20-25 %
 // slower in this form.  What replaces 59 kernel boundaries at ~7 us is 30 layers at ~6 us of address set-up, K-split reduction, GroupNorm
 // epilogue and meeting (NOTES.md section 12.4; the kernel prints its own per-layer timeline with ROHM_TRAJ_RESIDENT_TIMELINE=1).
 #include <stdio.h>
@@ -787,8 +787,8 @@ size_t resident_floats(int B, int T) {
 
 bool resident_ok(const rohm_trajnet* h, int B, int T, int n_steps, hipStream_t s) {
     // Default for TrajNet (no ControlNet branch), opt-in for TrajControl; ROHM_TRAJ_RESIDENT=0 / 1 switches it off / on for both.  Measured on
-    // MI355X (profiles/r6_ya_*): 3e-6 from the launch-per-layer loop after 100 steps, the reference's goldens green; per 100-step TrajNet loop
-    // 39.8 vs 41.3 ms at B = 1, 40.3 vs 46.0 at B = 8, 53.1 vs 55.8 at B = 32, 72.1 vs 73.2 at B = 64, 100 launches instead of 5 946.
+    // MI355X (profiles/r6_yd_*): 3e-6 from the launch-per-layer loop after 100 steps, the reference's goldens green; per 100-step TrajNet loop
+    // 38.4 vs 41.3 ms at B = 1, 38.8 vs 46.1 at B = 8, 52.3 vs 55.8 at B = 32, 69.9 vs 73.4 at B = 64, 100 launches instead of 5 946.
     // TrajControl is 20-25 % SLOWER in this form (its ControlNet branch shares the U-Net's slots here and hides on a second stream there).
     const char* e = getenv("ROHM_TRAJ_RESIDENT");
     if (e && e[0] == '0') return false;
